@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: forward Merge NTT, 64-bit, N = 2^16, batch = 1024 per GPU.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one gpuntt GPU_NTT call (all of its kernel launches) over one batch of synthetic
+random polynomials already resident in HBM.  Rank r owns its own batch (weak scaling, no
+data-path collective: polynomials are independent); the only collectives are
+the timing barrier and the max-reduction of the elapsed time.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for the roofline arithmetic).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import _load_pkg  # noqa: E402
+
+LOGN = 16
+BATCH = 1024
+BITS = 64
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+METRIC = "forward-NTTs/sec + achieved HBM GB/s, 64-bit Merge N=2^16 batch=1024"
+
+
+def cpu_baseline(P_mod_value, x_sample, logn):
+    """Times the CPU path on a bounded sample of the same workload on this host:
+    oracle/_ref (the reference's own NTTCPU::ntt, kind 'reference') when the prebuilt file is
+    present, else this repo's C restatement (kind 'port')."""
+    from oracle import oracle as O
+    n = 1 << logn
+    polys = x_sample.size // n
+    if O.have_ref():
+        R = O.Ref(BITS)
+        prm = R.merge_params(logn, O.X_N_minus)
+        assert prm["mod"][0] == P_mod_value
+        R.merge_ntt(x_sample[:n], prm)  # warm
+        t0 = time.perf_counter()
+        R.merge_ntt(x_sample, prm)
+        dt = time.perf_counter() - t0
+        kind = "reference"
+    else:
+        P = O.Port(BITS)
+        prm = P.merge_params(logn, O.X_N_minus)
+        P.merge_ntt(x_sample[:n], prm)
+        t0 = time.perf_counter()
+        P.merge_ntt(x_sample, prm)
+        dt = time.perf_counter() - t0
+        kind = "port"
+    return {"value": polys / dt, "unit": "NTT/s", "cores": 1, "kind": kind,
+            "sample": "%d of the %d polynomials of one batch (u64, N=2^%d), NTTCPU::ntt single thread, %.1f s"
+                      % (polys, BATCH, logn, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-polys", type=int, default=4096)
+    args = ap.parse_args()
+
+    import torch
+    g = _load_pkg()
+    g.load_library()  # raises if the HIP extension is missing: there is no fallback
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    torch.cuda.set_device(local_rank)
+    dev = "cuda:%d" % local_rank
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device(dev))
+
+    from oracle import oracle as O
+    P = O.Port(BITS)
+    prm = g.NTTParameters(LOGN, g.X_N_minus, BITS)
+    n = 1 << LOGN
+    # synthetic input x[p][i] = splitmix64(seed ^ (p*N+i)) mod q, seed per rank
+    x = P.splitmix(0x5EED0002 + rank, 0, BATCH * n, prm.modulus.value)
+    d_in = g.to_device(x, dev)
+    d_out = torch.empty_like(d_in)
+    table = g.to_device(prm.forward_table_device_order, dev)
+    cfg = g.ntt_configuration(n_power=LOGN, ntt_type=g.FORWARD, reduction_poly=g.X_N_minus)
+
+    def step():
+        g.GPU_NTT(d_in, d_out, table, prm.modulus, cfg, BATCH)
+
+    # correctness gate on the benchmarked configuration (a few polynomials vs the oracle)
+    step()
+    torch.cuda.synchronize()
+    y = g.to_host(d_out)
+    oprm = P.merge_params(LOGN, O.X_N_minus)
+    for p in (0, BATCH - 1):
+        if not np.array_equal(y[p * n:(p + 1) * n], P.merge_ntt(x[p * n:(p + 1) * n], oprm)):
+            raise SystemExit("bench: GPU result differs from the oracle -- refusing to time")
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    dev_ms = e0.elapsed_time(e1)  # HIP events on the stream the kernels ran on
+    if dist is not None:
+        t = torch.tensor([wall, dev_ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall, dev_ms = float(t[0]), float(t[1])
+
+    if rank == 0:
+        ms_per_step = wall * 1e3 / args.steps
+        call_ms = dev_ms / args.steps
+        alg_bytes = 2 * n * (BITS // 8) * BATCH  # every coefficient read once + written once
+        achieved = alg_bytes / (call_ms * 1e-3) / 1e9
+        line = {
+            "metric": METRIC,
+            "value": world * BATCH * args.steps / wall,
+            "unit": "NTT/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u64",
+            "data": "synthetic",
+            "config": {"workload": "Merge-NTT Data64 log2N=16 batch=1024 forward (BASELINE configs[1])",
+                       "log2N": LOGN, "batch_per_gpu": BATCH, "reduction_poly": "X_N_minus",
+                       "modulus": prm.modulus.value, "out_of_place": True,
+                       "parallelism": "batch-shard x%d" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_call": alg_bytes,
+                         "call_ms_hip_events": call_ms,
+                         "note": "one call = all kernel launches of one GPU_NTT (strided pass + "
+                                 "contiguous pass); per-kernel durations in profiles/"},
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(prm.modulus.value, x[:args.cpu_polys * n], LOGN)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,338 @@
+// c_api.cpp -- extern "C" boundary (include/gpuntt_c.h) over the C++ template API.
+#include <cstring>
+#include <exception>
+#include <stdexcept>
+#include <string>
+
+#include "gpuntt/ntt_4step/ntt_4step.cuh"
+#include "gpuntt/ntt_merge/ntt.cuh"
+#include "gpuntt_c.h"
+
+using namespace gpuntt;
+
+namespace
+{
+    thread_local std::string g_last_error;
+
+    template <typename F> int guarded(F&& f)
+    {
+        try
+        {
+            f();
+            return GPUNTT_OK;
+        }
+        catch (const std::invalid_argument& e)
+        {
+            g_last_error = e.what();
+            return GPUNTT_ERR_INVALID_ARGUMENT;
+        }
+        catch (const HipException& e)
+        {
+            g_last_error = e.what();
+            return GPUNTT_ERR_HIP;
+        }
+        catch (const std::exception& e)
+        {
+            g_last_error = e.what();
+            return GPUNTT_ERR_UNKNOWN;
+        }
+    }
+
+    template <typename T, typename CM> Modulus<T> to_mod(const CM& m)
+    {
+        Modulus<T> r;
+        r.value = m.value;
+        r.bit = m.bit;
+        r.mu = m.mu;
+        return r;
+    }
+
+    template <typename T, typename CM>
+    int ntt_single(const void* in, T* out, const T* roots, CM modulus, int n_power, int layout,
+                   int poly, int input_signed, void* stream, int batch)
+    {
+        using S = typename std::make_signed<T>::type;
+        return guarded([&] {
+            ntt_configuration<T> cfg = {n_power,
+                                        FORWARD,
+                                        static_cast<NTTLayout>(layout),
+                                        static_cast<ReductionPolynomial>(poly),
+                                        false,
+                                        0,
+                                        static_cast<hipStream_t>(stream)};
+            if (input_signed)
+                GPU_NTT<S>(static_cast<S*>(const_cast<void*>(in)), out, const_cast<T*>(roots),
+                           to_mod<T>(modulus), cfg, batch);
+            else
+                GPU_NTT<T>(static_cast<T*>(const_cast<void*>(in)), out, const_cast<T*>(roots),
+                           to_mod<T>(modulus), cfg, batch);
+        });
+    }
+
+    template <typename T, typename CM>
+    int intt_single(const T* in, void* out, const T* roots, CM modulus, int n_power, int layout,
+                    int poly, T mod_inverse, int output_signed, void* stream, int batch)
+    {
+        using S = typename std::make_signed<T>::type;
+        return guarded([&] {
+            ntt_configuration<T> cfg = {n_power,
+                                        INVERSE,
+                                        static_cast<NTTLayout>(layout),
+                                        static_cast<ReductionPolynomial>(poly),
+                                        false,
+                                        mod_inverse,
+                                        static_cast<hipStream_t>(stream)};
+            if (output_signed)
+                GPU_INTT<S>(const_cast<T*>(in), static_cast<S*>(out), const_cast<T*>(roots),
+                            to_mod<T>(modulus), cfg, batch);
+            else
+                GPU_INTT<T>(const_cast<T*>(in), static_cast<T*>(out), const_cast<T*>(roots),
+                            to_mod<T>(modulus), cfg, batch);
+        });
+    }
+
+    template <typename T, typename CM>
+    int ntt_rns(const void* in, T* out, const T* roots, const CM* modulus, int n_power, int layout,
+                int poly, int input_signed, void* stream, int batch, int mod_count)
+    {
+        using S = typename std::make_signed<T>::type;
+        static_assert(sizeof(CM) == sizeof(Modulus<T>), "C and C++ modulus layouts differ");
+        return guarded([&] {
+            ntt_rns_configuration<T> cfg = {n_power,
+                                            FORWARD,
+                                            static_cast<NTTLayout>(layout),
+                                            static_cast<ReductionPolynomial>(poly),
+                                            false,
+                                            nullptr,
+                                            static_cast<hipStream_t>(stream)};
+            auto* mods = reinterpret_cast<Modulus<T>*>(const_cast<CM*>(modulus));
+            if (input_signed)
+                GPU_NTT<S>(static_cast<S*>(const_cast<void*>(in)), out, const_cast<T*>(roots), mods,
+                           cfg, batch, mod_count);
+            else
+                GPU_NTT<T>(static_cast<T*>(const_cast<void*>(in)), out, const_cast<T*>(roots), mods,
+                           cfg, batch, mod_count);
+        });
+    }
+
+    template <typename T, typename CM>
+    int intt_rns(const T* in, void* out, const T* roots, const CM* modulus, int n_power, int layout,
+                 int poly, const T* mod_inverse, int output_signed, void* stream, int batch,
+                 int mod_count)
+    {
+        using S = typename std::make_signed<T>::type;
+        return guarded([&] {
+            ntt_rns_configuration<T> cfg = {n_power,
+                                            INVERSE,
+                                            static_cast<NTTLayout>(layout),
+                                            static_cast<ReductionPolynomial>(poly),
+                                            false,
+                                            const_cast<T*>(mod_inverse),
+                                            static_cast<hipStream_t>(stream)};
+            auto* mods = reinterpret_cast<Modulus<T>*>(const_cast<CM*>(modulus));
+            if (output_signed)
+                GPU_INTT<S>(const_cast<T*>(in), static_cast<S*>(out), const_cast<T*>(roots), mods,
+                            cfg, batch, mod_count);
+            else
+                GPU_INTT<T>(const_cast<T*>(in), static_cast<T*>(out), const_cast<T*>(roots), mods,
+                            cfg, batch, mod_count);
+        });
+    }
+
+    template <typename T, typename CM>
+    int fourstep_single(const T* in, T* out, const T* t1, const T* t2, const T* w, CM modulus,
+                        int n_power, int ntt_type, T mod_inverse, void* stream, int batch)
+    {
+        return guarded([&] {
+            ntt4step_configuration<T> cfg = {n_power, static_cast<type>(ntt_type), mod_inverse,
+                                             static_cast<hipStream_t>(stream)};
+            GPU_4STEP_NTT<T>(const_cast<T*>(in), out, const_cast<T*>(t1), const_cast<T*>(t2),
+                             const_cast<T*>(w), to_mod<T>(modulus), cfg, batch);
+        });
+    }
+
+    template <typename T, typename CM>
+    int fourstep_rns(const T* in, T* out, const T* t1, const T* t2, const T* w, const CM* modulus,
+                     int n_power, int ntt_type, const T* mod_inverse, void* stream, int batch,
+                     int mod_count)
+    {
+        return guarded([&] {
+            ntt4step_rns_configuration<T> cfg = {n_power, static_cast<type>(ntt_type),
+                                                 const_cast<T*>(mod_inverse),
+                                                 static_cast<hipStream_t>(stream)};
+            GPU_4STEP_NTT<T>(const_cast<T*>(in), out, const_cast<T*>(t1), const_cast<T*>(t2),
+                             const_cast<T*>(w),
+                             reinterpret_cast<Modulus<T>*>(const_cast<CM*>(modulus)), cfg, batch,
+                             mod_count);
+        });
+    }
+
+    template <typename T>
+    int merge_params(int logn, int poly, const T* factors, uint64_t* info, T* fwd, T* inv)
+    {
+        return guarded([&] {
+            if (poly != GPUNTT_X_N_PLUS && poly != GPUNTT_X_N_MINUS)
+                throw std::invalid_argument("Invalid reduction_poly!");
+            const auto rp = static_cast<ReductionPolynomial>(poly);
+            NTTParameters<T> p = factors ? NTTParameters<T>(logn,
+                                                            NTTFactors<T>(Modulus<T>(factors[0]),
+                                                                          factors[1], factors[2]),
+                                                            rp)
+                                         : NTTParameters<T>(logn, rp);
+            if (info)
+            {
+                info[0] = p.modulus.value;
+                info[1] = p.modulus.bit;
+                info[2] = p.modulus.mu;
+                info[3] = p.omega;
+                info[4] = p.psi;
+                info[5] = p.n_inv;
+                info[6] = p.root_of_unity_size;
+                info[7] = p.n;
+            }
+            if (fwd)
+            {
+                auto t = p.gpu_root_of_unity_table_generator(p.forward_root_of_unity_table);
+                std::memcpy(fwd, t.data(), t.size() * sizeof(T));
+            }
+            if (inv)
+            {
+                auto t = p.gpu_root_of_unity_table_generator(p.inverse_root_of_unity_table);
+                std::memcpy(inv, t.data(), t.size() * sizeof(T));
+            }
+        });
+    }
+
+    template <typename T>
+    int fourstep_params(int logn, int inverse, uint64_t* info, T* t1, T* t2, T* w)
+    {
+        return guarded([&] {
+            NTTParameters4Step<T> p(logn, ReductionPolynomial::X_N_minus);
+            if (info)
+            {
+                info[0] = p.modulus.value;
+                info[1] = p.modulus.bit;
+                info[2] = p.modulus.mu;
+                info[3] = p.omega;
+                info[4] = p.psi;
+                info[5] = p.n_inv;
+                info[6] = p.n1;
+                info[7] = p.n2;
+                info[8] = p.n;
+            }
+            if (t1)
+            {
+                auto t = p.gpu_root_of_unity_table_generator(
+                    inverse ? p.n1_based_inverse_root_of_unity_table : p.n1_based_root_of_unity_table);
+                std::memcpy(t1, t.data(), t.size() * sizeof(T));
+            }
+            if (t2)
+            {
+                auto t = p.gpu_root_of_unity_table_generator(
+                    inverse ? p.n2_based_inverse_root_of_unity_table : p.n2_based_root_of_unity_table);
+                std::memcpy(t2, t.data(), t.size() * sizeof(T));
+            }
+            if (w)
+            {
+                const auto& t = inverse ? p.W_inverse_root_of_unity_table : p.W_root_of_unity_table;
+                std::memcpy(w, t.data(), t.size() * sizeof(T));
+            }
+        });
+    }
+} // namespace
+
+extern "C"
+{
+    const char* gpuntt_last_error(void) { return g_last_error.c_str(); }
+    int gpuntt_version(void) { return 100; }
+
+    int gpuntt_modulus_u32(uint32_t q, gpuntt_modulus32* out)
+    {
+        return guarded([&] {
+            if (!out || q < 2)
+                throw std::invalid_argument("Invalid modulus!");
+            Modulus<Data32> m(q);
+            out->value = m.value;
+            out->bit = m.bit;
+            out->mu = m.mu;
+        });
+    }
+    int gpuntt_modulus_u64(uint64_t q, gpuntt_modulus64* out)
+    {
+        return guarded([&] {
+            if (!out || q < 2)
+                throw std::invalid_argument("Invalid modulus!");
+            Modulus<Data64> m(q);
+            out->value = m.value;
+            out->bit = m.bit;
+            out->mu = m.mu;
+        });
+    }
+
+#define GPUNTT_C_API(S, T, CM)                                                                    \
+    int gpuntt_ntt_##S(const void* in, T* out, const T* roots, CM modulus, int n_power,           \
+                       int ntt_layout, int reduction_poly, int input_signed, void* stream,        \
+                       int batch_size)                                                            \
+    {                                                                                             \
+        return ntt_single<T>(in, out, roots, modulus, n_power, ntt_layout, reduction_poly,        \
+                             input_signed, stream, batch_size);                                   \
+    }                                                                                             \
+    int gpuntt_intt_##S(const T* in, void* out, const T* inverse_roots, CM modulus, int n_power,  \
+                        int ntt_layout, int reduction_poly, T mod_inverse, int output_signed,     \
+                        void* stream, int batch_size)                                             \
+    {                                                                                             \
+        return intt_single<T>(in, out, inverse_roots, modulus, n_power, ntt_layout,               \
+                              reduction_poly, mod_inverse, output_signed, stream, batch_size);    \
+    }                                                                                             \
+    int gpuntt_ntt_rns_##S(const void* in, T* out, const T* roots, const CM* modulus,             \
+                           int n_power, int ntt_layout, int reduction_poly, int input_signed,     \
+                           void* stream, int batch_size, int mod_count)                           \
+    {                                                                                             \
+        return ntt_rns<T>(in, out, roots, modulus, n_power, ntt_layout, reduction_poly,           \
+                          input_signed, stream, batch_size, mod_count);                           \
+    }                                                                                             \
+    int gpuntt_intt_rns_##S(const T* in, void* out, const T* inverse_roots, const CM* modulus,    \
+                            int n_power, int ntt_layout, int reduction_poly,                      \
+                            const T* mod_inverse, int output_signed, void* stream,                \
+                            int batch_size, int mod_count)                                        \
+    {                                                                                             \
+        return intt_rns<T>(in, out, inverse_roots, modulus, n_power, ntt_layout, reduction_poly,  \
+                           mod_inverse, output_signed, stream, batch_size, mod_count);            \
+    }                                                                                             \
+    int gpuntt_4step_##S(const T* in, T* out, const T* n1_table, const T* n2_table,               \
+                         const T* w_table, CM modulus, int n_power, int ntt_type, T mod_inverse,  \
+                         void* stream, int batch_size)                                            \
+    {                                                                                             \
+        return fourstep_single<T>(in, out, n1_table, n2_table, w_table, modulus, n_power,         \
+                                  ntt_type, mod_inverse, stream, batch_size);                     \
+    }                                                                                             \
+    int gpuntt_4step_rns_##S(const T* in, T* out, const T* n1_table, const T* n2_table,           \
+                             const T* w_table, const CM* modulus, int n_power, int ntt_type,      \
+                             const T* mod_inverse, void* stream, int batch_size, int mod_count)   \
+    {                                                                                             \
+        return fourstep_rns<T>(in, out, n1_table, n2_table, w_table, modulus, n_power, ntt_type,  \
+                               mod_inverse, stream, batch_size, mod_count);                       \
+    }                                                                                             \
+    int gpuntt_transpose_##S(const T* in, T* out, int row, int col, int n_power, int batch_size)  \
+    {                                                                                             \
+        return guarded(                                                                           \
+            [&] { GPU_Transpose<T>(const_cast<T*>(in), out, row, col, n_power, batch_size); });   \
+    }                                                                                             \
+    int gpuntt_merge_params_##S(int logn, int reduction_poly, const T* factors_host,              \
+                                uint64_t* info_host, T* forward_table_host,                       \
+                                T* inverse_table_host)                                            \
+    {                                                                                             \
+        return merge_params<T>(logn, reduction_poly, factors_host, info_host,                     \
+                               forward_table_host, inverse_table_host);                           \
+    }                                                                                             \
+    int gpuntt_4step_params_##S(int logn, int inverse, uint64_t* info_host, T* n1_table_host,     \
+                                T* n2_table_host, T* w_table_host)                                \
+    {                                                                                             \
+        return fourstep_params<T>(logn, inverse, info_host, n1_table_host, n2_table_host,         \
+                                  w_table_host);                                                  \
+    }
+
+    GPUNTT_C_API(u32, uint32_t, gpuntt_modulus32)
+    GPUNTT_C_API(u64, uint64_t, gpuntt_modulus64)
+#undef GPUNTT_C_API
+}

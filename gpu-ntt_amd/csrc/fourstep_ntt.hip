@@ -1,0 +1,190 @@
+// fourstep_ntt.hip -- 4-Step NTT entry points (gpuntt::GPU_4STEP_NTT, GPU_Transpose).
+//
+// Replaces reference src/lib/ntt_4step/ntt_4step.cu:36-66 (transpose), :68-2291 (kernels),
+// :2293-3229 (hosts), :3292-3302 / :3606-3634 (exported instantiations).
+//
+// MI355X plan for N = n1 x n2 (shapes of NTTParameters4Step, nttparameters.cu:305-354):
+//   phase 1  one fused kernel: n1-point transform of every row of the n2 x n1 input inside a
+//            4096-coefficient tile, transposed store into the n1 x n2 output with the
+//            W[i*n2+j] multiply fused (merge_pass<..., FST=true>)
+//   phase 2  the n2-point row transforms are exactly a Merge transform of length n2 over
+//            batch*n1 rows with the n2 table -> the shared tile-pass planner (launch.hpp);
+//            the inverse applies cfg.mod_inverse (= N^-1) in its last pass.
+// => 2 sweeps for n2 <= 4096, 3 sweeps up to N = 2^24 (the reference also needs 2-3).
+#include <cstdio>
+
+#include "gpuntt/ntt_4step/ntt_4step.cuh"
+#include "launch_impl.hpp"
+
+namespace gpuntt
+{
+    namespace kern
+    {
+        // per polynomial: (row x col) row-major -> (col x row); 32x32 tiles through padded LDS
+        template <typename T>
+        __global__ __launch_bounds__(256) void transpose_batch(const T* __restrict__ in,
+                                                              T* __restrict__ out, int row, int col,
+                                                              unsigned long long poly_elems)
+        {
+            __shared__ T tile[32][33];
+            const unsigned long long base = static_cast<unsigned long long>(blockIdx.z) * poly_elems;
+            const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // 32 x 8
+            const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+#pragma unroll
+            for (int k = 0; k < 32; k += 8)
+            {
+                const int r = r0 + ty + k, c = c0 + tx;
+                if (r < row && c < col)
+                    tile[ty + k][tx] = in[base + static_cast<unsigned long long>(r) * col + c];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 32; k += 8)
+            {
+                const int c = c0 + ty + k, r = r0 + tx;
+                if (r < row && c < col)
+                    out[base + static_cast<unsigned long long>(c) * row + r] = tile[tx][ty + k];
+            }
+        }
+    } // namespace kern
+
+    template <typename T>
+    __host__ void GPU_Transpose(T* polynomial_in, T* polynomial_out, const int row, const int col,
+                                const int n_power, const int batch_size)
+    {
+        if (batch_size <= 0 || row <= 0 || col <= 0)
+            return;
+        const dim3 grid((col + 31) / 32, (row + 31) / 32, batch_size);
+        hipLaunchKernelGGL((kern::transpose_batch<T>), grid, dim3(256), 0, 0, polynomial_in,
+                           polynomial_out, row, col, 1ull << n_power);
+        GPUNTT_HIP_CHECK(hipGetLastError());
+    }
+
+    namespace
+    {
+        // n1 x n2 shapes, reference src/lib/common/nttparameters.cu:305-354
+        inline bool fourstep_shape(int n_power, int& log_n1, int& log_n2)
+        {
+            static const int l1[13] = {5, 5, 5, 6, 7, 5, 5, 5, 5, 6, 7, 7, 8};
+            if (n_power < 12 || n_power > 24)
+                return false;
+            log_n1 = l1[n_power - 12];
+            log_n2 = n_power - log_n1;
+            return true;
+        }
+
+        template <typename T, bool INV>
+        void fourstep_run(T* in, T* out, const T* n1_table, const T* n2_table, const T* w_table,
+                          const Modulus<T>* mods, Modulus<T> mod, int mod_count, const T* ninv_arr,
+                          T ninv, int n_power, int log_n1, int log_n2, int batch_size,
+                          hipStream_t stream)
+        {
+            kern::PassArgs<T> a{};
+            a.in = in;
+            a.out = out;
+            a.roots = n1_table;
+            a.mods = mods;
+            a.mod = mod;
+            a.ninv_arr = ninv_arr;
+            a.ninv = ninv;
+            a.w_table = w_table;
+            a.total = static_cast<unsigned long long>(batch_size) << n_power;
+            a.n = log_n1;
+            a.poly_shift = n_power;
+            a.root_shift = -1; // tables are shared by all moduli (reference SURVEY A.3)
+            a.mod_count = mod_count;
+            a.p_lo = 0;
+            a.n2_log = log_n2;
+            a.flags = 0;
+            const unsigned grid = static_cast<unsigned>(a.total >> kern::TL);
+            switch (log_n1)
+            {
+                case 5:
+                    host::launch_one<T, INV, true, 5, true>(a, grid, stream);
+                    break;
+                case 6:
+                    host::launch_one<T, INV, true, 6, true>(a, grid, stream);
+                    break;
+                case 7:
+                    host::launch_one<T, INV, true, 7, true>(a, grid, stream);
+                    break;
+                default:
+                    host::launch_one<T, INV, true, 8, true>(a, grid, stream);
+                    break;
+            }
+            // phase 2: n2-point transforms on the batch*n1 rows of `out`, in place
+            kern::PassArgs<T> b = a;
+            b.in = out;
+            b.roots = n2_table;
+            b.w_table = nullptr;
+            b.n = log_n2;
+            host::run_transform<T, INV>(b, 0u, INV ? kern::F_SCALE : 0u, stream);
+        }
+
+        template <typename T>
+        void fourstep_dispatch(T* in, T* out, const T* n1_table, const T* n2_table, const T* w_table,
+                               const Modulus<T>* mods, Modulus<T> mod, int mod_count,
+                               const T* ninv_arr, T ninv, int n_power, type ntt_type, int batch_size,
+                               hipStream_t stream)
+        {
+            int l1 = 0, l2 = 0;
+            if ((ntt_type != FORWARD && ntt_type != INVERSE) || !fourstep_shape(n_power, l1, l2))
+            {
+                // reference behaviour: report on stdout and return (ntt_4step.cu:2529-2532)
+                std::printf("This ring size is not supported!\n");
+                return;
+            }
+            if (batch_size <= 0)
+                return;
+            if ((static_cast<unsigned long long>(batch_size) << n_power) >> kern::TL > 0x7fffffffull)
+                throw std::invalid_argument("batch_size * N too large for one launch");
+            if (ntt_type == FORWARD)
+                fourstep_run<T, false>(in, out, n1_table, n2_table, w_table, mods, mod, mod_count,
+                                       ninv_arr, ninv, n_power, l1, l2, batch_size, stream);
+            else
+                fourstep_run<T, true>(in, out, n1_table, n2_table, w_table, mods, mod, mod_count,
+                                      ninv_arr, ninv, n_power, l1, l2, batch_size, stream);
+        }
+    } // namespace
+
+    template <typename T>
+    __host__ void GPU_4STEP_NTT(T* device_in, T* device_out, Root<T>* n1_root_of_unity_table,
+                                Root<T>* n2_root_of_unity_table, Root<T>* W_root_of_unity_table,
+                                Modulus<T> modulus, ntt4step_configuration<T> cfg, int batch_size)
+    {
+        fourstep_dispatch<T>(device_in, device_out, n1_root_of_unity_table, n2_root_of_unity_table,
+                             W_root_of_unity_table, nullptr, modulus, 1, nullptr, cfg.mod_inverse,
+                             cfg.n_power, cfg.ntt_type, batch_size, cfg.stream);
+    }
+
+    template <typename T>
+    __host__ void GPU_4STEP_NTT(T* device_in, T* device_out, Root<T>* n1_root_of_unity_table,
+                                Root<T>* n2_root_of_unity_table, Root<T>* W_root_of_unity_table,
+                                Modulus<T>* modulus, ntt4step_rns_configuration<T> cfg,
+                                int batch_size, int mod_count)
+    {
+        if (mod_count <= 0 || modulus == nullptr)
+            throw std::invalid_argument("Invalid mod_count!");
+        fourstep_dispatch<T>(device_in, device_out, n1_root_of_unity_table, n2_root_of_unity_table,
+                             W_root_of_unity_table, modulus, Modulus<T>(), mod_count,
+                             cfg.mod_inverse, static_cast<T>(0), cfg.n_power, cfg.ntt_type,
+                             batch_size, cfg.stream);
+    }
+
+    template __host__ void GPU_Transpose<Data32>(Data32*, Data32*, const int, const int, const int,
+                                                 const int);
+    template __host__ void GPU_Transpose<Data64>(Data64*, Data64*, const int, const int, const int,
+                                                 const int);
+    template __host__ void GPU_4STEP_NTT<Data32>(Data32*, Data32*, Root<Data32>*, Root<Data32>*,
+                                                 Root<Data32>*, Modulus<Data32>,
+                                                 ntt4step_configuration<Data32>, int);
+    template __host__ void GPU_4STEP_NTT<Data64>(Data64*, Data64*, Root<Data64>*, Root<Data64>*,
+                                                 Root<Data64>*, Modulus<Data64>,
+                                                 ntt4step_configuration<Data64>, int);
+    template __host__ void GPU_4STEP_NTT<Data32>(Data32*, Data32*, Root<Data32>*, Root<Data32>*,
+                                                 Root<Data32>*, Modulus<Data32>*,
+                                                 ntt4step_rns_configuration<Data32>, int, int);
+    template __host__ void GPU_4STEP_NTT<Data64>(Data64*, Data64*, Root<Data64>*, Root<Data64>*,
+                                                 Root<Data64>*, Modulus<Data64>*,
+                                                 ntt4step_rns_configuration<Data64>, int, int);
+} // namespace gpuntt

@@ -1,0 +1,10 @@
+// inst_u32_fwd.hip -- instantiates the Data32 forward (Cooley-Tukey) tile-pass kernel family.
+#include "launch_impl.hpp"
+
+namespace gpuntt
+{
+    namespace host
+    {
+        template void launch_pass<Data32, false>(const Pass&, const kern::PassArgs<Data32>&, hipStream_t);
+    }
+} // namespace gpuntt

@@ -1,0 +1,10 @@
+// inst_u64_fwd.hip -- instantiates the Data64 forward (Cooley-Tukey) tile-pass kernel family.
+#include "launch_impl.hpp"
+
+namespace gpuntt
+{
+    namespace host
+    {
+        template void launch_pass<Data64, false>(const Pass&, const kern::PassArgs<Data64>&, hipStream_t);
+    }
+} // namespace gpuntt

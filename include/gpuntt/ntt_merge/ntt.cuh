@@ -1,0 +1,103 @@
+// gpuntt/ntt_merge/ntt.cuh -- Merge-NTT launch API for MI355X (gfx950).
+//
+// Drop-in for the host API of reference src/include/gpuntt/ntt_merge/ntt.cuh:
+//   config structs               :31-51   (same members, same order -> designated
+//                                          initialisers in caller code keep working)
+//   GPU_NTT / GPU_INTT / *_Inplace, single modulus   :315-340
+//   GPU_NTT / GPU_INTT / *_Inplace, RNS              :395-421
+// The reference's __global__ kernel declarations and per-logN KernelConfig tables are not
+// part of this header: the HIP kernels behind these entry points are private to the
+// library (gpu-ntt_amd/csrc/merge_ntt.hip) and planned at run time.
+//
+// Semantics (identical to the reference):
+//   * data: T[batch][N] row-major device memory, N = 2^n_power, 1 <= n_power <= 28
+//   * GPU_NTT : natural-order in -> bit-reversed out;  GPU_INTT: bit-reversed in -> natural
+//     out, scaled by cfg.mod_inverse (= N^-1 mod q; device array indexed by modulus in RNS)
+//   * tables: bit-reversed powers of omega (X_N_minus, N/2 entries) or psi (X_N_plus, N
+//     entries); RNS: table of modulus i starts at element i << n_power; polynomial p uses
+//     modulus p % mod_count
+//   * cfg.ntt_type and cfg.zero_padding are ignored (direction = function name)
+//   * signed instantiations: GPU_NTT<Data64s> takes inputs in (-q, q); GPU_INTT<Data64s>
+//     returns centred residues
+//   * asynchronous on cfg.stream; in == out allowed; no allocation, no synchronisation
+//   * throws std::invalid_argument("Invalid n_power range!") / ("Invalid ntt_layout!"),
+//     HipException (alias CudaException) on a failed launch
+#pragma once
+
+#include "gpuntt/ntt_merge/ntt_cpu.cuh"
+
+typedef std::uint32_t location_t;
+
+namespace gpuntt
+{
+    template <typename T> struct ntt_configuration
+    {
+        int n_power;
+        type ntt_type;
+        NTTLayout ntt_layout;
+        ReductionPolynomial reduction_poly;
+        bool zero_padding;
+        Ninverse<T> mod_inverse;
+        stream_t stream;
+    };
+
+    template <typename T> struct ntt_rns_configuration
+    {
+        int n_power;
+        type ntt_type;
+        NTTLayout ntt_layout;
+        ReductionPolynomial reduction_poly;
+        bool zero_padding;
+        Ninverse<T>* mod_inverse;
+        stream_t stream;
+    };
+
+    // ---- single modulus (passed by value from the host) ---------------------------------
+    template <typename T>
+    __host__ void GPU_NTT(T* device_in, typename std::make_unsigned<T>::type* device_out,
+                          Root<typename std::make_unsigned<T>::type>* root_of_unity_table,
+                          Modulus<typename std::make_unsigned<T>::type> modulus,
+                          ntt_configuration<typename std::make_unsigned<T>::type> cfg,
+                          int batch_size);
+
+    template <typename T>
+    __host__ void GPU_INTT(typename std::make_unsigned<T>::type* device_in, T* device_out,
+                           Root<typename std::make_unsigned<T>::type>* root_of_unity_table,
+                           Modulus<typename std::make_unsigned<T>::type> modulus,
+                           ntt_configuration<typename std::make_unsigned<T>::type> cfg,
+                           int batch_size);
+
+    template <typename T>
+    __host__ void GPU_NTT_Inplace(T* device_inout, Root<T>* root_of_unity_table,
+                                  Modulus<T> modulus, ntt_configuration<T> cfg, int batch_size);
+
+    template <typename T>
+    __host__ void GPU_INTT_Inplace(T* device_inout, Root<T>* root_of_unity_table,
+                                   Modulus<T> modulus, ntt_configuration<T> cfg, int batch_size);
+
+    // ---- RNS: device arrays of moduli / tables / n^-1, polynomial p -> modulus p % mod_count
+    template <typename T>
+    __host__ void GPU_NTT(T* device_in, typename std::make_unsigned<T>::type* device_out,
+                          Root<typename std::make_unsigned<T>::type>* root_of_unity_table,
+                          Modulus<typename std::make_unsigned<T>::type>* modulus,
+                          ntt_rns_configuration<typename std::make_unsigned<T>::type> cfg,
+                          int batch_size, int mod_count);
+
+    template <typename T>
+    __host__ void GPU_INTT(typename std::make_unsigned<T>::type* device_in, T* device_out,
+                           Root<typename std::make_unsigned<T>::type>* root_of_unity_table,
+                           Modulus<typename std::make_unsigned<T>::type>* modulus,
+                           ntt_rns_configuration<typename std::make_unsigned<T>::type> cfg,
+                           int batch_size, int mod_count);
+
+    template <typename T>
+    __host__ void GPU_NTT_Inplace(T* device_inout, Root<T>* root_of_unity_table,
+                                  Modulus<T>* modulus, ntt_rns_configuration<T> cfg,
+                                  int batch_size, int mod_count);
+
+    template <typename T>
+    __host__ void GPU_INTT_Inplace(T* device_inout, Root<T>* root_of_unity_table,
+                                   Modulus<T>* modulus, ntt_rns_configuration<T> cfg,
+                                   int batch_size, int mod_count);
+
+} // namespace gpuntt

@@ -1,0 +1,145 @@
+/*
+ * gpuntt_c.h -- C ABI of the MI355X-native NTT library (libgpuntt.so).
+ *
+ * The reference (Alisah-Ozcan/GPU-NTT) exposes this path only as C++ templates resolved
+ * through explicit instantiations; it has no FFI.  This header is the flat
+ * extern "C" boundary an FFI (ctypes / cgo / JNI ...) binds instead -- plain pointers and
+ * sizes, no C++ or torch types -- one entry point per reference template overload:
+ *
+ *   gpuntt_ntt_{u32,u64}        GPU_NTT<T>  single modulus   src/include/gpuntt/ntt_merge/ntt.cuh:315-321
+ *   gpuntt_intt_{u32,u64}       GPU_INTT<T> single modulus   ntt.cuh:323-329
+ *   gpuntt_ntt_rns_{u32,u64}    GPU_NTT<T>  RNS              ntt.cuh:395-401
+ *   gpuntt_intt_rns_{u32,u64}   GPU_INTT<T> RNS              ntt.cuh:403-409
+ *       (in == out gives the *_Inplace overloads, ntt.cuh:331-340,411-421;
+ *        input_signed / output_signed select the Data32s/Data64s instantiations,
+ *        src/lib/ntt_merge/ntt.cu:4948-5082)
+ *   gpuntt_4step_{u32,u64}      GPU_4STEP_NTT<T> single      src/include/gpuntt/ntt_4step/ntt_4step.cuh:278-283
+ *   gpuntt_4step_rns_{u32,u64}  GPU_4STEP_NTT<T> RNS         ntt_4step.cuh:301-307
+ *   gpuntt_transpose_{u32,u64}  GPU_Transpose<T>             ntt_4step.cuh:46-49
+ *   gpuntt_modulus_*, gpuntt_merge_params_*, gpuntt_4step_params_*
+ *                               Modulus<T>, NTTParameters<T>, NTTParameters4Step<T>
+ *                               src/include/gpuntt/common/modular_arith.cuh:28-57,
+ *                               src/include/gpuntt/common/nttparameters.cuh:56-170
+ *
+ * All data/table/modulus-array pointers are DEVICE pointers unless the name ends in _host.
+ * Calls are asynchronous on `stream` (a hipStream_t passed as void*; NULL = default
+ * stream), allocate nothing and never synchronise.
+ *
+ * Return value: GPUNTT_OK, or a negative code with the text available from
+ * gpuntt_last_error() (thread-local).  GPUNTT_ERR_INVALID_ARGUMENT corresponds to the
+ * std::invalid_argument the C++ API throws (reference ntt.cu:2088-2091, 2252-2254),
+ * GPUNTT_ERR_HIP to HipException/CudaException (reference common.cuh:42-50).
+ */
+#ifndef GPUNTT_C_H
+#define GPUNTT_C_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C"
+{
+#endif
+
+#define GPUNTT_OK 0
+#define GPUNTT_ERR_INVALID_ARGUMENT (-1)
+#define GPUNTT_ERR_HIP (-2)
+#define GPUNTT_ERR_UNKNOWN (-3)
+
+    /* enum values of the reference (nttparameters.cuh:19-36) */
+#define GPUNTT_FORWARD 0
+#define GPUNTT_INVERSE 1
+#define GPUNTT_PER_POLYNOMIAL 0
+#define GPUNTT_PER_COEFFICIENT 1
+#define GPUNTT_X_N_PLUS 0  /* negacyclic X^N + 1 */
+#define GPUNTT_X_N_MINUS 1 /* cyclic     X^N - 1 */
+
+    /* layout-identical to Modulus<Data32> / Modulus<Data64> */
+    typedef struct { uint32_t value, bit, mu; } gpuntt_modulus32;
+    typedef struct { uint64_t value, bit, mu; } gpuntt_modulus64;
+
+    const char* gpuntt_last_error(void);
+    int gpuntt_version(void);
+
+    /* ---- Modulus<T>(q) ------------------------------------------------------------ */
+    int gpuntt_modulus_u32(uint32_t q, gpuntt_modulus32* out_host);
+    int gpuntt_modulus_u64(uint64_t q, gpuntt_modulus64* out_host);
+
+    /* ---- Merge NTT, single modulus -------------------------------------------------- */
+    int gpuntt_ntt_u32(const void* in, uint32_t* out, const uint32_t* roots,
+                       gpuntt_modulus32 modulus, int n_power, int ntt_layout, int reduction_poly,
+                       int input_signed, void* stream, int batch_size);
+    int gpuntt_ntt_u64(const void* in, uint64_t* out, const uint64_t* roots,
+                       gpuntt_modulus64 modulus, int n_power, int ntt_layout, int reduction_poly,
+                       int input_signed, void* stream, int batch_size);
+    int gpuntt_intt_u32(const uint32_t* in, void* out, const uint32_t* inverse_roots,
+                        gpuntt_modulus32 modulus, int n_power, int ntt_layout, int reduction_poly,
+                        uint32_t mod_inverse, int output_signed, void* stream, int batch_size);
+    int gpuntt_intt_u64(const uint64_t* in, void* out, const uint64_t* inverse_roots,
+                        gpuntt_modulus64 modulus, int n_power, int ntt_layout, int reduction_poly,
+                        uint64_t mod_inverse, int output_signed, void* stream, int batch_size);
+
+    /* ---- Merge NTT, RNS: polynomial p uses modulus p % mod_count, table at i << n_power -- */
+    int gpuntt_ntt_rns_u32(const void* in, uint32_t* out, const uint32_t* roots,
+                           const gpuntt_modulus32* modulus, int n_power, int ntt_layout,
+                           int reduction_poly, int input_signed, void* stream, int batch_size,
+                           int mod_count);
+    int gpuntt_ntt_rns_u64(const void* in, uint64_t* out, const uint64_t* roots,
+                           const gpuntt_modulus64* modulus, int n_power, int ntt_layout,
+                           int reduction_poly, int input_signed, void* stream, int batch_size,
+                           int mod_count);
+    int gpuntt_intt_rns_u32(const uint32_t* in, void* out, const uint32_t* inverse_roots,
+                            const gpuntt_modulus32* modulus, int n_power, int ntt_layout,
+                            int reduction_poly, const uint32_t* mod_inverse, int output_signed,
+                            void* stream, int batch_size, int mod_count);
+    int gpuntt_intt_rns_u64(const uint64_t* in, void* out, const uint64_t* inverse_roots,
+                            const gpuntt_modulus64* modulus, int n_power, int ntt_layout,
+                            int reduction_poly, const uint64_t* mod_inverse, int output_signed,
+                            void* stream, int batch_size, int mod_count);
+
+    /* ---- 4-Step NTT (cyclic, 12 <= n_power <= 24, in != out) ------------------------ */
+    int gpuntt_4step_u32(const uint32_t* in, uint32_t* out, const uint32_t* n1_table,
+                         const uint32_t* n2_table, const uint32_t* w_table,
+                         gpuntt_modulus32 modulus, int n_power, int ntt_type, uint32_t mod_inverse,
+                         void* stream, int batch_size);
+    int gpuntt_4step_u64(const uint64_t* in, uint64_t* out, const uint64_t* n1_table,
+                         const uint64_t* n2_table, const uint64_t* w_table,
+                         gpuntt_modulus64 modulus, int n_power, int ntt_type, uint64_t mod_inverse,
+                         void* stream, int batch_size);
+    int gpuntt_4step_rns_u32(const uint32_t* in, uint32_t* out, const uint32_t* n1_table,
+                             const uint32_t* n2_table, const uint32_t* w_table,
+                             const gpuntt_modulus32* modulus, int n_power, int ntt_type,
+                             const uint32_t* mod_inverse, void* stream, int batch_size,
+                             int mod_count);
+    int gpuntt_4step_rns_u64(const uint64_t* in, uint64_t* out, const uint64_t* n1_table,
+                             const uint64_t* n2_table, const uint64_t* w_table,
+                             const gpuntt_modulus64* modulus, int n_power, int ntt_type,
+                             const uint64_t* mod_inverse, void* stream, int batch_size,
+                             int mod_count);
+    int gpuntt_transpose_u32(const uint32_t* in, uint32_t* out, int row, int col, int n_power,
+                             int batch_size);
+    int gpuntt_transpose_u64(const uint64_t* in, uint64_t* out, int row, int col, int n_power,
+                             int batch_size);
+
+    /* ---- host-side parameter / table generation (no GPU needed) --------------------
+     * factors_host: {q, omega, psi} or NULL for the built-in pool.
+     * info_host[8] = {q, bit, mu, omega, psi, n_inv, root_of_unity_size, n}.
+     * tables are written in DEVICE order (bit-reversed), root_of_unity_size entries each. */
+    int gpuntt_merge_params_u32(int logn, int reduction_poly, const uint32_t* factors_host,
+                                uint64_t* info_host, uint32_t* forward_table_host,
+                                uint32_t* inverse_table_host);
+    int gpuntt_merge_params_u64(int logn, int reduction_poly, const uint64_t* factors_host,
+                                uint64_t* info_host, uint64_t* forward_table_host,
+                                uint64_t* inverse_table_host);
+    /* info_host[9] = {q, bit, mu, omega, psi, n_inv, n1, n2, n}; inverse != 0 selects the
+     * inverse tables; n1/n2 tables in DEVICE order (n1/2, n2/2 entries), W natural (n). */
+    int gpuntt_4step_params_u32(int logn, int inverse, uint64_t* info_host,
+                                uint32_t* n1_table_host, uint32_t* n2_table_host,
+                                uint32_t* w_table_host);
+    int gpuntt_4step_params_u64(int logn, int inverse, uint64_t* info_host,
+                                uint64_t* n1_table_host, uint64_t* n2_table_host,
+                                uint64_t* w_table_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPUNTT_C_H */

@@ -1,0 +1,124 @@
+"""-m gpu parity tests for the 4-Step NTT and GPU_Transpose, mirroring
+example/ntt_4step/test_4step_ntt.cu:147-178 and test_4step_intt.cu:81-179:
+  forward:  GPU_Transpose -> GPU_4STEP_NTT(FORWARD) -> GPU_Transpose == NTT_4STEP_CPU::ntt
+  inverse:  intt_first_transpose -> GPU_4STEP_NTT(INVERSE) -> GPU_Transpose == NTT_4STEP_CPU::intt"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from gpu_utils import sha
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def g(pkg):
+    import torch
+    assert torch.cuda.is_available()
+    pkg.load_library()
+    return pkg
+
+
+def run_fourstep(g, p4, x, batch, inverse, rns=False):
+    """full natural-order pipeline on the GPU; returns the flat result"""
+    import torch
+    t1, t2, w = (g.to_device(t) for t in p4.tables["inv" if inverse else "fwd"])
+    d_a = g.to_device(x)
+    d_b = torch.zeros_like(d_a)
+    if rns:
+        mods = g.modulus_array_to_device([p4.modulus], p4.bits)
+        ninv = g.to_device(np.array([p4.n_inv], dtype=g.np_dtype(p4.bits)))
+        cfg = g.ntt4step_rns_configuration(n_power=p4.logn,
+                                           ntt_type=g.INVERSE if inverse else g.FORWARD,
+                                           mod_inverse=ninv)
+        args = (mods, cfg, batch, 1)
+    else:
+        cfg = g.ntt4step_configuration(n_power=p4.logn,
+                                       ntt_type=g.INVERSE if inverse else g.FORWARD,
+                                       mod_inverse=p4.n_inv if inverse else 0)
+        args = (p4.modulus, cfg, batch)
+    torch.cuda.synchronize()
+    if not inverse:
+        g.GPU_Transpose(d_a, d_b, p4.n1, p4.n2, p4.logn, batch)
+        torch.cuda.synchronize()
+        g.GPU_4STEP_NTT(d_b, d_a, t1, t2, w, *args)
+        torch.cuda.synchronize()
+        g.GPU_Transpose(d_a, d_b, p4.n1, p4.n2, p4.logn, batch)
+        torch.cuda.synchronize()
+        return g.to_host(d_b)
+    g.GPU_4STEP_NTT(d_a, d_b, t1, t2, w, *args)
+    torch.cuda.synchronize()
+    g.GPU_Transpose(d_b, d_a, p4.n1, p4.n2, p4.logn, batch)
+    torch.cuda.synchronize()
+    return g.to_host(d_a)
+
+
+@pytest.mark.parametrize("bits", [32, 64])
+def test_transpose(g, bits):
+    import torch
+    rng = np.random.default_rng(3)
+    for row, col, batch in ((32, 128, 3), (256, 64, 2), (128, 512, 1)):
+        x = rng.integers(0, 2**31, size=batch * row * col).astype(g.np_dtype(bits))
+        d = g.to_device(x)
+        o = torch.zeros_like(d)
+        g.GPU_Transpose(d, o, row, col, int(np.log2(row * col)), batch)
+        torch.cuda.synchronize()
+        want = x.reshape(batch, row, col).transpose(0, 2, 1).reshape(-1)
+        assert np.array_equal(g.to_host(o), want)
+
+
+@pytest.mark.parametrize("bits", [32, 64])
+def test_fourstep_vs_oracle(g, bits):
+    # every n1 x n2 shape class: n1 in {32, 64, 128}, n2 from 128 (one tile) to 32768 (strided)
+    P = O.Port(bits)
+    for logn in (12, 13, 14, 15, 16, 17, 18, 20):
+        p4 = g.NTTParameters4Step(logn, bits)
+        oprm = P.fourstep_params(logn)
+        assert np.array_equal(p4.tables["fwd"][2], oprm["W_fwd"])
+        batch = 2 if logn <= 16 else 1
+        x = P.splitmix(400 + logn, 0, batch * p4.n, p4.modulus.value)
+        want = P.fourstep_ntt(x, oprm)
+        got = run_fourstep(g, p4, x, batch, inverse=False, rns=(logn % 2 == 0))
+        assert np.array_equal(got, want), ("forward", bits, logn)
+        xin = P.fourstep_intt_first_transpose(want, oprm)
+        back = run_fourstep(g, p4, xin, batch, inverse=True, rns=(logn % 2 == 1))
+        assert np.array_equal(back, x), ("inverse", bits, logn)
+
+
+@pytest.mark.parametrize("bits", [32, 64])
+def test_fourstep_golden(g, bits, golden_dir):
+    P = O.Port(bits)
+    gold = np.load(os.path.join(golden_dir, "fourstep_u%d.npz" % bits))
+    recs = [r for r in json.load(open(os.path.join(golden_dir, "digests.json")))["fourstep"]
+            if r["bits"] == bits]
+    for r in recs:
+        p4 = g.NTTParameters4Step(r["logn"], bits)
+        assert sha(p4.tables["fwd"][2]) == r["sha_W_fwd"] and sha(p4.tables["inv"][2]) == r["sha_W_inv"]
+        assert sha(p4.tables["fwd"][1]) == r["sha_n2_fwd_gpu"]
+        x = P.splitmix(r["seed"], 0, p4.n, r["q"])
+        assert sha(x) == r["sha_in"]
+        fwd = run_fourstep(g, p4, x, 1, inverse=False)
+        assert sha(fwd) == r["sha_fwd"], ("fwd", r["logn"])
+        # intt_first_transpose: flat[i*n2+j] = x[i + j*n1]
+        xin = x.reshape(p4.n2, p4.n1).T.reshape(-1).copy()
+        assert sha(xin) == r["sha_first_transpose"]
+        inv = run_fourstep(g, p4, xin, 1, inverse=True)
+        assert sha(inv) == r["sha_inv"], ("inv", r["logn"])
+        if "l%d_fwd" % r["logn"] in gold:
+            assert np.array_equal(fwd, gold["l%d_fwd" % r["logn"]])
+            assert np.array_equal(inv, gold["l%d_inv" % r["logn"]])
+
+
+def test_fourstep_unsupported_size_is_silent(g, capfd):
+    # reference ntt_4step.cu:2529-2532: message on stdout, no exception
+    import torch
+    p4 = g.NTTParameters4Step(12, 64)
+    t1, t2, w = (g.to_device(t) for t in p4.tables["fwd"])
+    d = g.to_device(np.zeros(4096, dtype=np.uint64))
+    o = torch.zeros_like(d)
+    cfg = g.ntt4step_configuration(n_power=11)
+    g.GPU_4STEP_NTT(d, o, t1, t2, w, p4.modulus, cfg, 1)
+    torch.cuda.synchronize()

@@ -1,0 +1,254 @@
+"""-m gpu parity tests for the Merge NTT: HIP path (through the C ABI) vs the oracle, the
+golden fixtures and size-independent properties.  Mirrors the reference's GPU examples
+(example/ntt_merge/test_merge_ntt.cu:46-341, test_merge_intt.cu:46-379): bit-exact equality."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from gpu_utils import MergeCase, sha
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def g(pkg):
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    pkg.load_library()
+    return pkg
+
+
+@pytest.mark.parametrize("bits", [32, 64])
+@pytest.mark.parametrize("poly", [O.X_N_plus, O.X_N_minus])
+def test_forward_inverse_all_sizes(g, bits, poly):
+    # every pass shape: single tile (1..12), strided + contiguous (13..20)
+    for logn in range(1, 21):
+        c = MergeCase(g, bits, logn, poly)
+        batch = 5 if logn <= 14 else (3 if logn <= 17 else 1)
+        x = c.random(batch, 1000 + logn)
+        want = c.P.merge_ntt(x, c.oprm)
+        got = c.gpu_forward(x, inplace=(logn % 2 == 0))
+        assert np.array_equal(got, want), ("forward", bits, poly, logn)
+        back = c.gpu_inverse(got, inplace=(logn % 2 == 1))
+        assert np.array_equal(back, x), ("inverse", bits, poly, logn)
+        # inverse of raw data against the oracle (not only as a round trip)
+        assert np.array_equal(c.gpu_inverse(x), c.P.merge_ntt(x, c.oprm, inverse=True))
+
+
+@pytest.mark.parametrize("bits", [32, 64])
+def test_ragged_batches_small_rings(g, bits):
+    # tiles that hold several polynomials and a ragged tail (reference LowRing tail guard,
+    # ntt.cu:27,107)
+    for logn in (1, 2, 3, 4, 7, 9, 11):
+        c = MergeCase(g, bits, logn, O.X_N_minus)
+        for batch in (1, 2, 3, 17, (4096 >> logn) + 1):
+            x = c.random(batch, 7 * logn + batch)
+            assert np.array_equal(c.gpu_forward(x), c.P.merge_ntt(x, c.oprm))
+            assert np.array_equal(c.gpu_inverse(x), c.P.merge_ntt(x, c.oprm, inverse=True))
+
+
+@pytest.mark.parametrize("bits", [32, 64])
+def test_edge_values(g, bits):
+    # all-zero, all-(q-1), delta and constant polynomials
+    c = MergeCase(g, bits, 13, O.X_N_plus)
+    n, q = c.n, c.q
+    rows = [np.zeros(n), np.full(n, q - 1), np.eye(1, n, 0)[0], np.eye(1, n, n - 1)[0] * (q - 1),
+            np.ones(n)]
+    x = np.concatenate([np.asarray(r, dtype=object) for r in rows]).astype(c.P.T)
+    assert np.array_equal(c.gpu_forward(x), c.P.merge_ntt(x, c.oprm))
+    assert np.array_equal(c.gpu_inverse(x), c.P.merge_ntt(x, c.oprm, inverse=True))
+
+
+@pytest.mark.parametrize("bits", [32, 64])
+def test_signed_input_and_centered_output(g, bits):
+    # GPU_NTT<Data64s>: signed input in (-q/2, q/2] gives the same result as its residue
+    # (test_merge_ntt.cu:185-341); GPU_INTT<Data64s>: centred output (test_merge_intt.cu:206-379)
+    import torch
+    for logn in (5, 12, 14):
+        c = MergeCase(g, bits, logn, O.X_N_minus)
+        q, n = c.q, c.n
+        x = c.random(2, 31 + logn)
+        sdt = np.int32 if bits == 32 else np.int64
+        xs = np.where(x > q // 2, x.astype(object) - q, x.astype(object)).astype(sdt)
+        d_in = g.to_device(xs)
+        d_out = torch.zeros_like(d_in)
+        g.GPU_NTT(d_in, d_out, c.fwd_dev, c.prm.modulus, c.cfg(), 2, dtype="s%d" % bits)
+        torch.cuda.synchronize()
+        want = c.P.merge_ntt(x, c.oprm)
+        assert np.array_equal(g.to_host(d_out), want)
+        d_back = torch.zeros_like(d_out)
+        g.GPU_INTT(d_out, d_back, c.inv_dev, c.prm.modulus, c.cfg(True), 2, dtype="s%d" % bits)
+        torch.cuda.synchronize()
+        assert np.array_equal(g.to_host(d_back, signed=True), xs)
+
+
+def _rns_setup(g, bits, logn, poly, factor_list):
+    """RNS stack: table of modulus i at i << n_power (ntt.cu:672-678)."""
+    cases = [MergeCase(g, bits, logn, poly, f) for f in factor_list]
+    n = 1 << logn
+    fwd = np.zeros(len(cases) * n, dtype=cases[0].P.T)
+    inv = np.zeros_like(fwd)
+    for i, c in enumerate(cases):
+        sz = c.prm.root_of_unity_size
+        fwd[i * n:i * n + sz] = c.prm.forward_table_device_order
+        inv[i * n:i * n + sz] = c.prm.inverse_table_device_order
+    mods = g.modulus_array_to_device([c.prm.modulus for c in cases], bits)
+    ninv = g.to_device(np.array([c.prm.n_inv for c in cases], dtype=cases[0].P.T))
+    return cases, g.to_device(fwd), g.to_device(inv), mods, ninv
+
+
+def _small_prime_factors(P, logn, count):
+    """`count` distinct NTT primes for any logn from the reference pools (4-step pool primes
+    all have 2^13 | q-1) with omega/psi derived from the pool psi."""
+    out = []
+    for lg in (12, 13, 14, 15, 17, 19, 20, 21, 22, 23, 24):
+        prm = P.fourstep_params(lg, with_W=False)
+        q = prm["mod"][0]
+        if any(q == f[0] for f in out):
+            continue
+        psi = pow(prm["psi"], 1 << (lg - logn), q)
+        out.append((q, psi * psi % q, psi))
+        if len(out) == count:
+            break
+    return out
+
+
+@pytest.mark.parametrize("bits", [32, 64])
+def test_rns_multi_modulus(g, bits):
+    # mod_count > 1 is never exercised by the reference's own examples; pinned via the oracle
+    import torch
+    P = O.Port(bits)
+    for logn, batch, mc in ((3, 10, 3), (8, 21, 3), (11, 7, 2), (12, 6, 3), (14, 6, 3)):
+        for poly in (O.X_N_plus, O.X_N_minus):
+            cases, fwd, inv, mods, ninv = _rns_setup(g, bits, logn, poly,
+                                                     _small_prime_factors(P, logn, mc))
+            n = 1 << logn
+            x = np.concatenate([cases[p % mc].P.splitmix(50 + p, 0, n, cases[p % mc].q)
+                                for p in range(batch)])
+            want = np.concatenate([cases[p % mc].P.merge_ntt(x[p * n:(p + 1) * n], cases[p % mc].oprm)
+                                   for p in range(batch)])
+            cfg = g.ntt_rns_configuration(n_power=logn, reduction_poly=poly)
+            d = g.to_device(x)
+            g.GPU_NTT_Inplace(d, fwd, mods, cfg, batch, mc)
+            torch.cuda.synchronize()
+            assert np.array_equal(g.to_host(d), want), (bits, logn, poly)
+            icfg = g.ntt_rns_configuration(n_power=logn, ntt_type=g.INVERSE, reduction_poly=poly,
+                                           mod_inverse=ninv)
+            g.GPU_INTT_Inplace(d, inv, mods, icfg, batch, mc)
+            torch.cuda.synchronize()
+            assert np.array_equal(g.to_host(d), x), (bits, logn, poly)
+
+
+def test_rns_c5_against_golden(g, golden_dir):
+    # BASELINE config 5: 8 distinct 60-bit primes, log2N = 16; digests from the reference build
+    import torch
+    rns = json.load(open(os.path.join(golden_dir, "rns_c5.json")))
+    fl = [(e["q"], e["omega"], e["psi"]) for e in rns["primes"]]
+    for poly, tag in ((O.X_N_plus, "plus"), (O.X_N_minus, "minus")):
+        cases, fwd, inv, mods, ninv = _rns_setup(g, 64, 16, poly, fl)
+        n = 1 << 16
+        x = np.concatenate([c.P.splitmix(e["seed_" + tag], 0, n, c.q)
+                            for c, e in zip(cases, rns["primes"])] * 2)  # batch 16
+        d = g.to_device(x)
+        cfg = g.ntt_rns_configuration(n_power=16, reduction_poly=poly)
+        out = torch.zeros_like(d)
+        g.GPU_NTT(d, out, fwd, mods, cfg, 16, 8)
+        torch.cuda.synchronize()
+        y = g.to_host(out)
+        for p in range(16):
+            assert sha(y[p * n:(p + 1) * n]) == rns["primes"][p % 8]["sha_fwd_" + tag]
+        icfg = g.ntt_rns_configuration(n_power=16, ntt_type=g.INVERSE, reduction_poly=poly,
+                                       mod_inverse=ninv)
+        g.GPU_INTT(d, out, inv, mods, icfg, 16, 8)
+        torch.cuda.synchronize()
+        z = g.to_host(out)
+        for p in range(16):
+            assert sha(z[p * n:(p + 1) * n]) == rns["primes"][p % 8]["sha_inv_" + tag]
+
+
+@pytest.mark.parametrize("bits", [32, 64])
+def test_golden_vectors(g, bits, golden_dir):
+    gold = np.load(os.path.join(golden_dir, "merge_u%d.npz" % bits))
+    recs = [r for r in json.load(open(os.path.join(golden_dir, "digests.json")))["merge"]
+            if r["bits"] == bits]
+    assert len(recs) == 24
+    for r in recs:
+        c = MergeCase(g, bits, r["logn"], r["poly"])
+        x = c.P.splitmix(r["seed"], 0, r["batch"] * c.n, r["q"])
+        assert sha(c.prm.forward_table_device_order) == r["sha_fwd_gpu_table"]
+        fwd, inv = c.gpu_forward(x), c.gpu_inverse(x)
+        assert sha(fwd) == r["sha_fwd"] and sha(inv) == r["sha_inv"], r
+        key = "p%d_l%d" % (r["poly"], r["logn"])
+        if key + "_fwd" in gold:
+            assert np.array_equal(fwd, gold[key + "_fwd"]) and np.array_equal(inv, gold[key + "_inv"])
+
+
+def test_reference_example_stream_known_answer(g, golden_dir):
+    # the mt19937(0) input of example/ntt_merge/test_merge_ntt.cu:70-96 (needs the libstdc++
+    # stream from oracle/_ref; digests were produced by the reference's NTTCPU)
+    if not O.have_ref():
+        pytest.skip("oracle/_ref not present")
+    R = O.Ref(64)
+    for r in json.load(open(os.path.join(golden_dir, "digests.json")))["mt19937"]:
+        c = MergeCase(g, 64, r["logn"], O.X_N_minus)
+        x = R.mt19937_uniform(0, r["q"], c.n)
+        y = c.gpu_forward(x, inplace=True)
+        assert [int(v) for v in y[:4]] == r["first_out"] and sha(y) == r["sha_out"]
+
+
+def test_full_size_c2_properties(g):
+    """BASELINE config 2 (u64, N = 2^16, batch = 1024) at full size: sampled polynomials
+    against the oracle, the exact round trip, and linearity NTT(a)+NTT(b) == NTT(a+b)."""
+    import torch
+    c = MergeCase(g, 64, 16, O.X_N_minus)
+    batch, n, q = 1024, c.n, c.q
+    x = c.random(batch, 0x5EED0002)
+    d = g.to_device(x)
+    out = torch.empty_like(d)
+    g.GPU_NTT(d, out, c.fwd_dev, c.prm.modulus, c.cfg(), batch)
+    torch.cuda.synchronize()
+    y = g.to_host(out)
+    for p in (0, 1, 511, 1023):
+        assert np.array_equal(y[p * n:(p + 1) * n], c.P.merge_ntt(x[p * n:(p + 1) * n], c.oprm))
+    assert int(y.max()) < q
+    # linearity over the first 512 vs the last 512 polynomials
+    a, b = x[:512 * n], x[512 * n:]
+    s = ((a.astype(object) + b.astype(object)) % q).astype(np.uint64)
+    ys = c.gpu_forward(s)
+    want = ((y[:512 * n].astype(object) + y[512 * n:].astype(object)) % q).astype(np.uint64)
+    assert np.array_equal(ys, want)
+    g.GPU_INTT_Inplace(out, c.inv_dev, c.prm.modulus, c.cfg(True), batch)
+    torch.cuda.synchronize()
+    assert np.array_equal(g.to_host(out), x)
+
+
+def test_streams_are_honoured(g):
+    import torch
+    c = MergeCase(g, 64, 14, O.X_N_minus)
+    x = c.random(8, 77)
+    s = torch.cuda.Stream()
+    d = g.to_device(x)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s):
+        g.GPU_NTT_Inplace(d, c.fwd_dev, c.prm.modulus, c.cfg(stream=s), 8)
+    s.synchronize()
+    assert np.array_equal(g.to_host(d), c.P.merge_ntt(x, c.oprm))
+
+
+def test_error_behaviour(g):
+    # std::invalid_argument("Invalid n_power range!") / ("Invalid ntt_layout!")
+    # (reference ntt.cu:2088-2091, 2252-2254) surface as ValueError through the C ABI
+    c = MergeCase(g, 64, 4, O.X_N_minus)
+    d = g.to_device(c.random(1, 1))
+    for bad in (0, 29, -3):
+        cfg = g.ntt_configuration(n_power=bad)
+        with pytest.raises(ValueError, match="Invalid n_power range!"):
+            g.GPU_NTT_Inplace(d, c.fwd_dev, c.prm.modulus, cfg, 1)
+    cfg = g.ntt_configuration(n_power=4, ntt_layout=7)
+    with pytest.raises(ValueError, match="Invalid ntt_layout!"):
+        g.GPU_NTT_Inplace(d, c.fwd_dev, c.prm.modulus, cfg, 1)
+    # batch 0 is a no-op
+    g.GPU_NTT_Inplace(d, c.fwd_dev, c.prm.modulus, c.cfg(), 0)

@@ -1,0 +1,117 @@
+"""CPU-side tests of the product library: the C-ABI library loads and exports every symbol
+include/gpuntt_c.h declares, the host parameter generators agree with the oracle and the
+golden digests, argument checking matches the reference's exception behaviour, the pass
+planner covers every n_power, and the batch-shard arithmetic is consistent.  No compute
+calls (there is no GPU here and the product has no CPU path)."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from gpu_utils import sha
+from oracle import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def g(pkg):
+    if not os.path.exists(pkg.LIB_PATH):
+        pkg.build_library()
+    pkg.load_library()
+    return pkg
+
+
+def test_c_abi_exports_every_declared_symbol(g):
+    hdr = open(os.path.join(ROOT, "include", "gpuntt_c.h")).read()
+    declared = set(re.findall(r"\b(gpuntt_[a-z0-9_]+)\s*\(", hdr))
+    declared = {d for d in declared if not d.startswith("gpuntt_modulus3") and d != "gpuntt_modulus6"}
+    assert len(declared) >= 22
+    lib = g.load_library()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert set(g.EXPORTED_SYMBOLS) == declared
+
+
+def test_modulus_struct_matches_reference_contract(g):
+    P = O.Port(64)
+    for q in (576460756061519873, 576460752303415297, 288230377292562433, 12289, 469762049):
+        m = g.Modulus(q)
+        assert (m.value, m.bit, m.mu) == P.modulus(q)
+    P32 = O.Port(32)
+    for q in (469762049, 268460033, 12289):
+        m = g.Modulus(q, bits=32)
+        assert (m.value, m.bit, m.mu) == P32.modulus(q)
+
+
+@pytest.mark.parametrize("bits", [32, 64])
+def test_merge_parameter_generator(g, bits, golden_dir):
+    P = O.Port(bits)
+    recs = [r for r in json.load(open(os.path.join(golden_dir, "digests.json")))["merge"]
+            if r["bits"] == bits]
+    for r in recs:
+        p = g.NTTParameters(r["logn"], r["poly"], bits)
+        assert (p.modulus.value, p.modulus.bit, p.modulus.mu) == (r["q"], r["bit"], r["mu"])
+        assert (p.omega, p.psi, p.n_inv) == (r["omega"], r["psi"], r["n_inv"])
+        assert sha(p.forward_table_device_order) == r["sha_fwd_gpu_table"]
+        assert sha(p.inverse_table_device_order) == r["sha_inv_gpu_table"]
+    # custom factors (NTTFactors constructor)
+    f = (576460752303415297, 288482366111684746, 238394956950829) if bits == 64 else \
+        (268460033, 36747374, 77090)
+    p = g.NTTParameters(12, O.X_N_plus, bits, f)
+    pp = P.merge_params(12, O.X_N_plus, f)
+    assert np.array_equal(p.forward_table_device_order, P.bitrev_table(pp["fwd"]))
+    assert p.n_inv == pp["n_inv"]
+
+
+@pytest.mark.parametrize("bits", [32, 64])
+def test_fourstep_parameter_generator(g, bits, golden_dir):
+    recs = [r for r in json.load(open(os.path.join(golden_dir, "digests.json")))["fourstep"]
+            if r["bits"] == bits and r["logn"] <= 20]
+    for r in recs:
+        p = g.NTTParameters4Step(r["logn"], bits)
+        assert (p.n1, p.n2, p.n_inv) == (r["n1"], r["n2"], r["n_inv"])
+        assert sha(p.tables["fwd"][2]) == r["sha_W_fwd"] and sha(p.tables["inv"][2]) == r["sha_W_inv"]
+        assert sha(p.tables["fwd"][0]) == r["sha_n1_fwd_gpu"]
+        assert sha(p.tables["inv"][1]) == r["sha_n2_inv_gpu"]
+    with pytest.raises(ValueError):
+        g.NTTParameters4Step(11, bits)
+
+
+def test_argument_errors_without_gpu(g):
+    lib = g.load_library()
+    m = g.Modulus(576460756061519873).c()
+    for bad in (0, 29):
+        assert lib.gpuntt_ntt_u64(None, None, None, m, bad, 0, 1, 0, None, 1) == -1
+        assert lib.gpuntt_last_error() == b"Invalid n_power range!"
+        assert lib.gpuntt_intt_u64(None, None, None, m, bad, 0, 1, ctypes.c_uint64(1), 0, None, 1) == -1
+    assert lib.gpuntt_ntt_u64(None, None, None, m, 12, 9, 1, 0, None, 1) == -1
+    assert lib.gpuntt_last_error() == b"Invalid ntt_layout!"
+    assert lib.gpuntt_ntt_rns_u64(None, None, None, None, 12, 0, 1, 0, None, 1, 0) == -1
+    # PerCoefficient range check (reference ntt.cu:2230-2233)
+    assert lib.gpuntt_ntt_u64(None, None, None, m, 10, 1, 1, 0, None, 1) == -1
+    assert lib.gpuntt_last_error() == b"Invalid n_power range!"
+
+
+def test_no_cpu_fallback(g):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("this check is for GPU-less hosts")
+    x = torch.zeros(16, dtype=torch.int64)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        g.GPU_NTT_Inplace(x, x, g.Modulus(576460756061519873), g.ntt_configuration(n_power=4), 1)
+
+
+def test_shard_range_partitions_batch(g):
+    for batch, mc in ((1024, 1), (512, 8), (8192, 1), (24, 3)):
+        for world in (1, 2, 4, 8):
+            spans = [g.shard_range(batch, r, world, mc) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == batch
+            for (a, b), (c, d) in zip(spans, spans[1:]):
+                assert b == c
+            assert all(lo % mc == 0 and hi % mc == 0 for lo, hi in spans)
+    with pytest.raises(ValueError):
+        g.shard_range(10, 0, 2, 4)
