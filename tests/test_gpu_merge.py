@@ -105,6 +105,8 @@ def _small_prime_factors(P, logn, count):
     all have 2^13 | q-1) with omega/psi derived from the pool psi."""
     out = []
     for lg in (12, 13, 14, 15, 17, 19, 20, 21, 22, 23, 24):
+        if lg < logn:
+            continue
         prm = P.fourstep_params(lg, with_W=False)
         q = prm["mod"][0]
         if any(q == f[0] for f in out):
@@ -113,6 +115,7 @@ def _small_prime_factors(P, logn, count):
         out.append((q, psi * psi % q, psi))
         if len(out) == count:
             break
+    assert len(out) == count
     return out
 
 
