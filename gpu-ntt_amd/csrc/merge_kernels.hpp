@@ -103,7 +103,8 @@ namespace gpuntt
         {
             unsigned long long base; // CONTIG: flat base; STRIDED: flat index bits supplied by the block
             int p_lo;
-            __device__ __forceinline__ TileMap(const PassArgs<T>& a)
+            __device__ __forceinline__ TileMap(const PassArgs<T>& a) : TileMap(a.n, a.p_lo) {}
+            __device__ __forceinline__ TileMap(int n, int pass_p_lo)
             {
                 constexpr int L = Geo<CONTIG, K>::L;
                 if constexpr (CONTIG)
@@ -113,13 +114,13 @@ namespace gpuntt
                 }
                 else
                 {
-                    p_lo = a.p_lo;
+                    p_lo = pass_p_lo;
                     const unsigned long long blk = blockIdx.x;
-                    const unsigned long long poly = blk >> (a.n - TL);
-                    const unsigned long long b = blk & ((1ull << (a.n - TL)) - 1);
+                    const unsigned long long poly = blk >> (n - TL);
+                    const unsigned long long b = blk & ((1ull << (n - TL)) - 1);
                     const unsigned long long xb = b & ((1ull << (p_lo - L)) - 1);
                     const unsigned long long hi = b >> (p_lo - L);
-                    base = (poly << a.n) | (hi << (p_lo + K)) | (xb << L);
+                    base = (poly << n) | (hi << (p_lo + K)) | (xb << L);
                 }
             }
             // flat coefficient index of tile element e

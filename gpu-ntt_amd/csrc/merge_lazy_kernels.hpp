@@ -1,0 +1,314 @@
+// merge_lazy_kernels.hpp -- the fast 64-bit Merge-NTT tile-pass kernel (gfx950).
+//
+// Same tile/round geometry as merge_kernels.hpp (4096-coefficient tiles, 16 coefficients per
+// thread, <= 4 radix-2 stages per register round, padded-LDS exchanges), but
+//   * twiddles are read from the library's prepared table of Shoup pairs {w, floor(w*2^64/q)}
+//     (prep.hip): block-uniform rounds fetch them through the scalar cache (s_load), the
+//     last contiguous round reads them fully coalesced from a per-thread permuted layout;
+//   * butterflies work on lazy residues in [0, B*q) with B tracked at compile time
+//     (lazy64.hpp); passes hand over lazy values, only the final pass normalises.
+// Replaces the hot loops of reference ForwardCore/InverseCore
+// (src/lib/ntt_merge/ntt.cu:596-761, 1086-1318).
+#pragma once
+
+#include "lazy64.hpp"
+#include "merge_kernels.hpp"
+
+namespace gpuntt
+{
+    namespace kern
+    {
+        enum : unsigned
+        {
+            F_PERM_LOW = 64u // prepared table uses the permuted layout for distances 1, 2, 4
+        };
+
+        struct LazyArgs
+        {
+            const void* in;
+            uint64_t* out;
+            const lazy::Tw64* tw;            // prepared twiddles: modulus slot mi at (mi << n)
+            const Modulus<uint64_t>* mods;   // device array (RNS) or nullptr
+            uint64_t q;                      // single modulus
+            const lazy::Tw64* ninv_arr;      // prepared n^-1 pairs per modulus (RNS) or nullptr
+            lazy::Tw64 ninv;                 // single modulus n^-1 pair
+            unsigned long long total;
+            int n;
+            int poly_shift;
+            int mod_count;
+            int p_lo;
+            unsigned flags;
+        };
+
+        // ---- compile-time schedule of range corrections for one pass --------------------
+        template <bool INV, bool CONTIG, int K, int IN_BOUND, int LIMIT> struct PassSched
+        {
+            using G = Geo<CONTIG, K>;
+            static constexpr int NR = G::NR;
+            struct Data
+            {
+                int ku[NR][R][EPT / 2];
+                int kv[NR][R][EPT / 2];
+                int c[NR][R][EPT / 2];
+                int bout[NR][EPT];
+                int bin[NR];
+                int final_bound;
+            };
+            static constexpr int stages_of(int r) { return (r == NR - 1) ? (K - R * (NR - 1)) : R; }
+            static constexpr int first_pos(int r)
+            {
+                return INV ? (G::L + r * R) : (G::L + K - 1 - r * R);
+            }
+            static constexpr int wl_of(int r)
+            {
+                int w = INV ? first_pos(r) : (first_pos(r) - R + 1);
+                return w < 0 ? 0 : (w > TL - R ? TL - R : w);
+            }
+            static constexpr Data make()
+            {
+                Data d{};
+                int bound_in = IN_BOUND;
+                for (int r = 0; r < NR; r++)
+                {
+                    int b[EPT] = {};
+                    for (int j = 0; j < EPT; j++)
+                        b[j] = bound_in;
+                    d.bin[r] = bound_in;
+                    for (int s = 0; s < stages_of(r); s++)
+                    {
+                        const int p = INV ? (first_pos(r) + s) : (first_pos(r) - s);
+                        const int jb = p - wl_of(r);
+                        for (int h = 0; h < EPT / 2; h++)
+                        {
+                            const int j0 = (h & ((1 << jb) - 1)) | ((h >> jb) << (jb + 1));
+                            const int j1 = j0 | (1 << jb);
+                            if (!INV)
+                            {
+                                const lazy::CtPlan pl = lazy::ct_plan(b[j0], LIMIT);
+                                d.ku[r][s][h] = pl.ku;
+                                b[j0] = b[j1] = pl.out;
+                            }
+                            else
+                            {
+                                const lazy::GsPlan pl = lazy::gs_plan(b[j0], b[j1], LIMIT);
+                                d.ku[r][s][h] = pl.ku;
+                                d.kv[r][s][h] = pl.kv;
+                                d.c[r][s][h] = pl.c;
+                                b[j0] = pl.out_u;
+                                b[j1] = lazy::TB;
+                            }
+                        }
+                    }
+                    int mx = 0;
+                    for (int j = 0; j < EPT; j++)
+                    {
+                        d.bout[r][j] = b[j];
+                        mx = b[j] > mx ? b[j] : mx;
+                    }
+                    bound_in = mx;
+                }
+                d.final_bound = bound_in;
+                return d;
+            }
+            static constexpr Data d = make();
+            static_assert(d.final_bound <= LIMIT, "lazy bound exceeds the headroom");
+        };
+
+        template <bool INV, bool CONTIG, int K, int IN_BOUND, bool LAST, int LIMIT>
+        __global__ __launch_bounds__(NT) void merge_pass_lazy(LazyArgs a)
+        {
+            using G = Geo<CONTIG, K>;
+            using SCH = PassSched<INV, CONTIG, K, IN_BOUND, LIMIT>;
+            using T = uint64_t;
+            // single-round passes with coalesced register windows never touch LDS
+            constexpr bool NEEDS_LDS = (G::NR > 1) || (SCH::wl_of(0) < 4);
+            __shared__ T lds[NEEDS_LDS ? LDS_ELEMS : 1];
+
+            const int t = threadIdx.x;
+            const TileMap<T, CONTIG, K> map(a.n, a.p_lo);
+            const unsigned long long poly = map.flat(0) >> a.poly_shift;
+            lazy::Mod64 m;
+            unsigned long long root_base = 0;
+            lazy::Tw64 ninv = a.ninv;
+            if (a.mods != nullptr)
+            {
+                const int mi = static_cast<int>(poly % static_cast<unsigned>(a.mod_count));
+                m.q = a.mods[mi].value;
+                root_base = static_cast<unsigned long long>(mi) << a.n;
+                if (LAST && INV)
+                    ninv = a.ninv_arr[mi];
+            }
+            else
+            {
+                m.q = a.q;
+            }
+            m.qneg = 0 - m.q;
+            const unsigned nmask = (1u << a.n) - 1u;
+
+            T v[EPT];
+
+            static_for<G::NR>([&](auto r_) {
+                constexpr int r = decltype(r_)::value;
+                constexpr int STAGES = SCH::stages_of(r);
+                constexpr int FIRST_POS = SCH::first_pos(r);
+                constexpr int WL = SCH::wl_of(r);
+                constexpr bool DIRECT_IO = (WL >= 4);
+                constexpr bool UNIFORM = (WL + R == TL); // no thread bits above the register window
+
+                // ---- gather -----------------------------------------------------------
+                if constexpr (r == 0)
+                {
+                    auto load = [&](unsigned long long f) -> T {
+                        if (f >= a.total)
+                            return 0;
+                        if (a.flags & F_SIGNED_IN)
+                        {
+                            const long long sv = static_cast<const long long*>(a.in)[f];
+                            return (sv < 0) ? static_cast<T>(m.q + static_cast<T>(sv)) : static_cast<T>(sv);
+                        }
+                        return static_cast<const T*>(a.in)[f];
+                    };
+                    if constexpr (DIRECT_IO)
+                    {
+#pragma unroll
+                        for (int j = 0; j < EPT; j++)
+                            v[j] = load(map.flat(elem_of<WL>(t, j)));
+                    }
+                    else
+                    {
+#pragma unroll
+                        for (int j = 0; j < EPT; j++)
+                            lds[lds_pad(t + NT * j)] = load(map.flat(t + NT * j));
+                        __syncthreads();
+#pragma unroll
+                        for (int j = 0; j < EPT; j++)
+                            v[j] = lds[lds_pad(elem_of<WL>(t, j))];
+                    }
+                }
+                else
+                {
+#pragma unroll
+                    for (int j = 0; j < EPT; j++)
+                        v[j] = lds[lds_pad(elem_of<WL>(t, j))];
+                }
+
+                // ---- butterflies ------------------------------------------------------
+                static_for<STAGES>([&](auto s_) {
+                    constexpr int s = decltype(s_)::value;
+                    constexpr int p = INV ? (FIRST_POS + s) : (FIRST_POS - s);
+                    constexpr int jb = p - WL;
+                    const int P = map.gpos(p);
+                    const unsigned stage_base = 1u << (a.n - 1 - P); // slots [2^S, 2^(S+1)), S = n-1-P
+                    static_for<EPT / 2>([&](auto h_) {
+                        constexpr int h = decltype(h_)::value;
+                        constexpr int j0 = (h & ((1 << jb) - 1)) | ((h >> jb) << (jb + 1));
+                        constexpr int j1 = j0 | (1 << jb);
+                        // twiddle slot
+                        unsigned ti;
+                        if constexpr (UNIFORM)
+                        {
+                            // depends on blockIdx and compile-time register bits only -> scalar load
+                            const unsigned idx0 = static_cast<unsigned>(map.flat(elem_of<WL>(0, j0))) & nmask;
+                            ti = idx0 >> (P + 1);
+                        }
+                        else
+                        {
+                            const unsigned idx = static_cast<unsigned>(map.flat(elem_of<WL>(t, j0))) & nmask;
+                            ti = idx >> (P + 1);
+                            if constexpr (CONTIG && K == TL && WL == 0 && p <= 2)
+                            {
+                                // per-thread twiddles of the distance-1/2/4 stages: [tile][k][thread]
+                                if (a.flags & F_PERM_LOW)
+                                {
+                                    constexpr int RP = EPT >> (p + 1); // twiddles per thread
+                                    constexpr int kk = j0 >> (p + 1);
+                                    const unsigned tile_in_poly = (static_cast<unsigned>(map.flat(0)) & nmask) >> TL;
+                                    ti = tile_in_poly * (RP * NT) + kk * NT + t;
+                                }
+                            }
+                        }
+                        const lazy::Tw64 tw = a.tw[root_base + stage_base + ti];
+                        if constexpr (!INV)
+                        {
+                            constexpr int ku = SCH::d.ku[r][s][h];
+                            T U = v[j0];
+                            if constexpr (ku != 0)
+                                U = m.template csub<ku>(U);
+                            const T Tm = m.mul(v[j1], tw);
+                            v[j0] = U + Tm;
+                            v[j1] = U + m.kq(lazy::TB) - Tm;
+                        }
+                        else
+                        {
+                            constexpr int ku = SCH::d.ku[r][s][h];
+                            constexpr int kv = SCH::d.kv[r][s][h];
+                            constexpr int c = SCH::d.c[r][s][h];
+                            T U = v[j0], V = v[j1];
+                            if constexpr (ku != 0)
+                                U = m.template csub<ku>(U);
+                            if constexpr (kv != 0)
+                                V = m.template csub<kv>(V);
+                            v[j0] = U + V;
+                            v[j1] = m.mul(U + m.kq(c) - V, tw);
+                        }
+                    });
+                });
+
+                // ---- scatter ----------------------------------------------------------
+                if constexpr (r == G::NR - 1)
+                {
+                    if constexpr (LAST)
+                    {
+                        static_for<EPT>([&](auto j_) {
+                            constexpr int j = decltype(j_)::value;
+                            if constexpr (INV)
+                            {
+                                T x = m.mul(v[j], ninv); // * n^-1, [0, 4q)
+                                x = m.template normalize<lazy::TB>(x);
+                                if (a.flags & F_CENTERED)
+                                    x = (x > (m.q >> 1)) ? (x - m.q) : x;
+                                v[j] = x;
+                            }
+                            else
+                            {
+                                v[j] = m.template normalize<SCH::d.bout[r][j]>(v[j]);
+                            }
+                        });
+                    }
+                    if constexpr (DIRECT_IO)
+                    {
+#pragma unroll
+                        for (int j = 0; j < EPT; j++)
+                        {
+                            const unsigned long long f = map.flat(elem_of<WL>(t, j));
+                            if (f < a.total)
+                                a.out[f] = v[j];
+                        }
+                    }
+                    else
+                    {
+#pragma unroll
+                        for (int j = 0; j < EPT; j++)
+                            lds[lds_pad(elem_of<WL>(t, j))] = v[j];
+                        __syncthreads();
+#pragma unroll
+                        for (int j = 0; j < EPT; j++)
+                        {
+                            const unsigned long long f = map.flat(t + NT * j);
+                            if (f < a.total)
+                                a.out[f] = lds[lds_pad(t + NT * j)];
+                        }
+                    }
+                }
+                else
+                {
+#pragma unroll
+                    for (int j = 0; j < EPT; j++)
+                        lds[lds_pad(elem_of<WL>(t, j))] = v[j];
+                    __syncthreads();
+                }
+            });
+        }
+
+    } // namespace kern
+} // namespace gpuntt

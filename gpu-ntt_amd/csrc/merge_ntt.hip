@@ -6,8 +6,12 @@
 // types, asynchronous launches on cfg.stream with a hipGetLastError() check after each,
 // in == out allowed, first pass reads `device_in` and later passes run in place on
 // `device_out`, cfg.ntt_type / cfg.zero_padding ignored.
+#include <cstdlib>
+#include <cstring>
+
 #include "gpuntt/ntt_merge/ntt.cuh"
 #include "launch.hpp"
+#include "lazy_launch.hpp"
 
 namespace gpuntt
 {
@@ -55,6 +59,67 @@ namespace gpuntt
             }
         }
 
+        // ---- fast 64-bit path (lazy residues + prepared Shoup twiddles) -----------------
+        // Used for Data64 single-modulus calls whose modulus leaves 4 bits of headroom
+        // (bit <= 60); everything else runs the generic Barrett kernels.
+        // GPUNTT_PATH=generic | fast overrides the size heuristic (testing / A-B timing);
+        // moduli without the headroom always take the generic kernels.
+        inline int forced_path()
+        {
+            static const int mode = [] {
+                const char* e = std::getenv("GPUNTT_PATH");
+                if (e == nullptr)
+                    return 0;
+                if (std::strcmp(e, "generic") == 0)
+                    return 1;
+                if (std::strcmp(e, "fast") == 0)
+                    return 2;
+                return 0;
+            }();
+            return mode;
+        }
+
+        inline bool lazy_eligible(const Modulus<Data64>& m, int n_power, int batch_size)
+        {
+            if (m.bit > static_cast<Data64>(host::LAZY_MAX_BIT) || m.value < 3)
+                return false;
+            if (n_power > host::LAZY_MAX_N_POWER)
+                return false;
+            if (forced_path() == 1)
+                return false;
+            if (forced_path() == 2)
+                return true;
+            // the per-call twiddle preparation touches N entries: not worth it for tiny jobs
+            return (static_cast<unsigned long long>(batch_size) << n_power) >= (1ull << 15) &&
+                   batch_size >= 2;
+        }
+
+        inline kern::LazyArgs lazy_args(const void* in, Data64* out, const Data64* roots,
+                                        const Modulus<Data64>& m, int n_power, ReductionPolynomial poly,
+                                        int batch_size, hipStream_t stream)
+        {
+            const bool neg = (poly == ReductionPolynomial::X_N_plus);
+            const bool perm = (n_power >= kern::TL);
+            auto* ws = static_cast<lazy::Tw64*>(
+                host::lazy_workspace(stream, sizeof(lazy::Tw64) << n_power));
+            host::launch_prep(roots, ws, nullptr, m.value, 1, n_power, neg, perm, nullptr, nullptr, stream);
+            kern::LazyArgs a{};
+            a.in = in;
+            a.out = out;
+            a.tw = ws;
+            a.mods = nullptr;
+            a.q = m.value;
+            a.ninv_arr = nullptr;
+            a.ninv = lazy::Tw64{0, 0};
+            a.total = static_cast<unsigned long long>(batch_size) << n_power;
+            a.n = n_power;
+            a.poly_shift = n_power;
+            a.mod_count = 1;
+            a.p_lo = 0;
+            a.flags = perm ? kern::F_PERM_LOW : 0u;
+            return a;
+        }
+
         template <typename TU> inline void set_multi(kern::PassArgs<TU>& a)
         {
             if (a.mods != nullptr && a.mod_count > 1 && a.poly_shift < kern::TL)
@@ -72,10 +137,20 @@ namespace gpuntt
     {
         using TU = typename std::make_unsigned<T>::type;
         check_layout_and_range(cfg.ntt_layout, cfg.n_power);
+        const unsigned in_flags = std::is_signed<T>::value ? kern::F_SIGNED_IN : 0u;
+        if constexpr (std::is_same<TU, Data64>::value)
+        {
+            if (batch_size > 0 && lazy_eligible(modulus, cfg.n_power, batch_size))
+            {
+                kern::LazyArgs la = lazy_args(device_in, device_out, root_of_unity_table, modulus,
+                                              cfg.n_power, cfg.reduction_poly, batch_size, cfg.stream);
+                host::run_transform_lazy<false>(la, in_flags, 0u, cfg.stream);
+                return;
+            }
+        }
         kern::PassArgs<TU> a = base_args<TU>(device_in, device_out, root_of_unity_table, cfg.n_power,
                                              cfg.reduction_poly, batch_size);
         a.mod = modulus;
-        const unsigned in_flags = std::is_signed<T>::value ? kern::F_SIGNED_IN : 0u;
         host::run_transform<TU, false>(a, in_flags, 0u, cfg.stream);
     }
 
@@ -88,13 +163,26 @@ namespace gpuntt
     {
         using TU = typename std::make_unsigned<T>::type;
         check_layout_and_range(cfg.ntt_layout, cfg.n_power);
+        const unsigned out_flags =
+            kern::F_SCALE | (std::is_signed<T>::value ? kern::F_CENTERED : 0u);
+        if constexpr (std::is_same<TU, Data64>::value)
+        {
+            if (batch_size > 0 && lazy_eligible(modulus, cfg.n_power, batch_size) &&
+                cfg.mod_inverse < modulus.value)
+            {
+                kern::LazyArgs la =
+                    lazy_args(device_in, reinterpret_cast<Data64*>(device_out), root_of_unity_table,
+                              modulus, cfg.n_power, cfg.reduction_poly, batch_size, cfg.stream);
+                la.ninv = lazy::Tw64{cfg.mod_inverse, host::shoup_host(cfg.mod_inverse, modulus.value)};
+                host::run_transform_lazy<true>(la, 0u, out_flags, cfg.stream);
+                return;
+            }
+        }
         kern::PassArgs<TU> a =
             base_args<TU>(device_in, reinterpret_cast<TU*>(device_out), root_of_unity_table,
                           cfg.n_power, cfg.reduction_poly, batch_size);
         a.mod = modulus;
         a.ninv = cfg.mod_inverse;
-        const unsigned out_flags =
-            kern::F_SCALE | (std::is_signed<T>::value ? kern::F_CENTERED : 0u);
         host::run_transform<TU, true>(a, 0u, out_flags, cfg.stream);
     }
 

@@ -255,3 +255,47 @@ def test_error_behaviour(g):
         g.GPU_NTT_Inplace(d, c.fwd_dev, c.prm.modulus, cfg, 1)
     # batch 0 is a no-op
     g.GPU_NTT_Inplace(d, c.fwd_dev, c.prm.modulus, c.cfg(), 0)
+
+
+def _run_in_subprocess(code, env_path):
+    """the path override is read once per process, so A/B runs need their own interpreter"""
+    import subprocess
+    import sys
+    env = dict(os.environ, GPUNTT_PATH=env_path, PYTHONPATH=os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return r.stdout
+
+
+_SWEEP = r'''
+import numpy as np, sys, os
+sys.path.insert(0, os.path.join(os.path.dirname(os.environ["PYTHONPATH"]), ""))
+from conftest import load_pkg
+from gpu_utils import MergeCase
+from oracle import oracle as O
+g = load_pkg(); g.load_library()
+for poly in (O.X_N_plus, O.X_N_minus):
+    for logn in range(1, 21):
+        c = MergeCase(g, 64, logn, poly)
+        batch = 3 if logn <= 17 else 2
+        x = c.random(batch, 4242 + logn)
+        want = c.P.merge_ntt(x, c.oprm)
+        got = c.gpu_forward(x, inplace=bool(logn & 1))
+        assert np.array_equal(got, want), ("fwd", poly, logn)
+        assert np.array_equal(c.gpu_inverse(got, inplace=not (logn & 1)), x), ("inv", poly, logn)
+        assert np.array_equal(c.gpu_inverse(x), c.P.merge_ntt(x, c.oprm, inverse=True)), ("inv raw", poly, logn)
+# user prime with other limb structure (4-step pool prime, 60 bit) and a small 31-bit prime in u64
+for f, logn in (((576460752303415297, 288482366111684746, 238394956950829), 12),):
+    c = MergeCase(g, 64, logn, O.X_N_plus, f)
+    x = c.random(4, 9)
+    assert np.array_equal(c.gpu_forward(x), c.P.merge_ntt(x, c.oprm))
+    assert np.array_equal(c.gpu_inverse(x), c.P.merge_ntt(x, c.oprm, inverse=True))
+print("SWEEP-OK")
+'''
+
+
+@pytest.mark.parametrize("path", ["fast", "generic"])
+def test_both_kernel_paths_all_sizes(g, path):
+    """The 64-bit fast path (lazy residues, prepared Shoup twiddles) and the generic Barrett
+    path must each be bit-exact for every ring size, regardless of the size heuristic."""
+    assert "SWEEP-OK" in _run_in_subprocess(_SWEEP, path)

@@ -22,6 +22,8 @@ constexpr int ITERS = 4096;
         uint64_t c0 = a0, c1 = a1, c2 = a2, c3 = a3, c4 = a4, c5 = a5, c6 = a6, c7 = a7;  \
         double d0 = a0, d1 = a1, d2 = a2, d3 = a3, d4 = a4, d5 = a5, d6 = a6, d7 = a7;    \
         double db = 1.0000001;                                                             \
+        uint64_t smask = __builtin_amdgcn_readfirstlane(seed) * 0x9E3779B97F4A7C15ull;     \
+        uint32_t sb = __builtin_amdgcn_readfirstlane(seed * 77u + 5u);                     \
         for (int i = 0; i < ITERS; i++) { BODY BODY BODY BODY }                            \
         uint32_t r = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;                                \
         uint64_t rc = c0 ^ c1 ^ c2 ^ c3 ^ c4 ^ c5 ^ c6 ^ c7;                               \
@@ -48,6 +50,19 @@ constexpr int ITERS = 4096;
 #define SUBCO(k) asm volatile("v_sub_co_u32 %0, vcc, %0, %1" : "+v"(a##k) : "v"(b) : "vcc");
 #define MIN32(k) asm volatile("v_min_u32 %0, %0, %1" : "+v"(a##k) : "v"(b));
 #define ALIGNBIT(k) asm volatile("v_alignbit_b32 %0, %0, %1, 7" : "+v"(a##k) : "v"(b));
+#define CMPCND(k) asm volatile("v_cmp_ge_u64 vcc, %1, %2\n\tv_cndmask_b32 %0, %0, %3, vcc" : "+v"(a##k) : "v"(c##k), "v"(c7), "v"(b) : "vcc");
+#define CNDE64(k) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a##k) : "v"(b), "s"(smask));
+#define AND32(k) asm volatile("v_and_b32 %0, %0, %1" : "+v"(a##k) : "v"(b));
+#define XOR32(k) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a##k) : "v"(b));
+#define SUB32(k) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(a##k) : "v"(b));
+#define LSHL32(k) asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(a##k));
+#define ADD3(k) asm volatile("v_add3_u32 %0, %0, %1, %1" : "+v"(a##k) : "v"(b));
+#define MOV32(k) asm volatile("v_mov_b32 %0, %1" : "=v"(a##k) : "v"(b));
+#define MAD64S(k) asm volatile("v_mad_u64_u32 %0, %3, %1, %2, %0" : "+v"(c##k) : "v"(a##k), "s"(sb), "s"(smask));
+#define MULLOS(k) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a##k) : "s"(sb));
+#define CMP32(k) asm volatile("v_cmp_ge_u32 vcc, %0, %1" : : "v"(a##k), "v"(b) : "vcc");
+#define MAX32(k) asm volatile("v_max_u32 %0, %0, %1" : "+v"(a##k) : "v"(b));
+#define LSHLADD32(k) asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(a##k) : "v"(b));
 #define MADU32(k) asm volatile("v_mad_u32_u16 %0, %0, %1, %0" : "+v"(a##k) : "v"(b));
 
 KERNEL(k_mul_lo, REP8(MUL_LO), 0)
@@ -69,6 +84,19 @@ KERNEL(k_cmp64, REP8(CMP64), 0)
 KERNEL(k_subco, REP8(SUBCO), 0)
 KERNEL(k_min32, REP8(MIN32), 0)
 KERNEL(k_alignbit, REP8(ALIGNBIT), 0)
+KERNEL(k_cmpcnd, REP8(CMPCND), 0)
+KERNEL(k_cnde64, REP8(CNDE64), 0)
+KERNEL(k_and32, REP8(AND32), 0)
+KERNEL(k_xor32, REP8(XOR32), 0)
+KERNEL(k_sub32, REP8(SUB32), 0)
+KERNEL(k_lshl32, REP8(LSHL32), 0)
+KERNEL(k_add3, REP8(ADD3), 0)
+KERNEL(k_mov32, REP8(MOV32), 0)
+KERNEL(k_mad64s, REP8(MAD64S), 0)
+KERNEL(k_mullos, REP8(MULLOS), 0)
+KERNEL(k_cmp32, REP8(CMP32), 0)
+KERNEL(k_max32, REP8(MAX32), 0)
+KERNEL(k_lshladd32, REP8(LSHLADD32), 0)
 
 typedef void (*kfn)(uint32_t*, uint32_t);
 
@@ -87,11 +115,15 @@ int main()
                          {"v_sub_co_u32", k_subco}, {"v_lshl_add_u64", k_lshladd64}, {"v_cndmask_b32", k_cndmask},
                          {"v_fma_f64", k_fma64}, {"v_mul_f64", k_mul64f}, {"v_fma_f32", k_fma32},
                          {"v_lshrrev_b64", k_lshr64}, {"v_cmp_ge_u64", k_cmp64}, {"v_min_u32", k_min32},
-                         {"v_alignbit_b32", k_alignbit}};
+                         {"v_alignbit_b32", k_alignbit}, {"cmp64+cndmask(2 instr)", k_cmpcnd},
+                         {"v_cndmask_b32_e64 sgpr", k_cnde64}, {"v_and_b32", k_and32}, {"v_xor_b32", k_xor32},
+                         {"v_sub_u32", k_sub32}, {"v_lshlrev_b32", k_lshl32}, {"v_add3_u32", k_add3},
+                         {"v_mov_b32", k_mov32}, {"v_mad_u64_u32 sgpr", k_mad64s}, {"v_mul_lo_u32 sgpr", k_mullos},
+                         {"v_cmp_ge_u32", k_cmp32}, {"v_max_u32", k_max32}, {"v_lshl_add_u32", k_lshladd32}};
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
-    for (int wpsimd : {1, 2, 4})
+    for (int wpsimd : {2, 4})
     {
         printf("--- %d wave(s) per SIMD ---\n", wpsimd);
         const int blocks = cus * wpsimd; // 256 threads = 4 waves = 1 per SIMD
