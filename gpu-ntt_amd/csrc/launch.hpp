@@ -30,8 +30,10 @@ namespace gpuntt
             int count;
         };
 
-        // forward order; the inverse runs the same list backwards
-        inline Plan make_plan(int n)
+        // forward order; the inverse runs the same list backwards.  `contig_k` = stages done by
+        // the contiguous pass when n > 12 (8..12): 12 minimises LDS exchanges, smaller values move
+        // butterflies into the (memory-bound) strided passes.
+        inline Plan make_plan(int n, int contig_k = kern::TL)
         {
             Plan pl{};
             pl.count = 0;
@@ -40,7 +42,11 @@ namespace gpuntt
                 pl.pass[pl.count++] = Pass{true, n, 0};
                 return pl;
             }
-            const int s = n - kern::TL;         // stages above the contiguous tile
+            if (contig_k > kern::TL)
+                contig_k = kern::TL;
+            if (contig_k < 8)
+                contig_k = 8;
+            const int s = n - contig_k;         // stages above the contiguous pass
             const int np = (s + 7) / 8;         // STRIDED passes of at most 8 stages
             int top = n;                        // stage positions [top-1 .. ] still to cover
             for (int i = 0; i < np; i++)
@@ -49,7 +55,7 @@ namespace gpuntt
                 top -= k;
                 pl.pass[pl.count++] = Pass{false, k, top};
             }
-            pl.pass[pl.count++] = Pass{true, kern::TL, 0};
+            pl.pass[pl.count++] = Pass{true, contig_k, 0};
             return pl;
         }
 

@@ -30,6 +30,9 @@ namespace gpuntt
             return static_cast<uint64_t>((static_cast<unsigned __int128>(w) << 64) / q);
         }
 
+        // stages handled by the contiguous pass of the fast path (GPUNTT_CONTIG_K overrides, 8..12)
+        int lazy_contig_k(int n);
+
         template <bool INV> void launch_pass_lazy(const Pass& p, int in_bound, bool last, const kern::LazyArgs& a,
                                                  hipStream_t stream);
         extern template void launch_pass_lazy<false>(const Pass&, int, bool, const kern::LazyArgs&, hipStream_t);
@@ -39,7 +42,7 @@ namespace gpuntt
         inline void run_transform_lazy(kern::LazyArgs base, unsigned first_in_flags, unsigned last_out_flags,
                                        hipStream_t stream)
         {
-            const Plan pl = make_plan(base.n);
+            const Plan pl = make_plan(base.n, lazy_contig_k(base.n));
             const void* src = base.in;
             for (int i = 0; i < pl.count; i++)
             {

@@ -32,13 +32,29 @@ namespace gpuntt
             {
                 if constexpr (!INV)
                 {
-                    if (in_bound != 1 && p.k == kern::TL && last)
-                        return launch_lazy_one<false, true, kern::TL, LIM, true>(a, grid, stream);
+                    if (in_bound != 1 && last)
+                        switch (p.k)
+                        {
+                            case 8: return launch_lazy_one<false, true, 8, LIM, true>(a, grid, stream);
+                            case 9: return launch_lazy_one<false, true, 9, LIM, true>(a, grid, stream);
+                            case 10: return launch_lazy_one<false, true, 10, LIM, true>(a, grid, stream);
+                            case 11: return launch_lazy_one<false, true, 11, LIM, true>(a, grid, stream);
+                            case 12: return launch_lazy_one<false, true, 12, LIM, true>(a, grid, stream);
+                            default: throw std::invalid_argument("internal: bad lazy contiguous pass");
+                        }
                 }
                 else
                 {
-                    if (in_bound == 1 && p.k == kern::TL && !last)
-                        return launch_lazy_one<true, true, kern::TL, 1, false>(a, grid, stream);
+                    if (in_bound == 1 && !last)
+                        switch (p.k)
+                        {
+                            case 8: return launch_lazy_one<true, true, 8, 1, false>(a, grid, stream);
+                            case 9: return launch_lazy_one<true, true, 9, 1, false>(a, grid, stream);
+                            case 10: return launch_lazy_one<true, true, 10, 1, false>(a, grid, stream);
+                            case 11: return launch_lazy_one<true, true, 11, 1, false>(a, grid, stream);
+                            case 12: return launch_lazy_one<true, true, 12, 1, false>(a, grid, stream);
+                            default: throw std::invalid_argument("internal: bad lazy contiguous pass");
+                        }
                 }
                 if (in_bound != 1 || !last)
                     throw std::invalid_argument("internal: unsupported lazy contiguous pass");

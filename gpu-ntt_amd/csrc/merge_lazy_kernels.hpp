@@ -20,7 +20,8 @@ namespace gpuntt
     {
         enum : unsigned
         {
-            F_PERM_LOW = 64u // prepared table uses the permuted layout for distances 1, 2, 4
+            F_PERM_LOW = 64u // (informational) prepared table permutes the distance-1/2/4 stages;
+                             // implied by n >= 12, i.e. by the CONTIG K = 12 kernel itself
         };
 
         struct LazyArgs
@@ -114,8 +115,12 @@ namespace gpuntt
             static_assert(d.final_bound <= LIMIT, "lazy bound exceeds the headroom");
         };
 
+        // twiddles of one register round, in stage order: stage s (register bit jb) contributes
+        // 2^(R-1-jb) entries -> at most 1 + 2 + 4 + 8 = 15 per thread
+        constexpr int TW_PER_ROUND = EPT - 1;
+
         template <bool INV, bool CONTIG, int K, int IN_BOUND, bool LAST, int LIMIT>
-        __global__ __launch_bounds__(NT) void merge_pass_lazy(LazyArgs a)
+        __global__ __launch_bounds__(NT, 4) void merge_pass_lazy(LazyArgs a)
         {
             using G = Geo<CONTIG, K>;
             using SCH = PassSched<INV, CONTIG, K, IN_BOUND, LIMIT>;
@@ -123,6 +128,9 @@ namespace gpuntt
             // single-round passes with coalesced register windows never touch LDS
             constexpr bool NEEDS_LDS = (G::NR > 1) || (SCH::wl_of(0) < 4);
             __shared__ T lds[NEEDS_LDS ? LDS_ELEMS : 1];
+
+            // single-pass transforms of rings smaller than a tile: the tile holds several polynomials
+            constexpr bool MULTI_POLY = CONTIG && (K < TL) && (IN_BOUND == 1) && LAST;
 
             const int t = threadIdx.x;
             const TileMap<T, CONTIG, K> map(a.n, a.p_lo);
@@ -144,8 +152,66 @@ namespace gpuntt
             }
             m.qneg = 0 - m.q;
             const unsigned nmask = (1u << a.n) - 1u;
+            const lazy::Tw64* __restrict__ tw_mod = a.tw + root_base;
+
+            // Issues every twiddle load of round r (15 x 16 B per thread, or scalar loads when the
+            // round is block-uniform).  Called one round ahead, in front of the LDS barrier, so the
+            // L2 latency is covered by the previous round's butterflies and the exchange.
+            auto load_twiddles = [&](auto r_, lazy::Tw64(&tws)[TW_PER_ROUND]) {
+                constexpr int r = decltype(r_)::value;
+                constexpr int STAGES = SCH::stages_of(r);
+                constexpr int FIRST_POS = SCH::first_pos(r);
+                constexpr int WL = SCH::wl_of(r);
+                constexpr bool UNIFORM = (WL + R == TL); // no thread bits above the register window
+                int off = 0;
+                static_for<STAGES>([&](auto s_) {
+                    constexpr int s = decltype(s_)::value;
+                    constexpr int p = INV ? (FIRST_POS + s) : (FIRST_POS - s);
+                    constexpr int jb = p - WL;
+                    constexpr int CNT = 1 << (R - 1 - jb);
+                    // prepared layout of the distance-1/2/4 stages of full tiles: [tile][k][thread]
+                    constexpr bool PERM = CONTIG && !MULTI_POLY && (WL == 0) && (p <= 2);
+                    const int P = map.gpos(p);
+                    const unsigned stage_base = 1u << (a.n - 1 - P); // slots [2^S, 2^(S+1)), S = n-1-P
+                    const lazy::Tw64* ps;
+                    if constexpr (PERM)
+                    {
+                        const unsigned tile_in_poly = (static_cast<unsigned>(map.flat(0)) & nmask) >> TL;
+                        ps = tw_mod + stage_base + tile_in_poly * (CNT * NT) + t;
+                    }
+                    else
+                    {
+                        // UNIFORM: blockIdx and compile-time bits only -> scalar loads
+                        const unsigned idx0 =
+                            static_cast<unsigned>(map.flat(elem_of<WL>(UNIFORM ? 0 : t, 0))) & nmask;
+                        ps = tw_mod + stage_base + (idx0 >> (P + 1));
+                    }
+                    static_for<CNT>([&](auto k_) {
+                        constexpr int kk = decltype(k_)::value;
+                        if constexpr (MULTI_POLY)
+                        {
+                            // a tile may hold several polynomials: the register bits above the ring
+                            // size select the polynomial, not the twiddle -> index every entry
+                            const unsigned idx =
+                                static_cast<unsigned>(map.flat(elem_of<WL>(UNIFORM ? 0 : t, kk << (jb + 1)))) & nmask;
+                            tws[off + kk] = tw_mod[stage_base + (idx >> (P + 1))];
+                        }
+                        else
+                        {
+                            tws[off + kk] = ps[PERM ? kk * NT : kk];
+                        }
+                    });
+                    off += CNT;
+                });
+            };
+
+            // whole tile inside the batch (always true for N >= 4096) and no signed conversion
+            const bool full_tile = CONTIG ? (((static_cast<unsigned long long>(blockIdx.x) + 1) << TL) <= a.total) : true;
+            const bool plain_io = full_tile && !(a.flags & F_SIGNED_IN);
 
             T v[EPT];
+            lazy::Tw64 tw_next[TW_PER_ROUND];
+            load_twiddles(std::integral_constant<int, 0>{}, tw_next);
 
             static_for<G::NR>([&](auto r_) {
                 constexpr int r = decltype(r_)::value;
@@ -153,12 +219,13 @@ namespace gpuntt
                 constexpr int FIRST_POS = SCH::first_pos(r);
                 constexpr int WL = SCH::wl_of(r);
                 constexpr bool DIRECT_IO = (WL >= 4);
-                constexpr bool UNIFORM = (WL + R == TL); // no thread bits above the register window
 
                 // ---- gather -----------------------------------------------------------
                 if constexpr (r == 0)
                 {
-                    auto load = [&](unsigned long long f) -> T {
+                    // fast path: whole tile in range and unsigned input -> 16 independent loads
+                    // in flight; the guarded path only serves ragged last tiles / signed input
+                    auto load_guarded = [&](unsigned long long f) -> T {
                         if (f >= a.total)
                             return 0;
                         if (a.flags & F_SIGNED_IN)
@@ -168,17 +235,40 @@ namespace gpuntt
                         }
                         return static_cast<const T*>(a.in)[f];
                     };
+                    const T* src = static_cast<const T*>(a.in); // may alias a.out (in-place calls)
                     if constexpr (DIRECT_IO)
                     {
+                        if (plain_io)
+                        {
 #pragma unroll
-                        for (int j = 0; j < EPT; j++)
-                            v[j] = load(map.flat(elem_of<WL>(t, j)));
+                            for (int j = 0; j < EPT; j++)
+                                v[j] = src[map.flat(elem_of<WL>(t, j))];
+                        }
+                        else
+                        {
+#pragma unroll
+                            for (int j = 0; j < EPT; j++)
+                                v[j] = load_guarded(map.flat(elem_of<WL>(t, j)));
+                        }
                     }
                     else
                     {
+                        if (plain_io)
+                        {
+                            T tmp[EPT];
 #pragma unroll
-                        for (int j = 0; j < EPT; j++)
-                            lds[lds_pad(t + NT * j)] = load(map.flat(t + NT * j));
+                            for (int j = 0; j < EPT; j++)
+                                tmp[j] = src[map.flat(t + NT * j)];
+#pragma unroll
+                            for (int j = 0; j < EPT; j++)
+                                lds[lds_pad(t + NT * j)] = tmp[j];
+                        }
+                        else
+                        {
+#pragma unroll
+                            for (int j = 0; j < EPT; j++)
+                                lds[lds_pad(t + NT * j)] = load_guarded(map.flat(t + NT * j));
+                        }
                         __syncthreads();
 #pragma unroll
                         for (int j = 0; j < EPT; j++)
@@ -192,42 +282,23 @@ namespace gpuntt
                         v[j] = lds[lds_pad(elem_of<WL>(t, j))];
                 }
 
+                lazy::Tw64 tw_cur[TW_PER_ROUND];
+#pragma unroll
+                for (int i = 0; i < TW_PER_ROUND; i++)
+                    tw_cur[i] = tw_next[i];
+
                 // ---- butterflies ------------------------------------------------------
+                int off = 0;
                 static_for<STAGES>([&](auto s_) {
                     constexpr int s = decltype(s_)::value;
                     constexpr int p = INV ? (FIRST_POS + s) : (FIRST_POS - s);
                     constexpr int jb = p - WL;
-                    const int P = map.gpos(p);
-                    const unsigned stage_base = 1u << (a.n - 1 - P); // slots [2^S, 2^(S+1)), S = n-1-P
                     static_for<EPT / 2>([&](auto h_) {
                         constexpr int h = decltype(h_)::value;
                         constexpr int j0 = (h & ((1 << jb) - 1)) | ((h >> jb) << (jb + 1));
                         constexpr int j1 = j0 | (1 << jb);
-                        // twiddle slot
-                        unsigned ti;
-                        if constexpr (UNIFORM)
-                        {
-                            // depends on blockIdx and compile-time register bits only -> scalar load
-                            const unsigned idx0 = static_cast<unsigned>(map.flat(elem_of<WL>(0, j0))) & nmask;
-                            ti = idx0 >> (P + 1);
-                        }
-                        else
-                        {
-                            const unsigned idx = static_cast<unsigned>(map.flat(elem_of<WL>(t, j0))) & nmask;
-                            ti = idx >> (P + 1);
-                            if constexpr (CONTIG && K == TL && WL == 0 && p <= 2)
-                            {
-                                // per-thread twiddles of the distance-1/2/4 stages: [tile][k][thread]
-                                if (a.flags & F_PERM_LOW)
-                                {
-                                    constexpr int RP = EPT >> (p + 1); // twiddles per thread
-                                    constexpr int kk = j0 >> (p + 1);
-                                    const unsigned tile_in_poly = (static_cast<unsigned>(map.flat(0)) & nmask) >> TL;
-                                    ti = tile_in_poly * (RP * NT) + kk * NT + t;
-                                }
-                            }
-                        }
-                        const lazy::Tw64 tw = a.tw[root_base + stage_base + ti];
+                        constexpr int kk = j0 >> (jb + 1);
+                        const lazy::Tw64 tw = tw_cur[off + kk];
                         if constexpr (!INV)
                         {
                             constexpr int ku = SCH::d.ku[r][s][h];
@@ -252,6 +323,7 @@ namespace gpuntt
                             v[j1] = m.mul(U + m.kq(c) - V, tw);
                         }
                     });
+                    off += 1 << (R - 1 - jb);
                 });
 
                 // ---- scatter ----------------------------------------------------------
@@ -277,12 +349,21 @@ namespace gpuntt
                     }
                     if constexpr (DIRECT_IO)
                     {
-#pragma unroll
-                        for (int j = 0; j < EPT; j++)
+                        if (full_tile)
                         {
-                            const unsigned long long f = map.flat(elem_of<WL>(t, j));
-                            if (f < a.total)
-                                a.out[f] = v[j];
+#pragma unroll
+                            for (int j = 0; j < EPT; j++)
+                                a.out[map.flat(elem_of<WL>(t, j))] = v[j];
+                        }
+                        else
+                        {
+#pragma unroll
+                            for (int j = 0; j < EPT; j++)
+                            {
+                                const unsigned long long f = map.flat(elem_of<WL>(t, j));
+                                if (f < a.total)
+                                    a.out[f] = v[j];
+                            }
                         }
                     }
                     else
@@ -291,17 +372,28 @@ namespace gpuntt
                         for (int j = 0; j < EPT; j++)
                             lds[lds_pad(elem_of<WL>(t, j))] = v[j];
                         __syncthreads();
-#pragma unroll
-                        for (int j = 0; j < EPT; j++)
+                        if (full_tile)
                         {
-                            const unsigned long long f = map.flat(t + NT * j);
-                            if (f < a.total)
-                                a.out[f] = lds[lds_pad(t + NT * j)];
+#pragma unroll
+                            for (int j = 0; j < EPT; j++)
+                                a.out[map.flat(t + NT * j)] = lds[lds_pad(t + NT * j)];
+                        }
+                        else
+                        {
+#pragma unroll
+                            for (int j = 0; j < EPT; j++)
+                            {
+                                const unsigned long long f = map.flat(t + NT * j);
+                                if (f < a.total)
+                                    a.out[f] = lds[lds_pad(t + NT * j)];
+                            }
                         }
                     }
                 }
                 else
                 {
+                    // next round's twiddles are requested before the exchange barrier
+                    load_twiddles(std::integral_constant<int, r + 1>{}, tw_next);
 #pragma unroll
                     for (int j = 0; j < EPT; j++)
                         lds[lds_pad(elem_of<WL>(t, j))] = v[j];

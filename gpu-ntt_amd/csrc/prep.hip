@@ -8,6 +8,7 @@
 // contiguous round loads them fully coalesced.  Cost: N-1 64-step divisions per modulus,
 // ~1 us of chip time at N = 2^16 -- nothing is cached between calls, so a caller that
 // rewrites its table in place is always honoured.
+#include <cstdlib>
 #include <map>
 #include <mutex>
 
@@ -85,6 +86,18 @@ namespace gpuntt
             std::mutex g_ws_mutex;
             std::map<std::pair<int, hipStream_t>, Slot> g_ws;
         } // namespace
+
+        int lazy_contig_k(int n)
+        {
+            static const int forced = [] {
+                const char* e = std::getenv("GPUNTT_CONTIG_K");
+                return e ? std::atoi(e) : 0;
+            }();
+            if (forced >= 8 && forced <= 12)
+                return forced;
+            (void) n;
+            return kern::TL;
+        }
 
         void* lazy_workspace(hipStream_t stream, size_t bytes)
         {
