@@ -30,7 +30,9 @@ namespace gpuntt
             uint64_t* out;
             const lazy::Tw64* tw;            // prepared twiddles: modulus slot mi at (mi << n)
             const Modulus<uint64_t>* mods;   // device array (RNS) or nullptr
-            uint64_t q;                      // single modulus
+            uint64_t q;                      // single modulus {value, bit, mu}
+            uint64_t q_bit;
+            uint64_t q_mu;
             const lazy::Tw64* ninv_arr;      // prepared n^-1 pairs per modulus (RNS) or nullptr
             lazy::Tw64 ninv;                 // single modulus n^-1 pair
             unsigned long long total;
@@ -119,38 +121,31 @@ namespace gpuntt
         // 2^(R-1-jb) entries -> at most 1 + 2 + 4 + 8 = 15 per thread
         constexpr int TW_PER_ROUND = EPT - 1;
 
-        template <bool INV, bool CONTIG, int K, int IN_BOUND, bool LAST, int LIMIT>
-        __global__ __launch_bounds__(NT, 4) void merge_pass_lazy(LazyArgs a)
+        // EXACT = false: lazy residues (modulus with >= 4 bits of headroom, bit <= 60)
+        // EXACT = true : canonical residues with the reference's Barrett contract, for moduli
+        //                without headroom (bit 61, 62); same data movement, same twiddle table
+        //                (only the plain w half of each pair is used)
+        template <bool EXACT, bool INV, bool CONTIG, int K, int IN_BOUND, bool LAST, int LIMIT>
+        __device__ __forceinline__ void pass_body(const LazyArgs& a, uint64_t* lds, uint64_t q_value,
+                                                  uint64_t q_bit, uint64_t q_mu, int mi)
         {
             using G = Geo<CONTIG, K>;
             using SCH = PassSched<INV, CONTIG, K, IN_BOUND, LIMIT>;
             using T = uint64_t;
-            // single-round passes with coalesced register windows never touch LDS
-            constexpr bool NEEDS_LDS = (G::NR > 1) || (SCH::wl_of(0) < 4);
-            __shared__ T lds[NEEDS_LDS ? LDS_ELEMS : 1];
 
             // single-pass transforms of rings smaller than a tile: the tile holds several polynomials
             constexpr bool MULTI_POLY = CONTIG && (K < TL) && (IN_BOUND == 1) && LAST;
 
             const int t = threadIdx.x;
             const TileMap<T, CONTIG, K> map(a.n, a.p_lo);
-            const unsigned long long poly = map.flat(0) >> a.poly_shift;
             lazy::Mod64 m;
-            unsigned long long root_base = 0;
-            lazy::Tw64 ninv = a.ninv;
-            if (a.mods != nullptr)
-            {
-                const int mi = static_cast<int>(poly % static_cast<unsigned>(a.mod_count));
-                m.q = a.mods[mi].value;
-                root_base = static_cast<unsigned long long>(mi) << a.n;
-                if (LAST && INV)
-                    ninv = a.ninv_arr[mi];
-            }
-            else
-            {
-                m.q = a.q;
-            }
+            m.q = q_value;
             m.qneg = 0 - m.q;
+            const dev::ModCtx<T> em{q_value, q_bit, q_mu};
+            const unsigned long long root_base = static_cast<unsigned long long>(mi) << a.n;
+            lazy::Tw64 ninv = a.ninv;
+            if (LAST && INV && a.ninv_arr != nullptr)
+                ninv = a.ninv_arr[mi];
             const unsigned nmask = (1u << a.n) - 1u;
             const lazy::Tw64* __restrict__ tw_mod = a.tw + root_base;
 
@@ -299,7 +294,14 @@ namespace gpuntt
                         constexpr int j1 = j0 | (1 << jb);
                         constexpr int kk = j0 >> (jb + 1);
                         const lazy::Tw64 tw = tw_cur[off + kk];
-                        if constexpr (!INV)
+                        if constexpr (EXACT)
+                        {
+                            if constexpr (!INV)
+                                dev::ct_butterfly(v[j0], v[j1], tw.w, em);
+                            else
+                                dev::gs_butterfly(v[j0], v[j1], tw.w, em);
+                        }
+                        else if constexpr (!INV)
                         {
                             constexpr int ku = SCH::d.ku[r][s][h];
                             T U = v[j0];
@@ -335,13 +337,16 @@ namespace gpuntt
                             constexpr int j = decltype(j_)::value;
                             if constexpr (INV)
                             {
-                                T x = m.mul(v[j], ninv); // * n^-1, [0, 4q)
-                                x = m.template normalize<lazy::TB>(x);
+                                T x;
+                                if constexpr (EXACT)
+                                    x = em.mul(v[j], ninv.w);
+                                else
+                                    x = m.template normalize<lazy::TB>(m.mul(v[j], ninv)); // * n^-1
                                 if (a.flags & F_CENTERED)
                                     x = (x > (m.q >> 1)) ? (x - m.q) : x;
                                 v[j] = x;
                             }
-                            else
+                            else if constexpr (!EXACT)
                             {
                                 v[j] = m.template normalize<SCH::d.bout[r][j]>(v[j]);
                             }
@@ -400,6 +405,36 @@ namespace gpuntt
                     __syncthreads();
                 }
             });
+        }
+
+        template <bool INV, bool CONTIG, int K, int IN_BOUND, bool LAST, int LIMIT>
+        __global__ __launch_bounds__(NT, 4) void merge_pass_lazy(LazyArgs a)
+        {
+            using G = Geo<CONTIG, K>;
+            using SCH = PassSched<INV, CONTIG, K, IN_BOUND, LIMIT>;
+            // single-round passes with coalesced register windows never touch LDS
+            constexpr bool NEEDS_LDS = (G::NR > 1) || (SCH::wl_of(0) < 4);
+            __shared__ uint64_t lds[NEEDS_LDS ? LDS_ELEMS : 1];
+
+            // the block's modulus: polynomial index of the tile % mod_count (tiles never straddle
+            // polynomials with different moduli here: RNS calls with N < 4096 and mod_count > 1
+            // are routed to the generic kernels by the host)
+            uint64_t qv = a.q, qb = a.q_bit, qm = a.q_mu;
+            int mi = 0;
+            if (a.mods != nullptr)
+            {
+                const TileMap<uint64_t, CONTIG, K> map(a.n, a.p_lo);
+                const unsigned long long poly = map.flat(0) >> a.poly_shift;
+                mi = static_cast<int>(poly % static_cast<unsigned>(a.mod_count));
+                const Modulus<uint64_t> md = a.mods[mi];
+                qv = md.value;
+                qb = md.bit;
+                qm = md.mu;
+            }
+            if (qb <= 60) // block-uniform
+                pass_body<false, INV, CONTIG, K, IN_BOUND, LAST, LIMIT>(a, lds, qv, qb, qm, mi);
+            else
+                pass_body<true, INV, CONTIG, K, IN_BOUND, LAST, LIMIT>(a, lds, qv, qb, qm, mi);
         }
 
     } // namespace kern

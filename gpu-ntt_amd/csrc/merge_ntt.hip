@@ -60,8 +60,10 @@ namespace gpuntt
         }
 
         // ---- fast 64-bit path (lazy residues + prepared Shoup twiddles) -----------------
-        // Used for Data64 single-modulus calls whose modulus leaves 4 bits of headroom
-        // (bit <= 60); everything else runs the generic Barrett kernels.
+        // Used for Data64 calls (single modulus and RNS).  Moduli with >= 4 bits of headroom
+        // (bit <= 60) run the lazy butterflies; blocks whose modulus has bit 61/62 switch to
+        // exact Barrett butterflies inside the same kernel.  Small jobs, rings above 2^24 and
+        // RNS stacks of rings below one tile stay on the generic kernels.
         // GPUNTT_PATH=generic | fast overrides the size heuristic (testing / A-B timing);
         // moduli without the headroom always take the generic kernels.
         inline int forced_path()
@@ -79,12 +81,14 @@ namespace gpuntt
             return mode;
         }
 
-        inline bool lazy_eligible(const Modulus<Data64>& m, int n_power, int batch_size)
+        inline bool lazy_eligible(int n_power, int batch_size, int mod_count)
         {
-            if (m.bit > static_cast<Data64>(host::LAZY_MAX_BIT) || m.value < 3)
-                return false;
             if (n_power > host::LAZY_MAX_N_POWER)
                 return false;
+            if (mod_count > 1 && n_power < kern::TL)
+                return false; // a tile would mix moduli
+            if ((static_cast<unsigned long long>(mod_count) << n_power) > (1ull << 26))
+                return false; // prepared table would exceed 1 GiB
             if (forced_path() == 1)
                 return false;
             if (forced_path() == 2)
@@ -94,27 +98,34 @@ namespace gpuntt
                    batch_size >= 2;
         }
 
+        // mods == nullptr: single modulus `m`; else device array of mod_count moduli (+ optional
+        // device array of n^-1 values whose Shoup pairs are prepared alongside the twiddles)
         inline kern::LazyArgs lazy_args(const void* in, Data64* out, const Data64* roots,
-                                        const Modulus<Data64>& m, int n_power, ReductionPolynomial poly,
-                                        int batch_size, hipStream_t stream)
+                                        const Modulus<Data64>& m, const Modulus<Data64>* mods,
+                                        int mod_count, const Data64* ninv_dev, int n_power,
+                                        ReductionPolynomial poly, int batch_size, hipStream_t stream)
         {
             const bool neg = (poly == ReductionPolynomial::X_N_plus);
             const bool perm = (n_power >= kern::TL);
-            auto* ws = static_cast<lazy::Tw64*>(
-                host::lazy_workspace(stream, sizeof(lazy::Tw64) << n_power));
-            host::launch_prep(roots, ws, nullptr, m.value, 1, n_power, neg, perm, nullptr, nullptr, stream);
+            const size_t entries = (static_cast<size_t>(mod_count) << n_power) + mod_count;
+            auto* ws = static_cast<lazy::Tw64*>(host::lazy_workspace(stream, sizeof(lazy::Tw64) * entries));
+            lazy::Tw64* ws_ninv = ws + (static_cast<size_t>(mod_count) << n_power);
+            host::launch_prep(roots, ws, mods, m.value, mod_count, n_power, neg, perm, ninv_dev,
+                              ninv_dev ? ws_ninv : nullptr, stream);
             kern::LazyArgs a{};
             a.in = in;
             a.out = out;
             a.tw = ws;
-            a.mods = nullptr;
+            a.mods = mods;
             a.q = m.value;
-            a.ninv_arr = nullptr;
+            a.q_bit = m.bit;
+            a.q_mu = m.mu;
+            a.ninv_arr = ninv_dev ? ws_ninv : nullptr;
             a.ninv = lazy::Tw64{0, 0};
             a.total = static_cast<unsigned long long>(batch_size) << n_power;
             a.n = n_power;
             a.poly_shift = n_power;
-            a.mod_count = 1;
+            a.mod_count = mod_count;
             a.p_lo = 0;
             a.flags = perm ? kern::F_PERM_LOW : 0u;
             return a;
@@ -140,10 +151,11 @@ namespace gpuntt
         const unsigned in_flags = std::is_signed<T>::value ? kern::F_SIGNED_IN : 0u;
         if constexpr (std::is_same<TU, Data64>::value)
         {
-            if (batch_size > 0 && lazy_eligible(modulus, cfg.n_power, batch_size))
+            if (batch_size > 0 && modulus.value >= 3 && lazy_eligible(cfg.n_power, batch_size, 1))
             {
-                kern::LazyArgs la = lazy_args(device_in, device_out, root_of_unity_table, modulus,
-                                              cfg.n_power, cfg.reduction_poly, batch_size, cfg.stream);
+                kern::LazyArgs la =
+                    lazy_args(device_in, device_out, root_of_unity_table, modulus, nullptr, 1, nullptr,
+                              cfg.n_power, cfg.reduction_poly, batch_size, cfg.stream);
                 host::run_transform_lazy<false>(la, in_flags, 0u, cfg.stream);
                 return;
             }
@@ -167,12 +179,13 @@ namespace gpuntt
             kern::F_SCALE | (std::is_signed<T>::value ? kern::F_CENTERED : 0u);
         if constexpr (std::is_same<TU, Data64>::value)
         {
-            if (batch_size > 0 && lazy_eligible(modulus, cfg.n_power, batch_size) &&
+            if (batch_size > 0 && modulus.value >= 3 && lazy_eligible(cfg.n_power, batch_size, 1) &&
                 cfg.mod_inverse < modulus.value)
             {
                 kern::LazyArgs la =
                     lazy_args(device_in, reinterpret_cast<Data64*>(device_out), root_of_unity_table,
-                              modulus, cfg.n_power, cfg.reduction_poly, batch_size, cfg.stream);
+                              modulus, nullptr, 1, nullptr, cfg.n_power, cfg.reduction_poly, batch_size,
+                              cfg.stream);
                 la.ninv = lazy::Tw64{cfg.mod_inverse, host::shoup_host(cfg.mod_inverse, modulus.value)};
                 host::run_transform_lazy<true>(la, 0u, out_flags, cfg.stream);
                 return;
@@ -212,12 +225,23 @@ namespace gpuntt
         check_layout_and_range(cfg.ntt_layout, cfg.n_power);
         if (mod_count <= 0 || modulus == nullptr)
             throw std::invalid_argument("Invalid mod_count!");
+        const unsigned in_flags = std::is_signed<T>::value ? kern::F_SIGNED_IN : 0u;
+        if constexpr (std::is_same<TU, Data64>::value)
+        {
+            if (batch_size > 0 && lazy_eligible(cfg.n_power, batch_size, mod_count))
+            {
+                kern::LazyArgs la =
+                    lazy_args(device_in, device_out, root_of_unity_table, Modulus<Data64>(), modulus,
+                              mod_count, nullptr, cfg.n_power, cfg.reduction_poly, batch_size, cfg.stream);
+                host::run_transform_lazy<false>(la, in_flags, 0u, cfg.stream);
+                return;
+            }
+        }
         kern::PassArgs<TU> a = base_args<TU>(device_in, device_out, root_of_unity_table, cfg.n_power,
                                              cfg.reduction_poly, batch_size);
         a.mods = modulus;
         a.mod_count = mod_count;
         set_multi(a);
-        const unsigned in_flags = std::is_signed<T>::value ? kern::F_SIGNED_IN : 0u;
         host::run_transform<TU, false>(a, in_flags, 0u, cfg.stream);
     }
 
@@ -232,6 +256,21 @@ namespace gpuntt
         check_layout_and_range(cfg.ntt_layout, cfg.n_power);
         if (mod_count <= 0 || modulus == nullptr)
             throw std::invalid_argument("Invalid mod_count!");
+        const unsigned out_flags =
+            kern::F_SCALE | (std::is_signed<T>::value ? kern::F_CENTERED : 0u);
+        if constexpr (std::is_same<TU, Data64>::value)
+        {
+            if (batch_size > 0 && cfg.mod_inverse != nullptr &&
+                lazy_eligible(cfg.n_power, batch_size, mod_count))
+            {
+                kern::LazyArgs la = lazy_args(device_in, reinterpret_cast<Data64*>(device_out),
+                                              root_of_unity_table, Modulus<Data64>(), modulus, mod_count,
+                                              cfg.mod_inverse, cfg.n_power, cfg.reduction_poly,
+                                              batch_size, cfg.stream);
+                host::run_transform_lazy<true>(la, 0u, out_flags, cfg.stream);
+                return;
+            }
+        }
         kern::PassArgs<TU> a =
             base_args<TU>(device_in, reinterpret_cast<TU*>(device_out), root_of_unity_table,
                           cfg.n_power, cfg.reduction_poly, batch_size);
@@ -239,8 +278,6 @@ namespace gpuntt
         a.mod_count = mod_count;
         a.ninv_arr = cfg.mod_inverse;
         set_multi(a);
-        const unsigned out_flags =
-            kern::F_SCALE | (std::is_signed<T>::value ? kern::F_CENTERED : 0u);
         host::run_transform<TU, true>(a, 0u, out_flags, cfg.stream);
     }
 

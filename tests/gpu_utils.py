@@ -65,3 +65,50 @@ class MergeCase:
             g.GPU_INTT(d_in, d_out, self.inv_dev, self.prm.modulus, self.cfg(True), batch)
         torch.cuda.synchronize()
         return g.to_host(d_out)
+
+
+def _is_probable_prime(n):
+    if n < 2:
+        return False
+    for p in (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37):
+        if n % p == 0:
+            return n == p
+    d, s = n - 1, 0
+    while d % 2 == 0:
+        d //= 2
+        s += 1
+    for a in (2, 325, 9375, 28178, 450775, 9780504, 1795265022):
+        a %= n
+        if a == 0:
+            continue
+        x = pow(a, d, n)
+        if x in (1, n - 1):
+            continue
+        for _ in range(s - 1):
+            x = x * x % n
+            if x == n - 1:
+                break
+        else:
+            return False
+    return True
+
+
+def find_ntt_factors(bits, logn, skip=0):
+    """(q, omega, psi) for an NTT prime with exactly `bits` bits and 2^(logn+1) | q-1
+    (psi of order 2N, omega = psi^2), found by search -- used to exercise moduli the
+    reference's pools do not contain (61/62-bit: no lazy headroom)."""
+    step = 1 << (logn + 1)
+    q = ((1 << bits) - 1) // step * step + 1
+    found = 0
+    while True:
+        if q.bit_length() == bits and _is_probable_prime(q):
+            if found == skip:
+                break
+            found += 1
+        q -= step
+    g = 2
+    while True:
+        psi = pow(g, (q - 1) >> (logn + 1), q)
+        if pow(psi, 1 << logn, q) == q - 1:
+            return q, psi * psi % q, psi
+        g += 1

@@ -1,0 +1,74 @@
+"""world_size-2 `gloo` test of the batch-shard layer (gpu-ntt_amd/dist.py) on CPU.
+
+The product has no CPU transform, so inside this test the per-rank "transform" is the oracle;
+what is being tested is the partition (shard_range incl. RNS alignment), the barrier +
+MAX-reduced timing bracket bench.py uses, and the digest gather: sharded result == unsharded."""
+import hashlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys, hashlib
+import numpy as np
+sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
+from conftest import load_pkg
+g = load_pkg()
+import importlib
+dist_mod = importlib.import_module("gpu_ntt_amd.dist")
+from oracle import oracle as O
+dist, rank, world = dist_mod.init_process_group("gloo")
+assert world == 2 and dist is not None
+P = O.Port(64)
+logn, batch, mc = 8, 24, 3
+n = 1 << logn
+prms = [P.merge_params(logn, O.X_N_plus, f) for f in FACTORS]
+lo, hi = g.shard_range(batch, rank, world, mc)
+assert lo % mc == 0 and hi % mc == 0
+# every rank regenerates only its own polynomials (global index p decides seed and modulus)
+x = np.concatenate([P.splitmix(100 + p, 0, n, prms[p % mc]["mod"][0]) for p in range(lo, hi)])
+state = {}
+def step():
+    state["y"] = np.concatenate([P.merge_ntt(x[i * n:(i + 1) * n], prms[(lo + i) % mc])
+                                 for i in range(hi - lo)])
+wall = dist_mod.timed_region(step, 2, dist, None)
+assert wall > 0
+digs = dist_mod.gather_digests(state["y"], dist)
+if rank == 0:
+    print("DIGESTS", " ".join(digs), "SPAN", lo, hi, flush=True)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_gloo_sharded_equals_unsharded(tmp_path):
+    from oracle import oracle as O
+    P = O.Port(64)
+    logn, batch, mc = 8, 24, 3
+    n = 1 << logn
+    factors = []
+    for lg in (12, 13, 14):
+        prm = P.fourstep_params(lg, with_W=False)
+        q = prm["mod"][0]
+        psi = pow(prm["psi"], 1 << (lg - logn), q)
+        factors.append((q, psi * psi % q, psi))
+    script = tmp_path / "worker.py"
+    script.write_text("ROOT = %r\nFACTORS = %r\n" % (ROOT, factors) + WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                        "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29531",
+                        str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("DIGESTS")][0].split()
+    digs = line[1:3]
+    # unsharded reference run in this process
+    prms = [P.merge_params(logn, O.X_N_plus, f) for f in factors]
+    full = [P.merge_ntt(P.splitmix(100 + p, 0, n, prms[p % mc]["mod"][0]), prms[p % mc])
+            for p in range(batch)]
+    want = [hashlib.sha256(np.concatenate(full[0:12]).tobytes()).hexdigest(),
+            hashlib.sha256(np.concatenate(full[12:24]).tobytes()).hexdigest()]
+    assert digs == want

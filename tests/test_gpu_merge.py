@@ -299,3 +299,39 @@ def test_both_kernel_paths_all_sizes(g, path):
     """The 64-bit fast path (lazy residues, prepared Shoup twiddles) and the generic Barrett
     path must each be bit-exact for every ring size, regardless of the size heuristic."""
     assert "SWEEP-OK" in _run_in_subprocess(_SWEEP, path)
+
+
+def test_moduli_without_lazy_headroom(g):
+    """61- and 62-bit primes (the reference's documented Data64 limit, modular_arith.cuh:66-67)
+    run the exact-Barrett branch of the fast kernels; an RNS stack mixing 60/61/62-bit moduli
+    exercises the per-block switch."""
+    import torch
+    from gpu_utils import find_ntt_factors
+    for bits in (61, 62):
+        for logn in (12, 14):
+            f = find_ntt_factors(bits, logn)
+            assert f[0].bit_length() == bits
+            for poly in (O.X_N_plus, O.X_N_minus):
+                c = MergeCase(g, 64, logn, poly, f)
+                assert c.prm.modulus.bit == bits
+                x = c.random(4, bits + logn)
+                want = c.P.merge_ntt(x, c.oprm)
+                assert np.array_equal(c.gpu_forward(x), want)
+                assert np.array_equal(c.gpu_inverse(want, inplace=True), x)
+    logn, batch = 13, 9
+    fl = [find_ntt_factors(62, logn), find_ntt_factors(60, logn), find_ntt_factors(61, logn)]
+    cases, fwd, inv, mods, ninv = _rns_setup(g, 64, logn, O.X_N_plus, fl)
+    n = 1 << logn
+    x = np.concatenate([cases[p % 3].P.splitmix(70 + p, 0, n, cases[p % 3].q) for p in range(batch)])
+    want = np.concatenate([cases[p % 3].P.merge_ntt(x[p * n:(p + 1) * n], cases[p % 3].oprm)
+                           for p in range(batch)])
+    d = g.to_device(x)
+    g.GPU_NTT_Inplace(d, fwd, mods, g.ntt_rns_configuration(n_power=logn, reduction_poly=O.X_N_plus),
+                      batch, 3)
+    torch.cuda.synchronize()
+    assert np.array_equal(g.to_host(d), want)
+    g.GPU_INTT_Inplace(d, inv, mods,
+                       g.ntt_rns_configuration(n_power=logn, ntt_type=g.INVERSE,
+                                               reduction_poly=O.X_N_plus, mod_inverse=ninv), batch, 3)
+    torch.cuda.synchronize()
+    assert np.array_equal(g.to_host(d), x)
