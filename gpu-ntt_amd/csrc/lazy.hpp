@@ -1,4 +1,4 @@
-// lazy64.hpp -- lazy-range 64-bit modular arithmetic for the fast Merge-NTT kernels (gfx950).
+// lazy.hpp -- lazy-range 64-bit and 32-bit modular arithmetic for the fast Merge-NTT kernels (gfx950).
 //
 // Measured on MI355X (tools/ubench_int.hip, profiles/ubench_int_r01.txt): v_mad_u64_u32 /
 // v_mul_{lo,hi}_u32 issue at ~4.3-5.1 cycles per wave, the same class as most VALU ops, while
@@ -9,9 +9,11 @@
 //     kernel, prep.hip), so  x*w mod q  =  x*w - qh*q  with  qh ~ hi64(x*w')  -- 9 multiply-class
 //     instructions, no shifts, no compare;
 //   * qh drops the low partial products (error <= 3), so the product lands in [0, 4q);
-//   * values are kept in [0, B*q) with B tracked at COMPILE TIME per register (bound.hpp);
+//   * values are kept in [0, B*q) with B tracked at COMPILE TIME per register (PassSched);
 //     a conditional subtraction is emitted only where U + 4q could overflow LIMIT*q < 2^64.
 //     For q < 2^60 (LIMIT = 16) that is one correction per two stages on the U input.
+//   * 32-bit moduli (q < 2^30): exact one-instruction quotient, products in [0, 2q), LIMIT 4,
+//     corrections are a subtract + unsigned min.
 //
 // Every kernel output is normalised to the canonical residue in [0, q), which is unique, so
 // the transform is bit-identical to the reference's Barrett code.
@@ -25,20 +27,40 @@ namespace gpuntt
 {
     namespace lazy
     {
-        struct alignas(16) Tw64
+        // twiddle + precomputed quotient floor(w * 2^W / q), W = 8 * sizeof(T)
+        template <typename T> struct Tw;
+        template <> struct alignas(16) Tw<uint64_t>
         {
-            uint64_t w;  // twiddle, canonical
-            uint64_t wp; // floor(w * 2^64 / q)
+            uint64_t w;
+            uint64_t wp;
         };
+        template <> struct alignas(8) Tw<uint32_t>
+        {
+            uint32_t w;
+            uint32_t wp;
+        };
+        using Tw64 = Tw<uint64_t>;
+        using Tw32 = Tw<uint32_t>;
 
         __device__ __forceinline__ uint32_t lo32(uint64_t v) { return static_cast<uint32_t>(v); }
         __device__ __forceinline__ uint32_t hi32(uint64_t v) { return static_cast<uint32_t>(v >> 32); }
 
-        struct Mod64
+        template <typename T> struct Mod;
+
+        // ---- 64-bit: sloppy-quotient Shoup product in [0, 4q); LIMIT 16 needs q < 2^60 ------
+        template <> struct Mod<uint64_t>
         {
+            static constexpr int TB = 4;      // product bound (units of q)
+            static constexpr int LIMIT = 16;  // lazy values stay below LIMIT * q < 2^64
+            static constexpr int MAX_BIT = 60;
             uint64_t q;
             uint64_t qneg; // 2^64 - q
 
+            __device__ __forceinline__ void set(uint64_t modulus)
+            {
+                q = modulus;
+                qneg = 0 - modulus;
+            }
             __device__ __forceinline__ uint64_t kq(int k) const { return q * static_cast<uint64_t>(k); }
 
             // x * w  (mod q), any x < 2^64, result in [0, 4q)
@@ -56,25 +78,48 @@ namespace gpuntt
                 const uint64_t m = kq(K);
                 return (x >= m) ? (x - m) : x;
             }
+        };
 
-            // [0, B*q) -> [0, q)
-            template <int B> __device__ __forceinline__ uint64_t normalize(uint64_t x) const
+        // ---- 32-bit: exact-quotient Shoup product in [0, 2q); q < 2^30 => LIMIT 4 ------------
+        template <> struct Mod<uint32_t>
+        {
+            static constexpr int TB = 2;
+            static constexpr int LIMIT = 4;
+            static constexpr int MAX_BIT = 30;
+            uint32_t q;
+
+            __device__ __forceinline__ void set(uint32_t modulus) { q = modulus; }
+            __device__ __forceinline__ uint32_t kq(int k) const { return q * static_cast<uint32_t>(k); }
+
+            __device__ __forceinline__ uint32_t mul(uint32_t x, const Tw32& t) const
             {
-                if constexpr (B > 8)
-                    x = csub<8>(x);
-                if constexpr (B > 4)
-                    x = csub<4>(x);
-                if constexpr (B > 2)
-                    x = csub<2>(x);
-                if constexpr (B > 1)
-                    x = csub<1>(x);
-                return x;
+                const uint32_t qh = __umulhi(x, t.wp);
+                return x * t.w - qh * q;
+            }
+
+            // x < 2*k*q:  min(x, x - k*q) as unsigned (the difference wraps above x when x < k*q)
+            template <int K> __device__ __forceinline__ uint32_t csub(uint32_t x) const
+            {
+                const uint32_t d = x - kq(K);
+                return d < x ? d : x;
             }
         };
 
-        // ---- compile-time range bookkeeping (units of q) --------------------------------
-        constexpr int TB = 4; // mul() output bound
+        // [0, B*q) -> [0, q)
+        template <int B, typename T> __device__ __forceinline__ T normalize(const Mod<T>& m, T x)
+        {
+            if constexpr (B > 8)
+                x = m.template csub<8>(x);
+            if constexpr (B > 4)
+                x = m.template csub<4>(x);
+            if constexpr (B > 2)
+                x = m.template csub<2>(x);
+            if constexpr (B > 1)
+                x = m.template csub<1>(x);
+            return x;
+        }
 
+        // ---- compile-time range bookkeeping (units of q) --------------------------------
         constexpr int ceil_pow2(int v)
         {
             int p = 1;
@@ -85,27 +130,27 @@ namespace gpuntt
         // conditional subtraction amount that halves a bound b (b <= 2k): k = ceil_pow2(b) / 2
         constexpr int csub_k(int b) { return ceil_pow2(b) / 2; }
 
-        // Cooley-Tukey (forward) butterfly plan for input bounds (bu, bv) under LIMIT:
-        //   U' = U + T, V' = U - T + 4q  with  T = V*w in [0, 4q)
+        // Cooley-Tukey (forward) butterfly plan for an input bound bu under `limit`:
+        //   U' = U + T, V' = U - T + tb*q  with  T = V*w in [0, tb*q)
         struct CtPlan
         {
             int ku;  // 0, or conditional-subtract k*q from U first
             int out; // bound of both outputs
         };
-        constexpr CtPlan ct_plan(int bu, int limit)
+        constexpr CtPlan ct_plan(int bu, int limit, int tb)
         {
             CtPlan p{0, 0};
-            if (bu + TB > limit)
+            if (bu + tb > limit)
             {
                 p.ku = csub_k(bu);
                 bu = p.ku;
             }
-            p.out = bu + TB;
+            p.out = bu + tb;
             return p;
         }
 
         // Gentleman-Sande (inverse) butterfly plan:
-        //   U' = U + V, V' = (U - V + c*q) * w  with  c >= bound(V), output V' in [0, 4q)
+        //   U' = U + V, V' = (U - V + c*q) * w  with  c >= bound(V), output V' in [0, tb*q)
         struct GsPlan
         {
             int ku, kv; // conditional subtractions applied first (0 = none)

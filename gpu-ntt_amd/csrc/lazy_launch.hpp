@@ -11,50 +11,104 @@ namespace gpuntt
 {
     namespace host
     {
-        constexpr int LAZY_LIMIT = 16;      // q < 2^60  =>  16 q < 2^64
-        constexpr int LAZY_MAX_BIT = 60;    // Modulus<T>::bit bound for the fast path
-        constexpr int LAZY_MAX_N_POWER = 24; // prepared table = 16 B * N per modulus
+        constexpr int LAZY_MAX_N_POWER = 24; // prepared table = 2 words * N per modulus
+
+        // tile size (log2) used by the fast kernels for element type T and ring size 2^n:
+        // 64-bit: 4096 coefficients (32 KiB of LDS); 32-bit: 16384 coefficients (64 KiB) once the
+        // ring no longer fits a 4096 tile, so rings up to 2^14 are a single HBM sweep
+        template <typename T> constexpr int lazy_tile_log(int n)
+        {
+            return (sizeof(T) == 4 && n > 12) ? 14 : 12;
+        }
 
         // per-(device, stream) scratch for prepared twiddles; grows on demand, stream-ordered reuse
         void* lazy_workspace(hipStream_t stream, size_t bytes);
 
         // fills ws[0 .. mod_count*N) with Shoup pairs of the caller's table (device order) and
-        // ws_ninv[0 .. mod_count) with the pairs of n^-1 (RNS only)
-        void launch_prep(const uint64_t* roots, lazy::Tw64* ws, const Modulus<uint64_t>* mods, uint64_t q,
-                         int mod_count, int n, bool negacyclic, bool perm_low, const uint64_t* ninv_arr,
-                         lazy::Tw64* ws_ninv, hipStream_t stream);
+        // ws_ninv[0 .. mod_count) with the pairs of n^-1 (RNS only); perm_tile_log > 0 permutes
+        // the distance-1/2/4 stages for tiles of that size
+        template <typename T>
+        void launch_prep(const T* roots, lazy::Tw<T>* ws, const Modulus<T>* mods, T q, int mod_count, int n,
+                         bool negacyclic, int perm_tile_log, const T* ninv_arr, lazy::Tw<T>* ws_ninv,
+                         unsigned* go_flag, hipStream_t stream);
+        extern template void launch_prep<uint64_t>(const uint64_t*, lazy::Tw64*, const Modulus<uint64_t>*,
+                                                   uint64_t, int, int, bool, int, const uint64_t*,
+                                                   lazy::Tw64*, unsigned*, hipStream_t);
+        extern template void launch_prep<uint32_t>(const uint32_t*, lazy::Tw32*, const Modulus<uint32_t>*,
+                                                   uint32_t, int, int, bool, int, const uint32_t*,
+                                                   lazy::Tw32*, unsigned*, hipStream_t);
 
-        // host Shoup companion floor(w * 2^64 / q)
+        // host Shoup companion floor(w * 2^W / q)
         inline uint64_t shoup_host(uint64_t w, uint64_t q)
         {
             return static_cast<uint64_t>((static_cast<unsigned __int128>(w) << 64) / q);
+        }
+        inline uint32_t shoup_host(uint32_t w, uint32_t q)
+        {
+            return static_cast<uint32_t>((static_cast<uint64_t>(w) << 32) / q);
+        }
+
+        // pass list for the fast kernels: like make_plan but with the tile size as a parameter
+        inline Plan make_plan_tl(int n, int tl, int contig_k)
+        {
+            Plan pl{};
+            pl.count = 0;
+            if (n <= tl)
+            {
+                pl.pass[pl.count++] = Pass{true, n, 0};
+                return pl;
+            }
+            if (contig_k > tl)
+                contig_k = tl;
+            if (contig_k < tl - 4)
+                contig_k = tl - 4;
+            const int s = n - contig_k;
+            const int np = (s + 7) / 8;
+            int top = n;
+            for (int i = 0; i < np; i++)
+            {
+                const int k = s / np + ((i < s % np) ? 1 : 0);
+                top -= k;
+                pl.pass[pl.count++] = Pass{false, k, top};
+            }
+            pl.pass[pl.count++] = Pass{true, contig_k, 0};
+            return pl;
         }
 
         // stages handled by the contiguous pass of the fast path (GPUNTT_CONTIG_K overrides, 8..12)
         int lazy_contig_k(int n);
 
-        template <bool INV> void launch_pass_lazy(const Pass& p, int in_bound, bool last, const kern::LazyArgs& a,
-                                                 hipStream_t stream);
-        extern template void launch_pass_lazy<false>(const Pass&, int, bool, const kern::LazyArgs&, hipStream_t);
-        extern template void launch_pass_lazy<true>(const Pass&, int, bool, const kern::LazyArgs&, hipStream_t);
+        // in_first: the pass reads canonical input (first pass of the transform)
+        template <typename T, bool INV>
+        void launch_pass_lazy(const Pass& p, int tile_log, bool in_first, bool last,
+                              const kern::LazyArgsT<T>& a, hipStream_t stream);
+        extern template void launch_pass_lazy<uint64_t, false>(const Pass&, int, bool, bool,
+                                                               const kern::LazyArgsT<uint64_t>&, hipStream_t);
+        extern template void launch_pass_lazy<uint64_t, true>(const Pass&, int, bool, bool,
+                                                              const kern::LazyArgsT<uint64_t>&, hipStream_t);
+        extern template void launch_pass_lazy<uint32_t, false>(const Pass&, int, bool, bool,
+                                                               const kern::LazyArgsT<uint32_t>&, hipStream_t);
+        extern template void launch_pass_lazy<uint32_t, true>(const Pass&, int, bool, bool,
+                                                              const kern::LazyArgsT<uint32_t>&, hipStream_t);
 
-        template <bool INV>
-        inline void run_transform_lazy(kern::LazyArgs base, unsigned first_in_flags, unsigned last_out_flags,
-                                       hipStream_t stream)
+        template <typename T, bool INV>
+        inline void run_transform_lazy(kern::LazyArgsT<T> base, unsigned first_in_flags,
+                                       unsigned last_out_flags, hipStream_t stream)
         {
-            const Plan pl = make_plan(base.n, lazy_contig_k(base.n));
+            const int tl = lazy_tile_log<T>(base.n);
+            const Plan pl = make_plan_tl(base.n, tl, tl == 12 ? lazy_contig_k(base.n) : tl);
             const void* src = base.in;
             for (int i = 0; i < pl.count; i++)
             {
                 const Pass& p = INV ? pl.pass[pl.count - 1 - i] : pl.pass[i];
-                kern::LazyArgs a = base;
+                kern::LazyArgsT<T> a = base;
                 a.in = src;
                 a.p_lo = p.p_lo;
                 if (i == 0)
                     a.flags |= first_in_flags;
                 if (i == pl.count - 1)
                     a.flags |= last_out_flags;
-                launch_pass_lazy<INV>(p, i == 0 ? 1 : LAZY_LIMIT, i == pl.count - 1, a, stream);
+                launch_pass_lazy<T, INV>(p, tl, i == 0, i == pl.count - 1, a, stream);
                 src = base.out;
             }
         }

@@ -1,4 +1,4 @@
-// lazy_launch_impl.hpp -- kernel dispatch of the fast 64-bit path (included by lazy_*.hip only)
+// lazy_launch_impl.hpp -- kernel dispatch of the fast path (included by lazy_*.hip only)
 #pragma once
 
 #include "lazy_launch.hpp"
@@ -7,130 +7,160 @@ namespace gpuntt
 {
     namespace host
     {
-        template <bool INV, bool CONTIG, int K, int IN_BOUND, bool LAST>
-        inline void launch_lazy_one(const kern::LazyArgs& a, unsigned grid, hipStream_t stream)
+        template <typename T, int TLOG, bool INV, bool CONTIG, int K, int IN_BOUND, bool LAST>
+        inline void launch_lazy_one(const kern::LazyArgsT<T>& a, unsigned grid, hipStream_t stream)
         {
-            hipLaunchKernelGGL((kern::merge_pass_lazy<INV, CONTIG, K, IN_BOUND, LAST, LAZY_LIMIT>), dim3(grid),
-                               dim3(kern::NT), 0, stream, a);
+            hipLaunchKernelGGL((kern::merge_pass_lazy<T, TLOG, INV, CONTIG, K, IN_BOUND, LAST>), dim3(grid),
+                               dim3(kern::LTile<TLOG>::NT), 0, stream, a);
             GPUNTT_HIP_CHECK(hipGetLastError());
         }
 
-        // instantiated combinations (see lazy_launch.hpp::run_transform_lazy):
-        //   forward: STRIDED (IN 1 | 16, not last), CONTIG K=12 (IN 16, last), CONTIG K<=12 (IN 1, last)
-        //   inverse: CONTIG K=12 (IN 1, not last), CONTIG K<=12 (IN 1, last), STRIDED (IN 16, last | not)
-        template <bool INV>
-        void launch_pass_lazy(const Pass& p, int in_bound, bool last, const kern::LazyArgs& a, hipStream_t stream)
+        // Instantiated pass shapes (everything run_transform_lazy can ask for):
+        //   single pass       CONTIG K = n <= TLOG              (IN 1, last)   [TLOG 14: K = 13, 14 only]
+        //   forward, n > TLOG STRIDED K 1..8 (IN 1 | LIMIT, not last) + CONTIG K (IN LIMIT, last)
+        //   inverse, n > TLOG CONTIG K (IN 1, not last) + STRIDED K 1..8 (IN LIMIT, last | not last)
+        //   with CONTIG K in 8..12 for 4096-coefficient tiles and K = 14 for 16384-coefficient tiles
+        template <typename T, int TLOG, bool INV>
+        void dispatch_tl(const Pass& p, bool in_first, bool last, const kern::LazyArgsT<T>& a,
+                         hipStream_t stream)
         {
-            const unsigned long long tiles = (a.total + kern::TILE - 1) >> kern::TL;
+            constexpr int LIM = lazy::Mod<T>::LIMIT;
+            constexpr int TILE = kern::LTile<TLOG>::TILE;
+            const unsigned long long tiles = (a.total + TILE - 1) >> TLOG;
             if (tiles == 0)
                 return;
             if (tiles > 0x7fffffffull)
                 throw std::invalid_argument("batch_size * N too large for one launch");
             const unsigned grid = static_cast<unsigned>(tiles);
-            constexpr int LIM = LAZY_LIMIT;
+#define GPUNTT_ONE(CONTIG_, K_, IN_, LAST_)                                                      \
+    return launch_lazy_one<T, TLOG, INV, CONTIG_, K_, IN_, LAST_>(a, grid, stream)
             if (p.contig)
             {
-                if constexpr (!INV)
+                if (in_first && last)
                 {
-                    if (in_bound != 1 && last)
+                    if constexpr (TLOG == 12)
                         switch (p.k)
                         {
-                            case 8: return launch_lazy_one<false, true, 8, LIM, true>(a, grid, stream);
-                            case 9: return launch_lazy_one<false, true, 9, LIM, true>(a, grid, stream);
-                            case 10: return launch_lazy_one<false, true, 10, LIM, true>(a, grid, stream);
-                            case 11: return launch_lazy_one<false, true, 11, LIM, true>(a, grid, stream);
-                            case 12: return launch_lazy_one<false, true, 12, LIM, true>(a, grid, stream);
-                            default: throw std::invalid_argument("internal: bad lazy contiguous pass");
+                            case 1: GPUNTT_ONE(true, 1, 1, true);
+                            case 2: GPUNTT_ONE(true, 2, 1, true);
+                            case 3: GPUNTT_ONE(true, 3, 1, true);
+                            case 4: GPUNTT_ONE(true, 4, 1, true);
+                            case 5: GPUNTT_ONE(true, 5, 1, true);
+                            case 6: GPUNTT_ONE(true, 6, 1, true);
+                            case 7: GPUNTT_ONE(true, 7, 1, true);
+                            case 8: GPUNTT_ONE(true, 8, 1, true);
+                            case 9: GPUNTT_ONE(true, 9, 1, true);
+                            case 10: GPUNTT_ONE(true, 10, 1, true);
+                            case 11: GPUNTT_ONE(true, 11, 1, true);
+                            case 12: GPUNTT_ONE(true, 12, 1, true);
+                            default: break;
                         }
-                }
-                else
-                {
-                    if (in_bound == 1 && !last)
+                    else
                         switch (p.k)
                         {
-                            case 8: return launch_lazy_one<true, true, 8, 1, false>(a, grid, stream);
-                            case 9: return launch_lazy_one<true, true, 9, 1, false>(a, grid, stream);
-                            case 10: return launch_lazy_one<true, true, 10, 1, false>(a, grid, stream);
-                            case 11: return launch_lazy_one<true, true, 11, 1, false>(a, grid, stream);
-                            case 12: return launch_lazy_one<true, true, 12, 1, false>(a, grid, stream);
-                            default: throw std::invalid_argument("internal: bad lazy contiguous pass");
+                            case 13: GPUNTT_ONE(true, 13, 1, true);
+                            case 14: GPUNTT_ONE(true, 14, 1, true);
+                            default: break;
                         }
                 }
-                if (in_bound != 1 || !last)
-                    throw std::invalid_argument("internal: unsupported lazy contiguous pass");
-                switch (p.k)
+                else if (!INV && !in_first && last)
                 {
-#define GPUNTT_CASE(KK)                                                                          \
-    case KK:                                                                                      \
-        return launch_lazy_one<INV, true, KK, 1, true>(a, grid, stream);
-                    GPUNTT_CASE(1)
-                    GPUNTT_CASE(2)
-                    GPUNTT_CASE(3)
-                    GPUNTT_CASE(4)
-                    GPUNTT_CASE(5)
-                    GPUNTT_CASE(6)
-                    GPUNTT_CASE(7)
-                    GPUNTT_CASE(8)
-                    GPUNTT_CASE(9)
-                    GPUNTT_CASE(10)
-                    GPUNTT_CASE(11)
-                    GPUNTT_CASE(12)
-#undef GPUNTT_CASE
-                    default:
-                        throw std::invalid_argument("internal: bad contiguous pass size");
+                    if constexpr (!INV)
+                    {
+                        if constexpr (TLOG == 12 && sizeof(T) == 8)
+                            switch (p.k)
+                            {
+                                case 8: GPUNTT_ONE(true, 8, LIM, true);
+                                case 9: GPUNTT_ONE(true, 9, LIM, true);
+                                case 10: GPUNTT_ONE(true, 10, LIM, true);
+                                case 11: GPUNTT_ONE(true, 11, LIM, true);
+                                case 12: GPUNTT_ONE(true, 12, LIM, true);
+                                default: break;
+                            }
+                        else if constexpr (TLOG == 14)
+                            if (p.k == 14)
+                                GPUNTT_ONE(true, 14, LIM, true);
+                    }
                 }
+                else if (INV && in_first && !last)
+                {
+                    if constexpr (INV)
+                    {
+                        if constexpr (TLOG == 12 && sizeof(T) == 8)
+                            switch (p.k)
+                            {
+                                case 8: GPUNTT_ONE(true, 8, 1, false);
+                                case 9: GPUNTT_ONE(true, 9, 1, false);
+                                case 10: GPUNTT_ONE(true, 10, 1, false);
+                                case 11: GPUNTT_ONE(true, 11, 1, false);
+                                case 12: GPUNTT_ONE(true, 12, 1, false);
+                                default: break;
+                            }
+                        else if constexpr (TLOG == 14)
+                            if (p.k == 14)
+                                GPUNTT_ONE(true, 14, 1, false);
+                    }
+                }
+                throw std::invalid_argument("internal: unsupported contiguous pass in the fast path");
             }
-            else
+            // strided passes exist only for rings larger than the tile
+            if constexpr ((TLOG == 12 && sizeof(T) == 8) || TLOG == 14)
             {
                 if constexpr (!INV)
                 {
-                    if (last)
-                        throw std::invalid_argument("internal: forward strided pass cannot be last");
-                    switch (p.k * 2 + (in_bound == 1 ? 1 : 0))
-                    {
+                    if (!last)
+                        switch (p.k * 2 + (in_first ? 1 : 0))
+                        {
 #define GPUNTT_CASE(KK)                                                                          \
-    case KK * 2 + 1:                                                                              \
-        return launch_lazy_one<false, false, KK, 1, false>(a, grid, stream);                      \
-    case KK * 2:                                                                                  \
-        return launch_lazy_one<false, false, KK, LIM, false>(a, grid, stream);
-                        GPUNTT_CASE(1)
-                        GPUNTT_CASE(2)
-                        GPUNTT_CASE(3)
-                        GPUNTT_CASE(4)
-                        GPUNTT_CASE(5)
-                        GPUNTT_CASE(6)
-                        GPUNTT_CASE(7)
-                        GPUNTT_CASE(8)
+    case KK * 2 + 1: GPUNTT_ONE(false, KK, 1, false);                                            \
+    case KK * 2: GPUNTT_ONE(false, KK, LIM, false);
+                            GPUNTT_CASE(1)
+                            GPUNTT_CASE(2)
+                            GPUNTT_CASE(3)
+                            GPUNTT_CASE(4)
+                            GPUNTT_CASE(5)
+                            GPUNTT_CASE(6)
+                            GPUNTT_CASE(7)
+                            GPUNTT_CASE(8)
 #undef GPUNTT_CASE
-                        default:
-                            throw std::invalid_argument("internal: bad strided pass size");
-                    }
+                            default: break;
+                        }
                 }
                 else
                 {
-                    if (in_bound == 1)
-                        throw std::invalid_argument("internal: inverse strided pass cannot be first");
-                    switch (p.k * 2 + (last ? 1 : 0))
-                    {
+                    if (!in_first)
+                        switch (p.k * 2 + (last ? 1 : 0))
+                        {
 #define GPUNTT_CASE(KK)                                                                          \
-    case KK * 2 + 1:                                                                              \
-        return launch_lazy_one<true, false, KK, LIM, true>(a, grid, stream);                      \
-    case KK * 2:                                                                                  \
-        return launch_lazy_one<true, false, KK, LIM, false>(a, grid, stream);
-                        GPUNTT_CASE(1)
-                        GPUNTT_CASE(2)
-                        GPUNTT_CASE(3)
-                        GPUNTT_CASE(4)
-                        GPUNTT_CASE(5)
-                        GPUNTT_CASE(6)
-                        GPUNTT_CASE(7)
-                        GPUNTT_CASE(8)
+    case KK * 2 + 1: GPUNTT_ONE(false, KK, LIM, true);                                           \
+    case KK * 2: GPUNTT_ONE(false, KK, LIM, false);
+                            GPUNTT_CASE(1)
+                            GPUNTT_CASE(2)
+                            GPUNTT_CASE(3)
+                            GPUNTT_CASE(4)
+                            GPUNTT_CASE(5)
+                            GPUNTT_CASE(6)
+                            GPUNTT_CASE(7)
+                            GPUNTT_CASE(8)
 #undef GPUNTT_CASE
-                        default:
-                            throw std::invalid_argument("internal: bad strided pass size");
-                    }
+                            default: break;
+                        }
                 }
             }
+#undef GPUNTT_ONE
+            throw std::invalid_argument("internal: unsupported strided pass in the fast path");
+        }
+
+        template <typename T, bool INV>
+        void launch_pass_lazy(const Pass& p, int tile_log, bool in_first, bool last,
+                              const kern::LazyArgsT<T>& a, hipStream_t stream)
+        {
+            if (tile_log == 12)
+                return dispatch_tl<T, 12, INV>(p, in_first, last, a, stream);
+            if constexpr (sizeof(T) == 4)
+                if (tile_log == 14)
+                    return dispatch_tl<T, 14, INV>(p, in_first, last, a, stream);
+            throw std::invalid_argument("internal: unsupported tile size in the fast path");
         }
     } // namespace host
 } // namespace gpuntt

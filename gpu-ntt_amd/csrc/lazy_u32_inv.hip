@@ -1,0 +1,5 @@
+// lazy_u32_inv.hip -- instantiates the inv fast-path kernels for uint32_t (lazy residues).
+#include "lazy_launch_impl.hpp"
+namespace gpuntt { namespace host {
+template void launch_pass_lazy<uint32_t, true>(const Pass&, int, bool, bool, const kern::LazyArgsT<uint32_t>&, hipStream_t);
+} }

@@ -1,0 +1,5 @@
+// lazy_u64_inv.hip -- instantiates the inv fast-path kernels for uint64_t (lazy residues).
+#include "lazy_launch_impl.hpp"
+namespace gpuntt { namespace host {
+template void launch_pass_lazy<uint64_t, true>(const Pass&, int, bool, bool, const kern::LazyArgsT<uint64_t>&, hipStream_t);
+} }

@@ -61,6 +61,7 @@ namespace gpuntt
             const T* ninv_arr;      // device array (RNS) or nullptr
             T ninv;
             const T* w_table;       // 4-step W matrix (F_FOURSTEP_T) or nullptr
+            const unsigned* skip_flag; // device word or nullptr: != 0 -> the fast path owns this call
             unsigned long long total; // batch * N coefficients
             int n;          // log2 of the transform length (twiddle indexing)
             int poly_shift; // log2 of the polynomial length (modulus selection: flat >> poly_shift)
@@ -245,6 +246,8 @@ namespace gpuntt
             using S = typename std::make_signed<T>::type;
             __shared__ T lds[LDS_ELEMS];
 
+            if (a.skip_flag != nullptr && *a.skip_flag != 0u)
+                return;
             const int t = threadIdx.x;
             const TileMap<T, CONTIG, K> map(a);
             // block-uniform context (exact when the tile lies inside one polynomial; with

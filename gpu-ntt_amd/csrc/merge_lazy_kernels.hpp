@@ -11,7 +11,7 @@
 // (src/lib/ntt_merge/ntt.cu:596-761, 1086-1318).
 #pragma once
 
-#include "lazy64.hpp"
+#include "lazy.hpp"
 #include "merge_kernels.hpp"
 
 namespace gpuntt
@@ -24,17 +24,18 @@ namespace gpuntt
                              // implied by n >= 12, i.e. by the CONTIG K = 12 kernel itself
         };
 
-        struct LazyArgs
+        template <typename T> struct LazyArgsT
         {
             const void* in;
-            uint64_t* out;
-            const lazy::Tw64* tw;            // prepared twiddles: modulus slot mi at (mi << n)
-            const Modulus<uint64_t>* mods;   // device array (RNS) or nullptr
-            uint64_t q;                      // single modulus {value, bit, mu}
-            uint64_t q_bit;
-            uint64_t q_mu;
-            const lazy::Tw64* ninv_arr;      // prepared n^-1 pairs per modulus (RNS) or nullptr
-            lazy::Tw64 ninv;                 // single modulus n^-1 pair
+            T* out;
+            const lazy::Tw<T>* tw;           // prepared twiddles: modulus slot mi at (mi << n)
+            const Modulus<T>* mods;          // device array (RNS) or nullptr
+            T q;                             // single modulus {value, bit, mu}
+            T q_bit;
+            T q_mu;
+            const lazy::Tw<T>* ninv_arr;     // prepared n^-1 pairs per modulus (RNS) or nullptr
+            lazy::Tw<T> ninv;                // single modulus n^-1 pair
+            const unsigned* go_flag;         // RNS: device word, 1 = every modulus has lazy headroom
             unsigned long long total;
             int n;
             int poly_shift;
@@ -42,11 +43,68 @@ namespace gpuntt
             int p_lo;
             unsigned flags;
         };
+        using LazyArgs = LazyArgsT<uint64_t>;
+
+        // ---- tile geometry of the fast kernels: 2^TLOG coefficients, 2^(TLOG-R) threads --------
+        template <int TLOG> struct LTile
+        {
+            static constexpr int TL = TLOG;
+            static constexpr int NT = 1 << (TLOG - R);
+            static constexpr int TILE = 1 << TLOG;
+            static constexpr int LDS_ELEMS = TILE + (TILE >> 4);
+        };
+        template <int TLOG, bool CONTIG, int K> struct LGeo
+        {
+            static constexpr int L = CONTIG ? 0 : (TLOG - K);
+            static constexpr int NR = (K + R - 1) / R;
+        };
+        template <int TLOG, bool CONTIG, int K> struct LTileMap
+        {
+            unsigned long long base;
+            int p_lo;
+            __device__ __forceinline__ LTileMap(int n, int pass_p_lo)
+            {
+                constexpr int L = LGeo<TLOG, CONTIG, K>::L;
+                if constexpr (CONTIG)
+                {
+                    base = static_cast<unsigned long long>(blockIdx.x) << TLOG;
+                    p_lo = 0;
+                }
+                else
+                {
+                    p_lo = pass_p_lo;
+                    const unsigned long long blk = blockIdx.x;
+                    const unsigned long long poly = blk >> (n - TLOG);
+                    const unsigned long long b = blk & ((1ull << (n - TLOG)) - 1);
+                    const unsigned long long xb = b & ((1ull << (p_lo - L)) - 1);
+                    const unsigned long long hi = b >> (p_lo - L);
+                    base = (poly << n) | (hi << (p_lo + K)) | (xb << L);
+                }
+            }
+            __device__ __forceinline__ unsigned long long flat(int e) const
+            {
+                constexpr int L = LGeo<TLOG, CONTIG, K>::L;
+                if constexpr (CONTIG)
+                    return base + static_cast<unsigned>(e);
+                else
+                    return base | (static_cast<unsigned long long>(e >> L) << p_lo) |
+                           static_cast<unsigned>(e & ((1 << L) - 1));
+            }
+            __device__ __forceinline__ int gpos(int p) const
+            {
+                constexpr int L = LGeo<TLOG, CONTIG, K>::L;
+                if constexpr (CONTIG)
+                    return p;
+                else
+                    return p_lo + (p - L);
+            }
+        };
 
         // ---- compile-time schedule of range corrections for one pass --------------------
-        template <bool INV, bool CONTIG, int K, int IN_BOUND, int LIMIT> struct PassSched
+        template <int TLOG, bool INV, bool CONTIG, int K, int IN_BOUND, int LIMIT, int TB> struct PassSched
         {
-            using G = Geo<CONTIG, K>;
+            using G = LGeo<TLOG, CONTIG, K>;
+            static constexpr int TL = TLOG;
             static constexpr int NR = G::NR;
             struct Data
             {
@@ -87,7 +145,7 @@ namespace gpuntt
                             const int j1 = j0 | (1 << jb);
                             if (!INV)
                             {
-                                const lazy::CtPlan pl = lazy::ct_plan(b[j0], LIMIT);
+                                const lazy::CtPlan pl = lazy::ct_plan(b[j0], LIMIT, TB);
                                 d.ku[r][s][h] = pl.ku;
                                 b[j0] = b[j1] = pl.out;
                             }
@@ -98,7 +156,7 @@ namespace gpuntt
                                 d.kv[r][s][h] = pl.kv;
                                 d.c[r][s][h] = pl.c;
                                 b[j0] = pl.out_u;
-                                b[j1] = lazy::TB;
+                                b[j1] = TB;
                             }
                         }
                     }
@@ -121,38 +179,42 @@ namespace gpuntt
         // 2^(R-1-jb) entries -> at most 1 + 2 + 4 + 8 = 15 per thread
         constexpr int TW_PER_ROUND = EPT - 1;
 
-        // EXACT = false: lazy residues (modulus with >= 4 bits of headroom, bit <= 60)
-        // EXACT = true : canonical residues with the reference's Barrett contract, for moduli
-        //                without headroom (bit 61, 62); same data movement, same twiddle table
-        //                (only the plain w half of each pair is used)
-        template <bool EXACT, bool INV, bool CONTIG, int K, int IN_BOUND, bool LAST, int LIMIT>
-        __device__ __forceinline__ void pass_body(const LazyArgs& a, uint64_t* lds, uint64_t q_value,
-                                                  uint64_t q_bit, uint64_t q_mu, int mi)
+        // EXACT = false: lazy residues (modulus with >= 4 bits of headroom, bit <= 60) -- the only
+        //                variant instantiated: fusing both behind a run-time branch cost the lazy
+        //                path its register allocation (spills), so moduli without headroom are
+        //                served by the generic kernels (merge_kernels.hpp) instead
+        // EXACT = true : canonical residues with the reference's Barrett contract on the same
+        //                data movement (kept for experiments)
+        template <typename T, int TLOG, bool EXACT, bool INV, bool CONTIG, int K, int IN_BOUND, bool LAST>
+        __device__ __forceinline__ void pass_body(const LazyArgsT<T>& a, T* lds, T q_value, T q_bit, T q_mu,
+                                                  int mi)
         {
-            using G = Geo<CONTIG, K>;
-            using SCH = PassSched<INV, CONTIG, K, IN_BOUND, LIMIT>;
-            using T = uint64_t;
+            using G = LGeo<TLOG, CONTIG, K>;
+            using M = lazy::Mod<T>;
+            using SCH = PassSched<TLOG, INV, CONTIG, K, IN_BOUND, M::LIMIT, M::TB>;
+            using TW = lazy::Tw<T>;
+            constexpr int TL = TLOG;
+            constexpr int NT = LTile<TLOG>::NT;
 
             // single-pass transforms of rings smaller than a tile: the tile holds several polynomials
             constexpr bool MULTI_POLY = CONTIG && (K < TL) && (IN_BOUND == 1) && LAST;
 
             const int t = threadIdx.x;
-            const TileMap<T, CONTIG, K> map(a.n, a.p_lo);
-            lazy::Mod64 m;
-            m.q = q_value;
-            m.qneg = 0 - m.q;
+            const LTileMap<TLOG, CONTIG, K> map(a.n, a.p_lo);
+            M m;
+            m.set(q_value);
             const dev::ModCtx<T> em{q_value, q_bit, q_mu};
             const unsigned long long root_base = static_cast<unsigned long long>(mi) << a.n;
-            lazy::Tw64 ninv = a.ninv;
+            TW ninv = a.ninv;
             if (LAST && INV && a.ninv_arr != nullptr)
                 ninv = a.ninv_arr[mi];
             const unsigned nmask = (1u << a.n) - 1u;
-            const lazy::Tw64* __restrict__ tw_mod = a.tw + root_base;
+            const TW* __restrict__ tw_mod = a.tw + root_base;
 
             // Issues every twiddle load of round r (15 x 16 B per thread, or scalar loads when the
             // round is block-uniform).  Called one round ahead, in front of the LDS barrier, so the
             // L2 latency is covered by the previous round's butterflies and the exchange.
-            auto load_twiddles = [&](auto r_, lazy::Tw64(&tws)[TW_PER_ROUND]) {
+            auto load_twiddles = [&](auto r_, TW(&tws)[TW_PER_ROUND]) {
                 constexpr int r = decltype(r_)::value;
                 constexpr int STAGES = SCH::stages_of(r);
                 constexpr int FIRST_POS = SCH::first_pos(r);
@@ -168,7 +230,7 @@ namespace gpuntt
                     constexpr bool PERM = CONTIG && !MULTI_POLY && (WL == 0) && (p <= 2);
                     const int P = map.gpos(p);
                     const unsigned stage_base = 1u << (a.n - 1 - P); // slots [2^S, 2^(S+1)), S = n-1-P
-                    const lazy::Tw64* ps;
+                    const TW* ps;
                     if constexpr (PERM)
                     {
                         const unsigned tile_in_poly = (static_cast<unsigned>(map.flat(0)) & nmask) >> TL;
@@ -183,7 +245,18 @@ namespace gpuntt
                     }
                     static_for<CNT>([&](auto k_) {
                         constexpr int kk = decltype(k_)::value;
-                        if constexpr (MULTI_POLY)
+                        if constexpr (CONTIG && !MULTI_POLY && (WL != 0) && (p <= 2))
+                        {
+                            // distance-1/2/4 stage that is not in the 16-contiguous-coefficient round
+                            // (contiguous passes of 9 or 10 stages): address the permuted layout
+                            // [tile][k][16-coefficient group] entry by entry
+                            const unsigned e0 = elem_of<WL>(t, kk << (jb + 1));
+                            const unsigned tile_in_poly = (static_cast<unsigned>(map.flat(0)) & nmask) >> TL;
+                            constexpr int RP = EPT >> (p + 1);
+                            tws[off + kk] = tw_mod[stage_base + tile_in_poly * (RP * NT) +
+                                                   ((e0 & (EPT - 1)) >> (p + 1)) * NT + (e0 >> R)];
+                        }
+                        else if constexpr (MULTI_POLY)
                         {
                             // a tile may hold several polynomials: the register bits above the ring
                             // size select the polynomial, not the twiddle -> index every entry
@@ -205,7 +278,7 @@ namespace gpuntt
             const bool plain_io = full_tile && !(a.flags & F_SIGNED_IN);
 
             T v[EPT];
-            lazy::Tw64 tw_next[TW_PER_ROUND];
+            TW tw_next[TW_PER_ROUND];
             load_twiddles(std::integral_constant<int, 0>{}, tw_next);
 
             static_for<G::NR>([&](auto r_) {
@@ -225,7 +298,8 @@ namespace gpuntt
                             return 0;
                         if (a.flags & F_SIGNED_IN)
                         {
-                            const long long sv = static_cast<const long long*>(a.in)[f];
+                            using S = typename std::make_signed<T>::type;
+                            const S sv = static_cast<const S*>(a.in)[f];
                             return (sv < 0) ? static_cast<T>(m.q + static_cast<T>(sv)) : static_cast<T>(sv);
                         }
                         return static_cast<const T*>(a.in)[f];
@@ -277,7 +351,7 @@ namespace gpuntt
                         v[j] = lds[lds_pad(elem_of<WL>(t, j))];
                 }
 
-                lazy::Tw64 tw_cur[TW_PER_ROUND];
+                TW tw_cur[TW_PER_ROUND];
 #pragma unroll
                 for (int i = 0; i < TW_PER_ROUND; i++)
                     tw_cur[i] = tw_next[i];
@@ -293,7 +367,7 @@ namespace gpuntt
                         constexpr int j0 = (h & ((1 << jb) - 1)) | ((h >> jb) << (jb + 1));
                         constexpr int j1 = j0 | (1 << jb);
                         constexpr int kk = j0 >> (jb + 1);
-                        const lazy::Tw64 tw = tw_cur[off + kk];
+                        const TW tw = tw_cur[off + kk];
                         if constexpr (EXACT)
                         {
                             if constexpr (!INV)
@@ -309,7 +383,7 @@ namespace gpuntt
                                 U = m.template csub<ku>(U);
                             const T Tm = m.mul(v[j1], tw);
                             v[j0] = U + Tm;
-                            v[j1] = U + m.kq(lazy::TB) - Tm;
+                            v[j1] = U + m.kq(M::TB) - Tm;
                         }
                         else
                         {
@@ -341,14 +415,14 @@ namespace gpuntt
                                 if constexpr (EXACT)
                                     x = em.mul(v[j], ninv.w);
                                 else
-                                    x = m.template normalize<lazy::TB>(m.mul(v[j], ninv)); // * n^-1
+                                    x = lazy::normalize<M::TB>(m, m.mul(v[j], ninv)); // * n^-1
                                 if (a.flags & F_CENTERED)
                                     x = (x > (m.q >> 1)) ? (x - m.q) : x;
                                 v[j] = x;
                             }
                             else if constexpr (!EXACT)
                             {
-                                v[j] = m.template normalize<SCH::d.bout[r][j]>(v[j]);
+                                v[j] = lazy::normalize<SCH::d.bout[r][j]>(m, v[j]);
                             }
                         });
                     }
@@ -407,34 +481,44 @@ namespace gpuntt
             });
         }
 
-        template <bool INV, bool CONTIG, int K, int IN_BOUND, bool LAST, int LIMIT>
-        __global__ __launch_bounds__(NT, 4) void merge_pass_lazy(LazyArgs a)
+        // waves per SIMD requested from the register allocator (128 VGPRs): four 256-thread
+        // tiles or one 1024-thread tile per CU.  (Two 1024-thread tiles per CU would need <= 64
+        // VGPRs; the 32-bit kernels want ~70 and spill heavily under that cap.)
+        template <int TLOG> struct LOcc
         {
-            using G = Geo<CONTIG, K>;
-            using SCH = PassSched<INV, CONTIG, K, IN_BOUND, LIMIT>;
+            static constexpr int WAVES = 4;
+        };
+
+        template <typename T, int TLOG, bool INV, bool CONTIG, int K, int IN_BOUND, bool LAST>
+        __global__ __launch_bounds__(LTile<TLOG>::NT, LOcc<TLOG>::WAVES) void merge_pass_lazy(LazyArgsT<T> a)
+        {
+            using G = LGeo<TLOG, CONTIG, K>;
+            using M = lazy::Mod<T>;
+            using SCH = PassSched<TLOG, INV, CONTIG, K, IN_BOUND, M::LIMIT, M::TB>;
             // single-round passes with coalesced register windows never touch LDS
             constexpr bool NEEDS_LDS = (G::NR > 1) || (SCH::wl_of(0) < 4);
-            __shared__ uint64_t lds[NEEDS_LDS ? LDS_ELEMS : 1];
+            __shared__ T lds[NEEDS_LDS ? LTile<TLOG>::LDS_ELEMS : 1];
 
+            // RNS calls: the twiddle-prep kernel publishes whether every modulus has the lazy
+            // headroom; if not, the generic kernels launched alongside do the work
+            if (a.go_flag != nullptr && *a.go_flag == 0u)
+                return;
             // the block's modulus: polynomial index of the tile % mod_count (tiles never straddle
-            // polynomials with different moduli here: RNS calls with N < 4096 and mod_count > 1
+            // polynomials with different moduli here: RNS calls with N < tile and mod_count > 1
             // are routed to the generic kernels by the host)
-            uint64_t qv = a.q, qb = a.q_bit, qm = a.q_mu;
+            T qv = a.q, qb = a.q_bit, qm = a.q_mu;
             int mi = 0;
             if (a.mods != nullptr)
             {
-                const TileMap<uint64_t, CONTIG, K> map(a.n, a.p_lo);
+                const LTileMap<TLOG, CONTIG, K> map(a.n, a.p_lo);
                 const unsigned long long poly = map.flat(0) >> a.poly_shift;
                 mi = static_cast<int>(poly % static_cast<unsigned>(a.mod_count));
-                const Modulus<uint64_t> md = a.mods[mi];
+                const Modulus<T> md = a.mods[mi];
                 qv = md.value;
                 qb = md.bit;
                 qm = md.mu;
             }
-            if (qb <= 60) // block-uniform
-                pass_body<false, INV, CONTIG, K, IN_BOUND, LAST, LIMIT>(a, lds, qv, qb, qm, mi);
-            else
-                pass_body<true, INV, CONTIG, K, IN_BOUND, LAST, LIMIT>(a, lds, qv, qb, qm, mi);
+            pass_body<T, TLOG, false, INV, CONTIG, K, IN_BOUND, LAST>(a, lds, qv, qb, qm, mi);
         }
 
     } // namespace kern

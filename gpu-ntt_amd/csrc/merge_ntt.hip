@@ -60,10 +60,13 @@ namespace gpuntt
         }
 
         // ---- fast 64-bit path (lazy residues + prepared Shoup twiddles) -----------------
-        // Used for Data64 calls (single modulus and RNS).  Moduli with >= 4 bits of headroom
-        // (bit <= 60) run the lazy butterflies; blocks whose modulus has bit 61/62 switch to
-        // exact Barrett butterflies inside the same kernel.  Small jobs, rings above 2^24 and
-        // RNS stacks of rings below one tile stay on the generic kernels.
+        // Used for Data64 calls whose moduli leave >= 4 bits of headroom (bit <= 60).
+        //   single modulus: the host sees Modulus<T>::bit and picks the path;
+        //   RNS: the moduli live in device memory, so the twiddle-prep kernel classifies them and
+        //        publishes a go-flag; the fast kernels AND the generic kernels are both enqueued,
+        //        each returning at once when the flag says the call belongs to the other family.
+        // Small jobs, rings above 2^24 and RNS stacks of rings below one tile use the generic
+        // kernels only.
         // GPUNTT_PATH=generic | fast overrides the size heuristic (testing / A-B timing);
         // moduli without the headroom always take the generic kernels.
         inline int forced_path()
@@ -81,11 +84,11 @@ namespace gpuntt
             return mode;
         }
 
-        inline bool lazy_eligible(int n_power, int batch_size, int mod_count)
+        template <typename TU> inline bool lazy_eligible(int n_power, int batch_size, int mod_count)
         {
             if (n_power > host::LAZY_MAX_N_POWER)
                 return false;
-            if (mod_count > 1 && n_power < kern::TL)
+            if (mod_count > 1 && n_power < host::lazy_tile_log<TU>(n_power))
                 return false; // a tile would mix moduli
             if ((static_cast<unsigned long long>(mod_count) << n_power) > (1ull << 26))
                 return false; // prepared table would exceed 1 GiB
@@ -100,19 +103,23 @@ namespace gpuntt
 
         // mods == nullptr: single modulus `m`; else device array of mod_count moduli (+ optional
         // device array of n^-1 values whose Shoup pairs are prepared alongside the twiddles)
-        inline kern::LazyArgs lazy_args(const void* in, Data64* out, const Data64* roots,
-                                        const Modulus<Data64>& m, const Modulus<Data64>* mods,
-                                        int mod_count, const Data64* ninv_dev, int n_power,
-                                        ReductionPolynomial poly, int batch_size, hipStream_t stream)
+        template <typename TU>
+        inline kern::LazyArgsT<TU> lazy_args(const void* in, TU* out, const TU* roots, const Modulus<TU>& m,
+                                            const Modulus<TU>* mods, int mod_count, const TU* ninv_dev,
+                                            int n_power, ReductionPolynomial poly, int batch_size,
+                                            hipStream_t stream)
         {
+            using TW = lazy::Tw<TU>;
             const bool neg = (poly == ReductionPolynomial::X_N_plus);
-            const bool perm = (n_power >= kern::TL);
+            const int tl = host::lazy_tile_log<TU>(n_power);
+            const int perm_tile_log = (n_power >= tl) ? tl : 0;
             const size_t entries = (static_cast<size_t>(mod_count) << n_power) + mod_count;
-            auto* ws = static_cast<lazy::Tw64*>(host::lazy_workspace(stream, sizeof(lazy::Tw64) * entries));
-            lazy::Tw64* ws_ninv = ws + (static_cast<size_t>(mod_count) << n_power);
-            host::launch_prep(roots, ws, mods, m.value, mod_count, n_power, neg, perm, ninv_dev,
-                              ninv_dev ? ws_ninv : nullptr, stream);
-            kern::LazyArgs a{};
+            auto* ws = static_cast<TW*>(host::lazy_workspace(stream, sizeof(TW) * (entries + 2)));
+            TW* ws_ninv = ws + (static_cast<size_t>(mod_count) << n_power);
+            unsigned* go_flag = mods ? reinterpret_cast<unsigned*>(ws + entries) : nullptr;
+            host::launch_prep<TU>(roots, ws, mods, m.value, mod_count, n_power, neg, perm_tile_log, ninv_dev,
+                                  ninv_dev ? ws_ninv : nullptr, go_flag, stream);
+            kern::LazyArgsT<TU> a{};
             a.in = in;
             a.out = out;
             a.tw = ws;
@@ -121,13 +128,14 @@ namespace gpuntt
             a.q_bit = m.bit;
             a.q_mu = m.mu;
             a.ninv_arr = ninv_dev ? ws_ninv : nullptr;
-            a.ninv = lazy::Tw64{0, 0};
+            a.ninv = TW{0, 0};
+            a.go_flag = go_flag;
             a.total = static_cast<unsigned long long>(batch_size) << n_power;
             a.n = n_power;
             a.poly_shift = n_power;
             a.mod_count = mod_count;
             a.p_lo = 0;
-            a.flags = perm ? kern::F_PERM_LOW : 0u;
+            a.flags = 0u;
             return a;
         }
 
@@ -149,16 +157,14 @@ namespace gpuntt
         using TU = typename std::make_unsigned<T>::type;
         check_layout_and_range(cfg.ntt_layout, cfg.n_power);
         const unsigned in_flags = std::is_signed<T>::value ? kern::F_SIGNED_IN : 0u;
-        if constexpr (std::is_same<TU, Data64>::value)
+        if (batch_size > 0 && modulus.value >= 3 && modulus.bit <= TU(lazy::Mod<TU>::MAX_BIT) &&
+            lazy_eligible<TU>(cfg.n_power, batch_size, 1))
         {
-            if (batch_size > 0 && modulus.value >= 3 && lazy_eligible(cfg.n_power, batch_size, 1))
-            {
-                kern::LazyArgs la =
-                    lazy_args(device_in, device_out, root_of_unity_table, modulus, nullptr, 1, nullptr,
+            kern::LazyArgsT<TU> la =
+                lazy_args<TU>(device_in, device_out, root_of_unity_table, modulus, nullptr, 1, nullptr,
                               cfg.n_power, cfg.reduction_poly, batch_size, cfg.stream);
-                host::run_transform_lazy<false>(la, in_flags, 0u, cfg.stream);
-                return;
-            }
+            host::run_transform_lazy<TU, false>(la, in_flags, 0u, cfg.stream);
+            return;
         }
         kern::PassArgs<TU> a = base_args<TU>(device_in, device_out, root_of_unity_table, cfg.n_power,
                                              cfg.reduction_poly, batch_size);
@@ -177,19 +183,15 @@ namespace gpuntt
         check_layout_and_range(cfg.ntt_layout, cfg.n_power);
         const unsigned out_flags =
             kern::F_SCALE | (std::is_signed<T>::value ? kern::F_CENTERED : 0u);
-        if constexpr (std::is_same<TU, Data64>::value)
+        if (batch_size > 0 && modulus.value >= 3 && modulus.bit <= TU(lazy::Mod<TU>::MAX_BIT) &&
+            lazy_eligible<TU>(cfg.n_power, batch_size, 1) && cfg.mod_inverse < modulus.value)
         {
-            if (batch_size > 0 && modulus.value >= 3 && lazy_eligible(cfg.n_power, batch_size, 1) &&
-                cfg.mod_inverse < modulus.value)
-            {
-                kern::LazyArgs la =
-                    lazy_args(device_in, reinterpret_cast<Data64*>(device_out), root_of_unity_table,
-                              modulus, nullptr, 1, nullptr, cfg.n_power, cfg.reduction_poly, batch_size,
-                              cfg.stream);
-                la.ninv = lazy::Tw64{cfg.mod_inverse, host::shoup_host(cfg.mod_inverse, modulus.value)};
-                host::run_transform_lazy<true>(la, 0u, out_flags, cfg.stream);
-                return;
-            }
+            kern::LazyArgsT<TU> la =
+                lazy_args<TU>(device_in, reinterpret_cast<TU*>(device_out), root_of_unity_table, modulus,
+                              nullptr, 1, nullptr, cfg.n_power, cfg.reduction_poly, batch_size, cfg.stream);
+            la.ninv = lazy::Tw<TU>{cfg.mod_inverse, host::shoup_host(cfg.mod_inverse, modulus.value)};
+            host::run_transform_lazy<TU, true>(la, 0u, out_flags, cfg.stream);
+            return;
         }
         kern::PassArgs<TU> a =
             base_args<TU>(device_in, reinterpret_cast<TU*>(device_out), root_of_unity_table,
@@ -226,21 +228,20 @@ namespace gpuntt
         if (mod_count <= 0 || modulus == nullptr)
             throw std::invalid_argument("Invalid mod_count!");
         const unsigned in_flags = std::is_signed<T>::value ? kern::F_SIGNED_IN : 0u;
-        if constexpr (std::is_same<TU, Data64>::value)
+        const unsigned* skip_flag = nullptr;
+        if (batch_size > 0 && lazy_eligible<TU>(cfg.n_power, batch_size, mod_count))
         {
-            if (batch_size > 0 && lazy_eligible(cfg.n_power, batch_size, mod_count))
-            {
-                kern::LazyArgs la =
-                    lazy_args(device_in, device_out, root_of_unity_table, Modulus<Data64>(), modulus,
-                              mod_count, nullptr, cfg.n_power, cfg.reduction_poly, batch_size, cfg.stream);
-                host::run_transform_lazy<false>(la, in_flags, 0u, cfg.stream);
-                return;
-            }
+            kern::LazyArgsT<TU> la =
+                lazy_args<TU>(device_in, device_out, root_of_unity_table, Modulus<TU>(), modulus, mod_count,
+                              nullptr, cfg.n_power, cfg.reduction_poly, batch_size, cfg.stream);
+            host::run_transform_lazy<TU, false>(la, in_flags, 0u, cfg.stream);
+            skip_flag = la.go_flag;
         }
         kern::PassArgs<TU> a = base_args<TU>(device_in, device_out, root_of_unity_table, cfg.n_power,
                                              cfg.reduction_poly, batch_size);
         a.mods = modulus;
         a.mod_count = mod_count;
+        a.skip_flag = skip_flag;
         set_multi(a);
         host::run_transform<TU, false>(a, in_flags, 0u, cfg.stream);
     }
@@ -258,18 +259,16 @@ namespace gpuntt
             throw std::invalid_argument("Invalid mod_count!");
         const unsigned out_flags =
             kern::F_SCALE | (std::is_signed<T>::value ? kern::F_CENTERED : 0u);
-        if constexpr (std::is_same<TU, Data64>::value)
+        const unsigned* skip_flag = nullptr;
+        if (batch_size > 0 && cfg.mod_inverse != nullptr &&
+            lazy_eligible<TU>(cfg.n_power, batch_size, mod_count))
         {
-            if (batch_size > 0 && cfg.mod_inverse != nullptr &&
-                lazy_eligible(cfg.n_power, batch_size, mod_count))
-            {
-                kern::LazyArgs la = lazy_args(device_in, reinterpret_cast<Data64*>(device_out),
-                                              root_of_unity_table, Modulus<Data64>(), modulus, mod_count,
-                                              cfg.mod_inverse, cfg.n_power, cfg.reduction_poly,
-                                              batch_size, cfg.stream);
-                host::run_transform_lazy<true>(la, 0u, out_flags, cfg.stream);
-                return;
-            }
+            kern::LazyArgsT<TU> la =
+                lazy_args<TU>(device_in, reinterpret_cast<TU*>(device_out), root_of_unity_table,
+                              Modulus<TU>(), modulus, mod_count, cfg.mod_inverse, cfg.n_power,
+                              cfg.reduction_poly, batch_size, cfg.stream);
+            host::run_transform_lazy<TU, true>(la, 0u, out_flags, cfg.stream);
+            skip_flag = la.go_flag;
         }
         kern::PassArgs<TU> a =
             base_args<TU>(device_in, reinterpret_cast<TU*>(device_out), root_of_unity_table,
@@ -277,6 +276,7 @@ namespace gpuntt
         a.mods = modulus;
         a.mod_count = mod_count;
         a.ninv_arr = cfg.mod_inverse;
+        a.skip_flag = skip_flag;
         set_multi(a);
         host::run_transform<TU, true>(a, 0u, out_flags, cfg.stream);
     }

@@ -18,12 +18,12 @@ namespace gpuntt
 {
     namespace kern
     {
-        __device__ __forceinline__ uint64_t shoup_quotient(uint64_t w, uint64_t q)
+        // floor(w * 2^W / q) for w < q by restoring division (q < 2^(W-2))
+        template <typename T> __device__ __forceinline__ T shoup_quotient(T w, T q)
         {
-            // floor(w * 2^64 / q) for w < q < 2^62 by restoring division
-            uint64_t rem = w, quo = 0;
+            T rem = w, quo = 0;
 #pragma unroll 8
-            for (int i = 0; i < 64; i++)
+            for (int i = 0; i < static_cast<int>(8 * sizeof(T)); i++)
             {
                 rem <<= 1;
                 const bool ge = rem >= q;
@@ -33,44 +33,57 @@ namespace gpuntt
             return quo;
         }
 
-        __global__ __launch_bounds__(256) void prep_twiddles(const uint64_t* __restrict__ roots,
-                                                             lazy::Tw64* __restrict__ ws,
-                                                             const Modulus<uint64_t>* __restrict__ mods,
-                                                             uint64_t q_single, int mod_count, int n,
-                                                             int negacyclic, int perm_low,
-                                                             const uint64_t* __restrict__ ninv_arr,
-                                                             lazy::Tw64* __restrict__ ws_ninv)
+        template <typename T>
+        __global__ __launch_bounds__(256) void prep_twiddles(const T* __restrict__ roots,
+                                                             lazy::Tw<T>* __restrict__ ws,
+                                                             const Modulus<T>* __restrict__ mods, T q_single,
+                                                             int mod_count, int n, int negacyclic,
+                                                             int perm_tile_log,
+                                                             const T* __restrict__ ninv_arr,
+                                                             lazy::Tw<T>* __restrict__ ws_ninv,
+                                                             unsigned* __restrict__ go_flag)
         {
             const unsigned long long gid = blockIdx.x * 256ull + threadIdx.x;
+            if (gid == 0 && go_flag != nullptr)
+            {
+                // every modulus must leave the lazy kernels their headroom
+                unsigned ok = 1u;
+                for (int i = 0; i < mod_count; i++)
+                    if (mods[i].bit > static_cast<T>(lazy::Mod<T>::MAX_BIT) || mods[i].value < 3)
+                        ok = 0u;
+                *go_flag = ok;
+            }
             const unsigned long long per_mod = 1ull << n;
             if (gid >= per_mod * mod_count)
                 return;
             const int mi = static_cast<int>(gid >> n);
             const unsigned slot = static_cast<unsigned>(gid & (per_mod - 1));
-            const uint64_t q = (mods != nullptr) ? mods[mi].value : q_single;
+            const T q = (mods != nullptr) ? mods[mi].value : q_single;
             if (slot == 0)
             {
                 if (ninv_arr != nullptr && ws_ninv != nullptr)
                 {
-                    const uint64_t v = ninv_arr[mi];
-                    ws_ninv[mi] = lazy::Tw64{v, shoup_quotient(v, q)};
+                    const T v = ninv_arr[mi];
+                    ws_ninv[mi] = lazy::Tw<T>{v, shoup_quotient<T>(v, q)};
                 }
-                ws[gid] = lazy::Tw64{0, 0};
+                ws[gid] = lazy::Tw<T>{0, 0};
                 return;
             }
             const int S = 31 - __clz(slot);       // stage: m = 2^S groups
             unsigned i = slot - (1u << S);        // permuted group index
             const int P = n - 1 - S;              // butterfly distance 2^P
-            if (perm_low && P <= 2)
+            if (perm_tile_log > 0 && P <= 2)
             {
+                // [tile][k][thread] layout of the stages whose twiddles differ per thread
+                const unsigned nt = 1u << (perm_tile_log - 4); // threads per tile (16 coefficients each)
                 const unsigned rp = 16u >> (P + 1);            // twiddles per thread
-                const unsigned tile = i / (rp * 256u), rem = i % (rp * 256u);
-                const unsigned kk = rem / 256u, t = rem % 256u;
-                i = tile * (rp * 256u) + t * rp + kk;
+                const unsigned tile = i / (rp * nt), rem = i % (rp * nt);
+                const unsigned kk = rem / nt, t = rem % nt;
+                i = tile * (rp * nt) + t * rp + kk;
             }
             const unsigned src = negacyclic ? ((1u << S) + i) : i;
-            const uint64_t w = roots[(static_cast<unsigned long long>(mi) << n) + src];
-            ws[gid] = lazy::Tw64{w, shoup_quotient(w, q)};
+            const T w = roots[(static_cast<unsigned long long>(mi) << n) + src];
+            ws[gid] = lazy::Tw<T>{w, shoup_quotient<T>(w, q)};
         }
     } // namespace kern
 
@@ -96,7 +109,7 @@ namespace gpuntt
             if (forced >= 8 && forced <= 12)
                 return forced;
             (void) n;
-            return kern::TL;
+            return 12;
         }
 
         void* lazy_workspace(hipStream_t stream, size_t bytes)
@@ -121,15 +134,20 @@ namespace gpuntt
             return s.ptr;
         }
 
-        void launch_prep(const uint64_t* roots, lazy::Tw64* ws, const Modulus<uint64_t>* mods, uint64_t q,
-                         int mod_count, int n, bool negacyclic, bool perm_low, const uint64_t* ninv_arr,
-                         lazy::Tw64* ws_ninv, hipStream_t stream)
+        template <typename T>
+        void launch_prep(const T* roots, lazy::Tw<T>* ws, const Modulus<T>* mods, T q, int mod_count, int n,
+                         bool negacyclic, int perm_tile_log, const T* ninv_arr, lazy::Tw<T>* ws_ninv,
+                         unsigned* go_flag, hipStream_t stream)
         {
             const unsigned long long entries = static_cast<unsigned long long>(mod_count) << n;
             const unsigned grid = static_cast<unsigned>((entries + 255) / 256);
-            hipLaunchKernelGGL(kern::prep_twiddles, dim3(grid), dim3(256), 0, stream, roots, ws, mods, q,
-                               mod_count, n, negacyclic ? 1 : 0, perm_low ? 1 : 0, ninv_arr, ws_ninv);
+            hipLaunchKernelGGL((kern::prep_twiddles<T>), dim3(grid), dim3(256), 0, stream, roots, ws, mods, q,
+                               mod_count, n, negacyclic ? 1 : 0, perm_tile_log, ninv_arr, ws_ninv, go_flag);
             GPUNTT_HIP_CHECK(hipGetLastError());
         }
+        template void launch_prep<uint64_t>(const uint64_t*, lazy::Tw64*, const Modulus<uint64_t>*, uint64_t, int,
+                                            int, bool, int, const uint64_t*, lazy::Tw64*, unsigned*, hipStream_t);
+        template void launch_prep<uint32_t>(const uint32_t*, lazy::Tw32*, const Modulus<uint32_t>*, uint32_t, int,
+                                            int, bool, int, const uint32_t*, lazy::Tw32*, unsigned*, hipStream_t);
     } // namespace host
 } // namespace gpuntt

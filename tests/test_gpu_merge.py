@@ -274,16 +274,16 @@ from conftest import load_pkg
 from gpu_utils import MergeCase
 from oracle import oracle as O
 g = load_pkg(); g.load_library()
-for poly in (O.X_N_plus, O.X_N_minus):
+for bits, poly in ((64, O.X_N_plus), (64, O.X_N_minus), (32, O.X_N_plus), (32, O.X_N_minus)):
     for logn in range(1, 21):
-        c = MergeCase(g, 64, logn, poly)
+        c = MergeCase(g, bits, logn, poly)
         batch = 3 if logn <= 17 else 2
         x = c.random(batch, 4242 + logn)
         want = c.P.merge_ntt(x, c.oprm)
         got = c.gpu_forward(x, inplace=bool(logn & 1))
-        assert np.array_equal(got, want), ("fwd", poly, logn)
-        assert np.array_equal(c.gpu_inverse(got, inplace=not (logn & 1)), x), ("inv", poly, logn)
-        assert np.array_equal(c.gpu_inverse(x), c.P.merge_ntt(x, c.oprm, inverse=True)), ("inv raw", poly, logn)
+        assert np.array_equal(got, want), ("fwd", bits, poly, logn)
+        assert np.array_equal(c.gpu_inverse(got, inplace=not (logn & 1)), x), ("inv", bits, poly, logn)
+        assert np.array_equal(c.gpu_inverse(x), c.P.merge_ntt(x, c.oprm, inverse=True)), ("inv raw", bits, poly, logn)
 # user prime with other limb structure (4-step pool prime, 60 bit) and a small 31-bit prime in u64
 for f, logn in (((576460752303415297, 288482366111684746, 238394956950829), 12),):
     c = MergeCase(g, 64, logn, O.X_N_plus, f)
