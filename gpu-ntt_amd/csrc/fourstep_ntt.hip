@@ -12,9 +12,12 @@
 //            the inverse applies cfg.mod_inverse (= N^-1) in its last pass.
 // => 2 sweeps for n2 <= 4096, 3 sweeps up to N = 2^24 (the reference also needs 2-3).
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 
 #include "gpuntt/ntt_4step/ntt_4step.cuh"
 #include "launch_impl.hpp"
+#include "lazy_launch.hpp"
 
 namespace gpuntt
 {
@@ -121,6 +124,66 @@ namespace gpuntt
             host::run_transform<T, INV>(b, 0u, INV ? kern::F_SCALE : 0u, stream);
         }
 
+        // fast path: single modulus with lazy headroom.  Workspace layout (Shoup pairs):
+        //   [0, n1)  n1 table by stage | [n1, n1 + N)  W matrix | [.., + n2)  n2 table by stage
+        template <typename T, bool INV>
+        bool fourstep_run_lazy(T* in, T* out, const T* n1_table, const T* n2_table, const T* w_table,
+                               const Modulus<T>& mod, T ninv, int n_power, int log_n1, int log_n2,
+                               int batch_size, hipStream_t stream)
+        {
+            using TW = lazy::Tw<T>;
+            if (mod.bit > T(lazy::Mod<T>::MAX_BIT) || mod.value < 3 || (INV && ninv >= mod.value))
+                return false;
+            if (const char* e = std::getenv("GPUNTT_PATH"))
+                if (std::strcmp(e, "generic") == 0)
+                    return false;
+            const size_t n1 = size_t(1) << log_n1, n2 = size_t(1) << log_n2, n = size_t(1) << n_power;
+            auto* ws = static_cast<TW*>(host::lazy_workspace(stream, sizeof(TW) * (n1 + n + n2 + 2)));
+            TW* ws_n1 = ws;
+            TW* ws_w = ws + n1;
+            TW* ws_n2 = ws + n1 + n;
+            host::launch_prep<T>(n1_table, ws_n1, nullptr, mod.value, 1, log_n1, false, 0, nullptr, nullptr,
+                                 nullptr, stream);
+            host::launch_prep_pairs<T>(w_table, ws_w, n, mod.value, stream);
+            const int tl2 = host::lazy_tile_log<T>(log_n2);
+            host::launch_prep<T>(n2_table, ws_n2, nullptr, mod.value, 1, log_n2, false,
+                                 (log_n2 >= tl2) ? tl2 : 0, nullptr, nullptr, nullptr, stream);
+
+            kern::LazyArgsT<T> a{};
+            a.in = in;
+            a.out = out;
+            a.tw = ws_n1;
+            a.mods = nullptr;
+            a.q = mod.value;
+            a.q_bit = mod.bit;
+            a.q_mu = mod.mu;
+            a.ninv_arr = nullptr;
+            a.ninv = TW{0, 0};
+            a.go_flag = nullptr;
+            a.w_pairs = ws_w;
+            a.n2_log = log_n2;
+            a.batch = batch_size;
+            a.total = static_cast<unsigned long long>(batch_size) << n_power;
+            a.n = log_n1;
+            a.poly_shift = n_power;
+            a.mod_count = 1;
+            a.p_lo = 0;
+            a.flags = 0u;
+            host::launch_fourstep_phase1_lazy<T, INV>(log_n1, a, stream);
+
+            // phase 2: n2-point transforms of the batch * n1 rows of `out`, in place
+            kern::LazyArgsT<T> b = a;
+            b.in = out;
+            b.tw = ws_n2;
+            b.w_pairs = nullptr;
+            b.n = log_n2;
+            b.poly_shift = log_n2;
+            if (INV)
+                b.ninv = TW{ninv, host::shoup_host(ninv, mod.value)};
+            host::run_transform_lazy<T, INV>(b, 0u, 0u, stream);
+            return true;
+        }
+
         template <typename T>
         void fourstep_dispatch(T* in, T* out, const T* n1_table, const T* n2_table, const T* w_table,
                                const Modulus<T>* mods, Modulus<T> mod, int mod_count,
@@ -138,6 +201,17 @@ namespace gpuntt
                 return;
             if ((static_cast<unsigned long long>(batch_size) << n_power) >> kern::TL > 0x7fffffffull)
                 throw std::invalid_argument("batch_size * N too large for one launch");
+            if (mods == nullptr)
+            {
+                const bool done =
+                    (ntt_type == FORWARD)
+                        ? fourstep_run_lazy<T, false>(in, out, n1_table, n2_table, w_table, mod, ninv, n_power,
+                                                      l1, l2, batch_size, stream)
+                        : fourstep_run_lazy<T, true>(in, out, n1_table, n2_table, w_table, mod, ninv, n_power,
+                                                     l1, l2, batch_size, stream);
+                if (done)
+                    return;
+            }
             if (ntt_type == FORWARD)
                 fourstep_run<T, false>(in, out, n1_table, n2_table, w_table, mods, mod, mod_count,
                                        ninv_arr, ninv, n_power, l1, l2, batch_size, stream);

@@ -38,6 +38,21 @@ namespace gpuntt
                                                    uint32_t, int, int, bool, int, const uint32_t*,
                                                    lazy::Tw32*, unsigned*, hipStream_t);
 
+        template <typename T>
+        void launch_prep_pairs(const T* src, lazy::Tw<T>* dst, unsigned long long count, T q, hipStream_t stream);
+        extern template void launch_prep_pairs<uint64_t>(const uint64_t*, lazy::Tw64*, unsigned long long,
+                                                         uint64_t, hipStream_t);
+        extern template void launch_prep_pairs<uint32_t>(const uint32_t*, lazy::Tw32*, unsigned long long,
+                                                         uint32_t, hipStream_t);
+
+        // 4-step phase 1 (fused n1-point transform + transpose + W multiply), log_n1 in 5..8
+        template <typename T, bool INV>
+        void launch_fourstep_phase1_lazy(int log_n1, const kern::LazyArgsT<T>& a, hipStream_t stream);
+        extern template void launch_fourstep_phase1_lazy<uint64_t, false>(int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
+        extern template void launch_fourstep_phase1_lazy<uint64_t, true>(int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
+        extern template void launch_fourstep_phase1_lazy<uint32_t, false>(int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
+        extern template void launch_fourstep_phase1_lazy<uint32_t, true>(int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
+
         // host Shoup companion floor(w * 2^W / q)
         inline uint64_t shoup_host(uint64_t w, uint64_t q)
         {

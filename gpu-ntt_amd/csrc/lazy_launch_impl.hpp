@@ -152,6 +152,29 @@ namespace gpuntt
         }
 
         template <typename T, bool INV>
+        void launch_fourstep_phase1_lazy(int log_n1, const kern::LazyArgsT<T>& a, hipStream_t stream)
+        {
+            constexpr int TLOG = 12;
+            const unsigned grid = static_cast<unsigned>(a.total >> TLOG);
+            switch (log_n1)
+            {
+#define GPUNTT_CASE(KK)                                                                          \
+    case KK:                                                                                      \
+        hipLaunchKernelGGL((kern::fourstep_phase1_lazy<T, TLOG, INV, KK>), dim3(grid),            \
+                           dim3(kern::LTile<TLOG>::NT), 0, stream, a);                            \
+        break;
+                GPUNTT_CASE(5)
+                GPUNTT_CASE(6)
+                GPUNTT_CASE(7)
+                GPUNTT_CASE(8)
+#undef GPUNTT_CASE
+                default:
+                    throw std::invalid_argument("internal: bad 4-step n1");
+            }
+            GPUNTT_HIP_CHECK(hipGetLastError());
+        }
+
+        template <typename T, bool INV>
         void launch_pass_lazy(const Pass& p, int tile_log, bool in_first, bool last,
                               const kern::LazyArgsT<T>& a, hipStream_t stream)
         {

@@ -36,6 +36,9 @@ namespace gpuntt
             const lazy::Tw<T>* ninv_arr;     // prepared n^-1 pairs per modulus (RNS) or nullptr
             lazy::Tw<T> ninv;                // single modulus n^-1 pair
             const unsigned* go_flag;         // RNS: device word, 1 = every modulus has lazy headroom
+            const lazy::Tw<T>* w_pairs;      // 4-step phase 1: prepared W matrix (N pairs)
+            int n2_log;                      // 4-step phase 1: log2 n2
+            int batch;                       // 4-step phase 1: polynomials (block order is poly-minor)
             unsigned long long total;
             int n;
             int poly_shift;
@@ -52,6 +55,7 @@ namespace gpuntt
             static constexpr int NT = 1 << (TLOG - R);
             static constexpr int TILE = 1 << TLOG;
             static constexpr int LDS_ELEMS = TILE + (TILE >> 4);
+            static constexpr int LDS_ELEMS_FST = TILE + (TILE >> 4) + (TILE >> 5);
         };
         template <int TLOG, bool CONTIG, int K> struct LGeo
         {
@@ -62,6 +66,8 @@ namespace gpuntt
         {
             unsigned long long base;
             int p_lo;
+            // CONTIG tile at an explicit flat base (4-step phase 1 orders its blocks poly-minor)
+            __device__ __forceinline__ explicit LTileMap(unsigned long long flat_base) : base(flat_base), p_lo(0) {}
             __device__ __forceinline__ LTileMap(int n, int pass_p_lo)
             {
                 constexpr int L = LGeo<TLOG, CONTIG, K>::L;
@@ -185,9 +191,16 @@ namespace gpuntt
         //                served by the generic kernels (merge_kernels.hpp) instead
         // EXACT = true : canonical residues with the reference's Barrett contract on the same
         //                data movement (kept for experiments)
-        template <typename T, int TLOG, bool EXACT, bool INV, bool CONTIG, int K, int IN_BOUND, bool LAST>
+        // FST = 4-step phase 1 (reference FourStepForwardCoreT1..4 / FourStepInverseCoreT1..4 plus
+        // the W product, src/lib/ntt_4step/ntt_4step.cu:68-743, 1049-1058, 1177-1872): CONTIG pass
+        // over the rows (length n1 = 2^K) of the n2 x n1 input, stored transposed into the n1 x n2
+        // output with the W multiply fused; output canonical.  Blocks are ordered poly-minor so the
+        // polynomials of a batch that share a slice of W run back to back (W stays in L2).
+        template <typename T, int TLOG, bool EXACT, bool INV, bool CONTIG, int K, int IN_BOUND, bool LAST,
+                  bool FST = false>
         __device__ __forceinline__ void pass_body(const LazyArgsT<T>& a, T* lds, T q_value, T q_bit, T q_mu,
-                                                  int mi)
+                                                  int mi, unsigned long long fst_poly = 0,
+                                                  unsigned fst_tile = 0)
         {
             using G = LGeo<TLOG, CONTIG, K>;
             using M = lazy::Mod<T>;
@@ -197,10 +210,13 @@ namespace gpuntt
             constexpr int NT = LTile<TLOG>::NT;
 
             // single-pass transforms of rings smaller than a tile: the tile holds several polynomials
-            constexpr bool MULTI_POLY = CONTIG && (K < TL) && (IN_BOUND == 1) && LAST;
+            constexpr bool MULTI_POLY = CONTIG && (K < TL) && (IN_BOUND == 1) && (LAST || FST);
 
             const int t = threadIdx.x;
-            const LTileMap<TLOG, CONTIG, K> map(a.n, a.p_lo);
+            const LTileMap<TLOG, CONTIG, K> map =
+                FST ? LTileMap<TLOG, CONTIG, K>((fst_poly << a.poly_shift) +
+                                                (static_cast<unsigned long long>(fst_tile) << TL))
+                    : LTileMap<TLOG, CONTIG, K>(a.n, a.p_lo);
             M m;
             m.set(q_value);
             const dev::ModCtx<T> em{q_value, q_bit, q_mu};
@@ -274,7 +290,8 @@ namespace gpuntt
             };
 
             // whole tile inside the batch (always true for N >= 4096) and no signed conversion
-            const bool full_tile = CONTIG ? (((static_cast<unsigned long long>(blockIdx.x) + 1) << TL) <= a.total) : true;
+            const bool full_tile =
+                (CONTIG && !FST) ? (((static_cast<unsigned long long>(blockIdx.x) + 1) << TL) <= a.total) : true;
             const bool plain_io = full_tile && !(a.flags & F_SIGNED_IN);
 
             T v[EPT];
@@ -426,7 +443,40 @@ namespace gpuntt
                             }
                         });
                     }
-                    if constexpr (DIRECT_IO)
+                    if constexpr (FST)
+                    {
+                        static_assert(!FST || (CONTIG && K >= 4 && K <= 8), "phase-1 rows are 32..256 long");
+                        constexpr int RB = TL - K; // log2 rows per tile
+                        __syncthreads();           // all gathers from the e + (e >> 4) layout are done
+#pragma unroll
+                        for (int j = 0; j < EPT; j++)
+                            lds[lds_pad_t<K>(elem_of<WL>(t, j))] = v[j];
+                        __syncthreads();
+                        const unsigned row0 = fst_tile << RB;
+                        T x[EPT];
+                        TW wv[EPT];
+#pragma unroll
+                        for (int j = 0; j < EPT; j++)
+                        {
+                            const int o = t + NT * j;
+                            const int jl = o & ((1 << RB) - 1);
+                            const int i = o >> RB;
+                            wv[j] = a.w_pairs[(static_cast<unsigned long long>(i) << a.n2_log) + row0 + jl];
+                            x[j] = lds[lds_pad_t<K>((jl << K) | i)];
+                        }
+#pragma unroll
+                        for (int j = 0; j < EPT; j++)
+                        {
+                            const int o = t + NT * j;
+                            const int jl = o & ((1 << RB) - 1);
+                            const int i = o >> RB;
+                            const unsigned long long widx =
+                                (static_cast<unsigned long long>(i) << a.n2_log) + row0 + jl;
+                            a.out[(fst_poly << a.poly_shift) + widx] =
+                                lazy::normalize<M::TB>(m, m.mul(x[j], wv[j]));
+                        }
+                    }
+                    else if constexpr (DIRECT_IO)
                     {
                         if (full_tile)
                         {
@@ -519,6 +569,16 @@ namespace gpuntt
                 qm = md.mu;
             }
             pass_body<T, TLOG, false, INV, CONTIG, K, IN_BOUND, LAST>(a, lds, qv, qb, qm, mi);
+        }
+
+        // 4-step phase 1 kernel; grid = batch * N / TILE blocks, block b -> (tile b / batch, poly b % batch)
+        template <typename T, int TLOG, bool INV, int K>
+        __global__ __launch_bounds__(LTile<TLOG>::NT, LOcc<TLOG>::WAVES) void fourstep_phase1_lazy(LazyArgsT<T> a)
+        {
+            __shared__ T lds[LTile<TLOG>::LDS_ELEMS_FST];
+            const unsigned long long poly = blockIdx.x % static_cast<unsigned>(a.batch);
+            const unsigned tile = blockIdx.x / static_cast<unsigned>(a.batch);
+            pass_body<T, TLOG, false, INV, true, K, 1, false, true>(a, lds, a.q, a.q_bit, a.q_mu, 0, poly, tile);
         }
 
     } // namespace kern

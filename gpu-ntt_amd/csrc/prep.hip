@@ -85,6 +85,18 @@ namespace gpuntt
             const T w = roots[(static_cast<unsigned long long>(mi) << n) + src];
             ws[gid] = lazy::Tw<T>{w, shoup_quotient<T>(w, q)};
         }
+
+        // plain residues -> Shoup pairs, same order (4-step W matrix)
+        template <typename T>
+        __global__ __launch_bounds__(256) void prep_pairs(const T* __restrict__ src, lazy::Tw<T>* __restrict__ dst,
+                                                          unsigned long long count, T q)
+        {
+            const unsigned long long gid = blockIdx.x * 256ull + threadIdx.x;
+            if (gid >= count)
+                return;
+            const T w = src[gid];
+            dst[gid] = lazy::Tw<T>{w, shoup_quotient<T>(w, q)};
+        }
     } // namespace kern
 
     namespace host
@@ -145,6 +157,18 @@ namespace gpuntt
                                mod_count, n, negacyclic ? 1 : 0, perm_tile_log, ninv_arr, ws_ninv, go_flag);
             GPUNTT_HIP_CHECK(hipGetLastError());
         }
+        template <typename T>
+        void launch_prep_pairs(const T* src, lazy::Tw<T>* dst, unsigned long long count, T q, hipStream_t stream)
+        {
+            const unsigned grid = static_cast<unsigned>((count + 255) / 256);
+            hipLaunchKernelGGL((kern::prep_pairs<T>), dim3(grid), dim3(256), 0, stream, src, dst, count, q);
+            GPUNTT_HIP_CHECK(hipGetLastError());
+        }
+        template void launch_prep_pairs<uint64_t>(const uint64_t*, lazy::Tw64*, unsigned long long, uint64_t,
+                                                  hipStream_t);
+        template void launch_prep_pairs<uint32_t>(const uint32_t*, lazy::Tw32*, unsigned long long, uint32_t,
+                                                  hipStream_t);
+
         template void launch_prep<uint64_t>(const uint64_t*, lazy::Tw64*, const Modulus<uint64_t>*, uint64_t, int,
                                             int, bool, int, const uint64_t*, lazy::Tw64*, unsigned*, hipStream_t);
         template void launch_prep<uint32_t>(const uint32_t*, lazy::Tw32*, const Modulus<uint32_t>*, uint32_t, int,
