@@ -68,24 +68,19 @@ def main():
     ap.add_argument("--cpu-polys", type=int, default=4096)
     args = ap.parse_args()
 
+    import importlib
     import torch
     g = _load_pkg()
     g.load_library()  # raises if the HIP extension is missing: there is no fallback
+    dist_mod = importlib.import_module("gpu_ntt_amd.dist")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device(dev))
+    dist, rank, world = dist_mod.init_process_group("nccl", dev)
 
     from oracle import oracle as O
     P = O.Port(BITS)
@@ -112,27 +107,23 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record()
-    for _ in range(args.steps):
-        step()
-    e1.record()
-    torch.cuda.synchronize()
+
+    def timed_steps():
+        # HIP events on the stream the kernels are launched on bracket exactly the K steps
+        e0.record()
+        for _ in range(args.steps):
+            step()
+        e1.record()
+
+    # barrier + synchronize on both sides, MAX over ranks (gpu-ntt_amd/dist.py)
+    wall = dist_mod.timed_region(timed_steps, 1, dist, dev)
+    dev_ms = e0.elapsed_time(e1)
     if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-    dev_ms = e0.elapsed_time(e1)  # HIP events on the stream the kernels ran on
-    if dist is not None:
-        t = torch.tensor([wall, dev_ms], device=dev, dtype=torch.float64)
+        t = torch.tensor([dev_ms], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall, dev_ms = float(t[0]), float(t[1])
+        dev_ms = float(t[0])
 
     if rank == 0:
         ms_per_step = wall * 1e3 / args.steps
@@ -160,8 +151,9 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_call": alg_bytes,
                          "call_ms_hip_events": call_ms,
-                         "note": "one call = all kernel launches of one GPU_NTT (strided pass + "
-                                 "contiguous pass); per-kernel durations in profiles/"},
+                         "note": "one call = every launch of one GPU_NTT (twiddle prep + 4-stage strided "
+                                 "pass + 12-stage contiguous pass = 2 HBM sweeps); the contiguous pass "
+                                 "dominates and is VALU-issue bound; per-kernel averages in profiles/"},
         }
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(prm.modulus.value, x[:args.cpu_polys * n], LOGN)
