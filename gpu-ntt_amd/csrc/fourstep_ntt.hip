@@ -143,11 +143,11 @@ namespace gpuntt
             TW* ws_w = ws + n1;
             TW* ws_n2 = ws + n1 + n;
             host::launch_prep<T>(n1_table, ws_n1, nullptr, mod.value, 1, log_n1, false, 0, nullptr, nullptr,
-                                 nullptr, stream);
+                                 nullptr, nullptr, stream);
             host::launch_prep_pairs<T>(w_table, ws_w, n, mod.value, stream);
             const int tl2 = host::lazy_tile_log<T>(log_n2);
             host::launch_prep<T>(n2_table, ws_n2, nullptr, mod.value, 1, log_n2, false,
-                                 (log_n2 >= tl2) ? tl2 : 0, nullptr, nullptr, nullptr, stream);
+                                 (log_n2 >= tl2) ? tl2 : 0, nullptr, nullptr, nullptr, nullptr, stream);
 
             kern::LazyArgsT<T> a{};
             a.in = in;
@@ -160,6 +160,8 @@ namespace gpuntt
             a.ninv_arr = nullptr;
             a.ninv = TW{0, 0};
             a.go_flag = nullptr;
+            a.norm = lazy::make_norm_const(static_cast<uint64_t>(mod.value), static_cast<uint64_t>(mod.bit));
+            a.norm_arr = nullptr;
             a.w_pairs = ws_w;
             a.n2_log = log_n2;
             a.batch = batch_size;

@@ -47,6 +47,26 @@ namespace gpuntt
 
         template <typename T> struct Mod;
 
+        // constants of the one-multiply final normalisation (64-bit only): for x < 16 q
+        //   k = ((x >> sh) * M) >> (32 + c)  is floor(x / q) or one less, so x - k*q is in [0, 2q)
+        // with sh = max(bit - 27, 0), qt = (q >> sh) + [sh > 0], c = bit - 1 - sh, M = floor(2^(32+c) / qt)
+        struct NormConst
+        {
+            uint32_t sh, c, M, pad;
+        };
+        __host__ __device__ inline NormConst make_norm_const(uint64_t q, uint64_t bit)
+        {
+            NormConst n{0, 0, 0, 0};
+            if (q < 3 || bit < 2 || bit > 60)
+                return n;
+            n.sh = bit > 27 ? static_cast<uint32_t>(bit - 27) : 0u;
+            const uint64_t qt = (q >> n.sh) + (n.sh > 0 ? 1u : 0u); // exact when nothing is shifted out
+            n.c = static_cast<uint32_t>(bit - 1 - n.sh);
+            const uint64_t m = (1ull << (32 + n.c)) / qt;
+            n.M = m > 0xffffffffull ? 0xffffffffu : static_cast<uint32_t>(m);
+            return n;
+        }
+
         // ---- 64-bit: sloppy-quotient Shoup product in [0, 4q); LIMIT 16 needs q < 2^60 ------
         template <> struct Mod<uint64_t>
         {
@@ -55,11 +75,21 @@ namespace gpuntt
             static constexpr int MAX_BIT = 60;
             uint64_t q;
             uint64_t qneg; // 2^64 - q
+            NormConst nc;
 
-            __device__ __forceinline__ void set(uint64_t modulus)
+            __device__ __forceinline__ void set(uint64_t modulus, const NormConst& n)
             {
                 q = modulus;
                 qneg = 0 - modulus;
+                nc = n;
+            }
+            // x < 16 q  ->  [0, 2q): quotient estimate from the top bits, one 32 x 64 multiply-subtract
+            __device__ __forceinline__ uint64_t reduce_2q(uint64_t x) const
+            {
+                const uint32_t xt = static_cast<uint32_t>(x >> nc.sh);
+                const uint32_t k = __umulhi(xt, nc.M) >> nc.c;
+                const uint64_t r = static_cast<uint64_t>(k) * lo32(qneg) + x; // v_mad_u64_u32
+                return r + (static_cast<uint64_t>(k * hi32(qneg)) << 32);
             }
             __device__ __forceinline__ uint64_t kq(int k) const { return q * static_cast<uint64_t>(k); }
 
@@ -72,11 +102,16 @@ namespace gpuntt
                 return x * t.w + qh * qneg;
             }
 
-            // if (x >= k*q) x -= k*q
+            // if (x >= k*q) x -= k*q   -- 4 instructions: v_lshl_add_u64 with the negated constant
+            // (kept opaque so it is not re-canonicalised into a carry-chained subtract, which
+            // costs an extra select and VCC hazard nops), one 64-bit compare, two selects
             template <int K> __device__ __forceinline__ uint64_t csub(uint64_t x) const
             {
                 const uint64_t m = kq(K);
-                return (x >= m) ? (x - m) : x;
+                const uint64_t negm = 0 - m;
+                uint64_t d;
+                asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(d) : "v"(x), "s"(negm));
+                return (x >= m) ? d : x;
             }
         };
 
@@ -88,7 +123,8 @@ namespace gpuntt
             static constexpr int MAX_BIT = 30;
             uint32_t q;
 
-            __device__ __forceinline__ void set(uint32_t modulus) { q = modulus; }
+            __device__ __forceinline__ void set(uint32_t modulus, const NormConst&) { q = modulus; }
+            __device__ __forceinline__ uint32_t reduce_2q(uint32_t x) const { return csub<2>(x); }
             __device__ __forceinline__ uint32_t kq(int k) const { return q * static_cast<uint32_t>(k); }
 
             __device__ __forceinline__ uint32_t mul(uint32_t x, const Tw32& t) const
@@ -108,6 +144,8 @@ namespace gpuntt
         // [0, B*q) -> [0, q)
         template <int B, typename T> __device__ __forceinline__ T normalize(const Mod<T>& m, T x)
         {
+            if constexpr (sizeof(T) == 8 && B > 4)
+                return m.template csub<1>(m.reduce_2q(x)); // 10 instructions instead of 4 x 4
             if constexpr (B > 8)
                 x = m.template csub<8>(x);
             if constexpr (B > 4)

@@ -35,6 +35,8 @@ namespace gpuntt
             T q_mu;
             const lazy::Tw<T>* ninv_arr;     // prepared n^-1 pairs per modulus (RNS) or nullptr
             lazy::Tw<T> ninv;                // single modulus n^-1 pair
+            lazy::NormConst norm;            // single modulus: final-normalisation constants
+            const lazy::NormConst* norm_arr; // RNS: per modulus (written by the prep kernel) or nullptr
             const unsigned* go_flag;         // RNS: device word, 1 = every modulus has lazy headroom
             const lazy::Tw<T>* w_pairs;      // 4-step phase 1: prepared W matrix (N pairs)
             int n2_log;                      // 4-step phase 1: log2 n2
@@ -121,15 +123,28 @@ namespace gpuntt
                 int bin[NR];
                 int final_bound;
             };
-            static constexpr int stages_of(int r) { return (r == NR - 1) ? (K - R * (NR - 1)) : R; }
+            // Round shapes.  The short round (K mod 4 stages) is the one FARTHEST from bit 0: first
+            // for the forward transform (stages run top-down), last for the inverse (bottom-up), so
+            // the remaining rounds are aligned to bit groups [..][7..4][3..0] of the tile: the
+            // 16-contiguous-coefficient round always owns distances 1,2,4,8 and windows of STRIDED
+            // passes never dip below the contiguous-run bits (lanes of a wave then differ only in
+            // those bits and every twiddle of the pass is wave-uniform).
+            static constexpr int SHORT = K - R * (NR - 1);
+            static constexpr int stages_of(int r)
+            {
+                return INV ? ((r == NR - 1) ? SHORT : R) : ((r == 0) ? SHORT : R);
+            }
             static constexpr int first_pos(int r)
             {
-                return INV ? (G::L + r * R) : (G::L + K - 1 - r * R);
+                if (INV)
+                    return G::L + r * R;
+                return (r == 0) ? (G::L + K - 1) : (G::L + K - 1 - SHORT - (r - 1) * R);
             }
             static constexpr int wl_of(int r)
             {
                 int w = INV ? first_pos(r) : (first_pos(r) - R + 1);
-                return w < 0 ? 0 : (w > TL - R ? TL - R : w);
+                const int lo = CONTIG ? 0 : (G::L > TL - R ? TL - R : G::L);
+                return w < lo ? lo : (w > TL - R ? TL - R : w);
             }
             static constexpr Data make()
             {
@@ -218,7 +233,7 @@ namespace gpuntt
                                                 (static_cast<unsigned long long>(fst_tile) << TL))
                     : LTileMap<TLOG, CONTIG, K>(a.n, a.p_lo);
             M m;
-            m.set(q_value);
+            m.set(q_value, (a.norm_arr != nullptr) ? a.norm_arr[mi] : a.norm);
             const dev::ModCtx<T> em{q_value, q_bit, q_mu};
             const unsigned long long root_base = static_cast<unsigned long long>(mi) << a.n;
             TW ninv = a.ninv;
@@ -235,7 +250,11 @@ namespace gpuntt
                 constexpr int STAGES = SCH::stages_of(r);
                 constexpr int FIRST_POS = SCH::first_pos(r);
                 constexpr int WL = SCH::wl_of(r);
-                constexpr bool UNIFORM = (WL + R == TL); // no thread bits above the register window
+                // block-uniform: no thread bits above the register window; wave-uniform: the 64 lanes
+                // of a wave differ only in tile bits below the window (WL >= 6) -> scalar loads with
+                // the wave's first thread id
+                constexpr bool UNIFORM = (WL + R == TL) || (WL >= 6);
+                const int t_uni = (WL + R == TL) ? 0 : __builtin_amdgcn_readfirstlane(t);
                 int off = 0;
                 static_for<STAGES>([&](auto s_) {
                     constexpr int s = decltype(s_)::value;
@@ -256,7 +275,7 @@ namespace gpuntt
                     {
                         // UNIFORM: blockIdx and compile-time bits only -> scalar loads
                         const unsigned idx0 =
-                            static_cast<unsigned>(map.flat(elem_of<WL>(UNIFORM ? 0 : t, 0))) & nmask;
+                            static_cast<unsigned>(map.flat(elem_of<WL>(UNIFORM ? t_uni : t, 0))) & nmask;
                         ps = tw_mod + stage_base + (idx0 >> (P + 1));
                     }
                     static_for<CNT>([&](auto k_) {
@@ -277,7 +296,7 @@ namespace gpuntt
                             // a tile may hold several polynomials: the register bits above the ring
                             // size select the polynomial, not the twiddle -> index every entry
                             const unsigned idx =
-                                static_cast<unsigned>(map.flat(elem_of<WL>(UNIFORM ? 0 : t, kk << (jb + 1)))) & nmask;
+                                static_cast<unsigned>(map.flat(elem_of<WL>(UNIFORM ? t_uni : t, kk << (jb + 1)))) & nmask;
                             tws[off + kk] = tw_mod[stage_base + (idx >> (P + 1))];
                         }
                         else

@@ -114,11 +114,15 @@ namespace gpuntt
             const int tl = host::lazy_tile_log<TU>(n_power);
             const int perm_tile_log = (n_power >= tl) ? tl : 0;
             const size_t entries = (static_cast<size_t>(mod_count) << n_power) + mod_count;
-            auto* ws = static_cast<TW*>(host::lazy_workspace(stream, sizeof(TW) * (entries + 2)));
+            // workspace: twiddle pairs | n^-1 pairs | go-flag | per-modulus normalisation constants
+            const size_t tail = 16 + sizeof(lazy::NormConst) * static_cast<size_t>(mod_count);
+            auto* ws = static_cast<TW*>(host::lazy_workspace(stream, sizeof(TW) * entries + tail));
             TW* ws_ninv = ws + (static_cast<size_t>(mod_count) << n_power);
-            unsigned* go_flag = mods ? reinterpret_cast<unsigned*>(ws + entries) : nullptr;
+            unsigned char* tail_p = reinterpret_cast<unsigned char*>(ws + entries);
+            unsigned* go_flag = mods ? reinterpret_cast<unsigned*>(tail_p) : nullptr;
+            auto* norm_arr = mods ? reinterpret_cast<lazy::NormConst*>(tail_p + 16) : nullptr;
             host::launch_prep<TU>(roots, ws, mods, m.value, mod_count, n_power, neg, perm_tile_log, ninv_dev,
-                                  ninv_dev ? ws_ninv : nullptr, go_flag, stream);
+                                  ninv_dev ? ws_ninv : nullptr, go_flag, norm_arr, stream);
             kern::LazyArgsT<TU> a{};
             a.in = in;
             a.out = out;
@@ -130,6 +134,8 @@ namespace gpuntt
             a.ninv_arr = ninv_dev ? ws_ninv : nullptr;
             a.ninv = TW{0, 0};
             a.go_flag = go_flag;
+            a.norm = lazy::make_norm_const(static_cast<uint64_t>(m.value), static_cast<uint64_t>(m.bit));
+            a.norm_arr = norm_arr;
             a.total = static_cast<unsigned long long>(batch_size) << n_power;
             a.n = n_power;
             a.poly_shift = n_power;

@@ -41,7 +41,8 @@ namespace gpuntt
                                                              int perm_tile_log,
                                                              const T* __restrict__ ninv_arr,
                                                              lazy::Tw<T>* __restrict__ ws_ninv,
-                                                             unsigned* __restrict__ go_flag)
+                                                             unsigned* __restrict__ go_flag,
+                                                             lazy::NormConst* __restrict__ norm_arr)
         {
             const unsigned long long gid = blockIdx.x * 256ull + threadIdx.x;
             if (gid == 0 && go_flag != nullptr)
@@ -52,6 +53,9 @@ namespace gpuntt
                     if (mods[i].bit > static_cast<T>(lazy::Mod<T>::MAX_BIT) || mods[i].value < 3)
                         ok = 0u;
                 *go_flag = ok;
+                if (norm_arr != nullptr)
+                    for (int i = 0; i < mod_count; i++)
+                        norm_arr[i] = lazy::make_norm_const(mods[i].value, mods[i].bit);
             }
             const unsigned long long per_mod = 1ull << n;
             if (gid >= per_mod * mod_count)
@@ -149,12 +153,12 @@ namespace gpuntt
         template <typename T>
         void launch_prep(const T* roots, lazy::Tw<T>* ws, const Modulus<T>* mods, T q, int mod_count, int n,
                          bool negacyclic, int perm_tile_log, const T* ninv_arr, lazy::Tw<T>* ws_ninv,
-                         unsigned* go_flag, hipStream_t stream)
+                         unsigned* go_flag, lazy::NormConst* norm_arr, hipStream_t stream)
         {
             const unsigned long long entries = static_cast<unsigned long long>(mod_count) << n;
             const unsigned grid = static_cast<unsigned>((entries + 255) / 256);
             hipLaunchKernelGGL((kern::prep_twiddles<T>), dim3(grid), dim3(256), 0, stream, roots, ws, mods, q,
-                               mod_count, n, negacyclic ? 1 : 0, perm_tile_log, ninv_arr, ws_ninv, go_flag);
+                               mod_count, n, negacyclic ? 1 : 0, perm_tile_log, ninv_arr, ws_ninv, go_flag, norm_arr);
             GPUNTT_HIP_CHECK(hipGetLastError());
         }
         template <typename T>
@@ -170,8 +174,8 @@ namespace gpuntt
                                                   hipStream_t);
 
         template void launch_prep<uint64_t>(const uint64_t*, lazy::Tw64*, const Modulus<uint64_t>*, uint64_t, int,
-                                            int, bool, int, const uint64_t*, lazy::Tw64*, unsigned*, hipStream_t);
+                                            int, bool, int, const uint64_t*, lazy::Tw64*, unsigned*, lazy::NormConst*, hipStream_t);
         template void launch_prep<uint32_t>(const uint32_t*, lazy::Tw32*, const Modulus<uint32_t>*, uint32_t, int,
-                                            int, bool, int, const uint32_t*, lazy::Tw32*, unsigned*, hipStream_t);
+                                            int, bool, int, const uint32_t*, lazy::Tw32*, unsigned*, lazy::NormConst*, hipStream_t);
     } // namespace host
 } // namespace gpuntt

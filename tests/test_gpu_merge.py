@@ -335,3 +335,17 @@ def test_moduli_without_lazy_headroom(g):
                                                reduction_poly=O.X_N_plus, mod_inverse=ninv), batch, 3)
     torch.cuda.synchronize()
     assert np.array_equal(g.to_host(d), x)
+
+
+def test_small_and_odd_sized_moduli_u64(g):
+    """64-bit words holding small primes (14..50 bit): exercises the shift-free branch of the
+    one-multiply final normalisation and the lazy bounds far from the 60-bit case."""
+    from gpu_utils import find_ntt_factors
+    for bits, logn in ((14, 10), (20, 13), (27, 13), (28, 14), (31, 12), (40, 13), (50, 16), (59, 13)):
+        f = find_ntt_factors(bits, logn)
+        for poly in (O.X_N_plus, O.X_N_minus):
+            c = MergeCase(g, 64, logn, poly, f)
+            x = c.random(8, bits * 3 + logn)
+            want = c.P.merge_ntt(x, c.oprm)
+            assert np.array_equal(c.gpu_forward(x), want), (bits, logn, poly)
+            assert np.array_equal(c.gpu_inverse(want), x), (bits, logn, poly)
