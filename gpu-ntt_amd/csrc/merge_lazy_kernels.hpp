@@ -293,11 +293,11 @@ namespace gpuntt
                         }
                         else if constexpr (MULTI_POLY)
                         {
-                            // a tile may hold several polynomials: the register bits above the ring
-                            // size select the polynomial, not the twiddle -> index every entry
-                            const unsigned idx =
-                                static_cast<unsigned>(map.flat(elem_of<WL>(UNIFORM ? t_uni : t, kk << (jb + 1)))) & nmask;
-                            tws[off + kk] = tw_mod[stage_base + (idx >> (P + 1))];
+                            // a tile holds several rings of length 2^K (n == K here): window bits
+                            // at or above the ring size select the ring, not the twiddle, so the
+                            // offset of entry kk is a compile-time constant
+                            constexpr int KOFF = ((kk << (jb + 1 + WL)) & ((1 << K) - 1)) >> (p + 1);
+                            tws[off + kk] = ps[KOFF];
                         }
                         else
                         {
@@ -472,27 +472,32 @@ namespace gpuntt
                             lds[lds_pad_t<K>(elem_of<WL>(t, j))] = v[j];
                         __syncthreads();
                         const unsigned row0 = fst_tile << RB;
-                        T x[EPT];
-                        TW wv[EPT];
+                        // two halves of 8 keep {coefficient, W pair} in 48 VGPRs instead of 96
 #pragma unroll
-                        for (int j = 0; j < EPT; j++)
+                        for (int half = 0; half < 2; half++)
                         {
-                            const int o = t + NT * j;
-                            const int jl = o & ((1 << RB) - 1);
-                            const int i = o >> RB;
-                            wv[j] = a.w_pairs[(static_cast<unsigned long long>(i) << a.n2_log) + row0 + jl];
-                            x[j] = lds[lds_pad_t<K>((jl << K) | i)];
-                        }
+                            T x[EPT / 2];
+                            TW wv[EPT / 2];
 #pragma unroll
-                        for (int j = 0; j < EPT; j++)
-                        {
-                            const int o = t + NT * j;
-                            const int jl = o & ((1 << RB) - 1);
-                            const int i = o >> RB;
-                            const unsigned long long widx =
-                                (static_cast<unsigned long long>(i) << a.n2_log) + row0 + jl;
-                            a.out[(fst_poly << a.poly_shift) + widx] =
-                                lazy::normalize<M::TB>(m, m.mul(x[j], wv[j]));
+                            for (int jj = 0; jj < EPT / 2; jj++)
+                            {
+                                const int o = t + NT * (half * (EPT / 2) + jj);
+                                const int jl = o & ((1 << RB) - 1);
+                                const int i = o >> RB;
+                                wv[jj] = a.w_pairs[(static_cast<unsigned long long>(i) << a.n2_log) + row0 + jl];
+                                x[jj] = lds[lds_pad_t<K>((jl << K) | i)];
+                            }
+#pragma unroll
+                            for (int jj = 0; jj < EPT / 2; jj++)
+                            {
+                                const int o = t + NT * (half * (EPT / 2) + jj);
+                                const int jl = o & ((1 << RB) - 1);
+                                const int i = o >> RB;
+                                const unsigned long long widx =
+                                    (static_cast<unsigned long long>(i) << a.n2_log) + row0 + jl;
+                                a.out[(fst_poly << a.poly_shift) + widx] =
+                                    lazy::normalize<M::TB>(m, m.mul(x[jj], wv[jj]));
+                            }
                         }
                     }
                     else if constexpr (DIRECT_IO)
