@@ -126,6 +126,17 @@ def main():
         dev_ms = float(t[0])
 
     if rank == 0:
+        # HBM bytes per call from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+        # passes of this same command, summarised by tools/pmc_summary.py with the gfx950 x2 fetch
+        # correction); a profile cannot be taken from inside the timed run, so the committed
+        # summary of the current round is quoted
+        traffic = None
+        try:
+            pm = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles")) if p.endswith("_pmc_traffic.json"))
+            if pm:
+                traffic = json.load(open(os.path.join(ROOT, "profiles", pm[-1])))["bytes_per_call"]
+        except Exception:
+            traffic = None
         ms_per_step = wall * 1e3 / args.steps
         call_ms = dev_ms / args.steps
         alg_bytes = 2 * n * (BITS // 8) * BATCH  # every coefficient read once + written once
@@ -148,7 +159,7 @@ def main():
                        "modulus": prm.modulus.value, "out_of_place": True,
                        "parallelism": "batch-shard x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_call": alg_bytes,
                          "call_ms_hip_events": call_ms,
                          "note": "one call = every launch of one GPU_NTT (twiddle prep + 4-stage strided "
