@@ -106,6 +106,17 @@ namespace gpuntt
                 else
                     return p_lo + (p - L);
             }
+            // flat(e) = base + part(e), and part() is additive over disjoint tile bits: the part of
+            // the register bits is block-uniform (goes into the scalar base address), the part of
+            // the thread bits is one 32-bit lane offset shared by all 16 accesses of a thread
+            __device__ __forceinline__ unsigned part(unsigned e) const
+            {
+                constexpr int L = LGeo<TLOG, CONTIG, K>::L;
+                if constexpr (CONTIG)
+                    return e;
+                else
+                    return ((e >> L) << p_lo) | (e & ((1u << L) - 1u));
+            }
         };
 
         // ---- compile-time schedule of range corrections for one pass --------------------
@@ -194,6 +205,14 @@ namespace gpuntt
             }
             static constexpr Data d = make();
             static_assert(d.final_bound <= LIMIT, "lazy bound exceeds the headroom");
+        };
+
+        // waves per SIMD requested from the register allocator: four 256-thread tiles per CU
+        // (128 VGPRs) or two 1024-thread tiles per CU (64 VGPRs; the 32-bit kernels fit once the
+        // twiddles of a round are loaded at the start of that round instead of a round ahead)
+        template <int TLOG> struct LOcc
+        {
+            static constexpr int WAVES = (TLOG >= 14) ? 8 : 4;
         };
 
         // twiddles of one register round, in stage order: stage s (register bit jb) contributes
@@ -313,9 +332,15 @@ namespace gpuntt
                 (CONTIG && !FST) ? (((static_cast<unsigned long long>(blockIdx.x) + 1) << TL) <= a.total) : true;
             const bool plain_io = full_tile && !(a.flags & F_SIGNED_IN);
 
+            // 64-bit: request a round's twiddles one round ahead (in front of the exchange barrier);
+            // 32-bit big tiles: at the start of the round (halves the live twiddle registers; the
+            // 8 waves per SIMD cover the latency)
+            constexpr bool TW_AHEAD = (LOcc<TLOG>::WAVES <= 4);
+
             T v[EPT];
             TW tw_next[TW_PER_ROUND];
-            load_twiddles(std::integral_constant<int, 0>{}, tw_next);
+            if constexpr (TW_AHEAD)
+                load_twiddles(std::integral_constant<int, 0>{}, tw_next);
 
             static_for<G::NR>([&](auto r_) {
                 constexpr int r = decltype(r_)::value;
@@ -345,9 +370,10 @@ namespace gpuntt
                     {
                         if (plain_io)
                         {
+                            const unsigned lane = map.part(elem_of<WL>(t, 0));
 #pragma unroll
                             for (int j = 0; j < EPT; j++)
-                                v[j] = src[map.flat(elem_of<WL>(t, j))];
+                                v[j] = (src + (map.base + map.part(static_cast<unsigned>(j) << WL)))[lane];
                         }
                         else
                         {
@@ -363,7 +389,7 @@ namespace gpuntt
                             T tmp[EPT];
 #pragma unroll
                             for (int j = 0; j < EPT; j++)
-                                tmp[j] = src[map.flat(t + NT * j)];
+                                tmp[j] = (src + (map.base + static_cast<unsigned>(NT * j)))[t];
 #pragma unroll
                             for (int j = 0; j < EPT; j++)
                                 lds[lds_pad(t + NT * j)] = tmp[j];
@@ -388,9 +414,16 @@ namespace gpuntt
                 }
 
                 TW tw_cur[TW_PER_ROUND];
+                if constexpr (TW_AHEAD)
+                {
 #pragma unroll
-                for (int i = 0; i < TW_PER_ROUND; i++)
-                    tw_cur[i] = tw_next[i];
+                    for (int i = 0; i < TW_PER_ROUND; i++)
+                        tw_cur[i] = tw_next[i];
+                }
+                else
+                {
+                    load_twiddles(r_, tw_cur);
+                }
 
                 // ---- butterflies ------------------------------------------------------
                 int off = 0;
@@ -481,21 +514,25 @@ namespace gpuntt
 #pragma unroll
                             for (int jj = 0; jj < EPT / 2; jj++)
                             {
-                                const int o = t + NT * (half * (EPT / 2) + jj);
+                                // o = t + NT * j: column i = o >> RB splits into a uniform and a lane part
+                                const int jr = half * (EPT / 2) + jj;
+                                const int o = t + NT * jr;
                                 const int jl = o & ((1 << RB) - 1);
                                 const int i = o >> RB;
-                                wv[jj] = a.w_pairs[(static_cast<unsigned long long>(i) << a.n2_log) + row0 + jl];
+                                const unsigned lane = (static_cast<unsigned>(t >> RB) << a.n2_log) + (t & ((1 << RB) - 1));
+                                const unsigned long long ubase =
+                                    (static_cast<unsigned long long>((NT >> RB) * jr) << a.n2_log) + row0;
+                                wv[jj] = (a.w_pairs + ubase)[lane];
                                 x[jj] = lds[lds_pad_t<K>((jl << K) | i)];
                             }
 #pragma unroll
                             for (int jj = 0; jj < EPT / 2; jj++)
                             {
-                                const int o = t + NT * (half * (EPT / 2) + jj);
-                                const int jl = o & ((1 << RB) - 1);
-                                const int i = o >> RB;
-                                const unsigned long long widx =
-                                    (static_cast<unsigned long long>(i) << a.n2_log) + row0 + jl;
-                                a.out[(fst_poly << a.poly_shift) + widx] =
+                                const int jr = half * (EPT / 2) + jj;
+                                const unsigned lane = (static_cast<unsigned>(t >> RB) << a.n2_log) + (t & ((1 << RB) - 1));
+                                const unsigned long long ubase =
+                                    (static_cast<unsigned long long>((NT >> RB) * jr) << a.n2_log) + row0;
+                                (a.out + ((fst_poly << a.poly_shift) + ubase))[lane] =
                                     lazy::normalize<M::TB>(m, m.mul(x[jj], wv[jj]));
                             }
                         }
@@ -504,9 +541,10 @@ namespace gpuntt
                     {
                         if (full_tile)
                         {
+                            const unsigned lane = map.part(elem_of<WL>(t, 0));
 #pragma unroll
                             for (int j = 0; j < EPT; j++)
-                                a.out[map.flat(elem_of<WL>(t, j))] = v[j];
+                                (a.out + (map.base + map.part(static_cast<unsigned>(j) << WL)))[lane] = v[j];
                         }
                         else
                         {
@@ -529,7 +567,7 @@ namespace gpuntt
                         {
 #pragma unroll
                             for (int j = 0; j < EPT; j++)
-                                a.out[map.flat(t + NT * j)] = lds[lds_pad(t + NT * j)];
+                                (a.out + (map.base + static_cast<unsigned>(NT * j)))[t] = lds[lds_pad(t + NT * j)];
                         }
                         else
                         {
@@ -546,7 +584,8 @@ namespace gpuntt
                 else
                 {
                     // next round's twiddles are requested before the exchange barrier
-                    load_twiddles(std::integral_constant<int, r + 1>{}, tw_next);
+                    if constexpr (TW_AHEAD)
+                        load_twiddles(std::integral_constant<int, r + 1>{}, tw_next);
 #pragma unroll
                     for (int j = 0; j < EPT; j++)
                         lds[lds_pad(elem_of<WL>(t, j))] = v[j];
@@ -554,14 +593,6 @@ namespace gpuntt
                 }
             });
         }
-
-        // waves per SIMD requested from the register allocator (128 VGPRs): four 256-thread
-        // tiles or one 1024-thread tile per CU.  (Two 1024-thread tiles per CU would need <= 64
-        // VGPRs; the 32-bit kernels want ~70 and spill heavily under that cap.)
-        template <int TLOG> struct LOcc
-        {
-            static constexpr int WAVES = 4;
-        };
 
         template <typename T, int TLOG, bool INV, bool CONTIG, int K, int IN_BOUND, bool LAST>
         __global__ __launch_bounds__(LTile<TLOG>::NT, LOcc<TLOG>::WAVES) void merge_pass_lazy(LazyArgsT<T> a)
