@@ -6,5 +6,6 @@ namespace gpuntt
     namespace host
     {
         template void launch_pass<Data32, false>(const Pass&, const kern::PassArgs<Data32>&, hipStream_t);
+        template void launch_column_small<Data32, false>(const kern::PassArgs<Data32>&, int, int, hipStream_t);
     }
 } // namespace gpuntt

@@ -6,5 +6,6 @@ namespace gpuntt
     namespace host
     {
         template void launch_pass<Data64, false>(const Pass&, const kern::PassArgs<Data64>&, hipStream_t);
+        template void launch_column_small<Data64, false>(const kern::PassArgs<Data64>&, int, int, hipStream_t);
     }
 } // namespace gpuntt

@@ -68,6 +68,14 @@ namespace gpuntt
         extern template void launch_pass<Data64, false>(const Pass&, const kern::PassArgs<Data64>&, hipStream_t);
         extern template void launch_pass<Data64, true>(const Pass&, const kern::PassArgs<Data64>&, hipStream_t);
 
+        // small-matrix column transform (merge_kernels.hpp::column_ntt_small), defined in inst_*.hip
+        template <typename T, bool INV>
+        void launch_column_small(const kern::PassArgs<T>& a, int n, int log_w, hipStream_t stream);
+        extern template void launch_column_small<Data32, false>(const kern::PassArgs<Data32>&, int, int, hipStream_t);
+        extern template void launch_column_small<Data32, true>(const kern::PassArgs<Data32>&, int, int, hipStream_t);
+        extern template void launch_column_small<Data64, false>(const kern::PassArgs<Data64>&, int, int, hipStream_t);
+        extern template void launch_column_small<Data64, true>(const kern::PassArgs<Data64>&, int, int, hipStream_t);
+
         // Runs the whole pass list.  `base` carries pointers, moduli, n, poly_shift,
         // root_shift, total and the direction-independent flags; this routine fills the
         // per-pass fields.  first_in_flags apply to the first pass only (signed input),

@@ -73,5 +73,20 @@ namespace gpuntt
             }
         }
 
+
+        template <typename T, bool INV>
+        void launch_column_small(const kern::PassArgs<T>& a, int n, int log_w, hipStream_t stream)
+        {
+            // one block owns all N rows of a group of columns; 2^cols_log columns keep >= 256 butterflies
+            int cols_log = 9 - n;
+            if (cols_log < 0)
+                cols_log = 0;
+            if (cols_log > log_w)
+                cols_log = log_w;
+            const unsigned grid = 1u << (log_w - cols_log);
+            hipLaunchKernelGGL((kern::column_ntt_small<T, INV>), dim3(grid), dim3(256), 0, stream, a, n, log_w,
+                               cols_log);
+            GPUNTT_HIP_CHECK(hipGetLastError());
+        }
     } // namespace host
 } // namespace gpuntt

@@ -385,5 +385,72 @@ namespace gpuntt
             });
         }
 
+        // Column-wise (PerCoefficient) transform for matrices too small for a 4096-coefficient
+        // strided tile: one thread per butterfly, stages separated by block barriers, one block per
+        // group of `cols_per_block` columns (all N rows).  Correctness path, not a fast path.
+        template <typename T, bool INV>
+        __global__ __launch_bounds__(256) void column_ntt_small(PassArgs<T> a, int n, int log_w, int cols_log)
+        {
+            using S = typename std::make_signed<T>::type;
+            const dev::ModCtx<T> m = (a.mods != nullptr)
+                                         ? dev::ModCtx<T>{a.mods[0].value, a.mods[0].bit, a.mods[0].mu}
+                                         : dev::ModCtx<T>{a.mod.value, a.mod.bit, a.mod.mu};
+            const T ninv = (a.ninv_arr != nullptr) ? a.ninv_arr[0] : a.ninv;
+            const unsigned w = 1u << log_w, nrow = 1u << n, cols = 1u << cols_log;
+            const unsigned col0 = blockIdx.x << cols_log;
+            const unsigned half = (nrow >> 1) << cols_log; // butterflies per stage in this block
+            // copy in -> out (with signed conversion) so the stages can run in place on `out`
+            for (unsigned e = threadIdx.x; e < (nrow << cols_log); e += 256)
+            {
+                const unsigned r = e >> cols_log, c = col0 + (e & (cols - 1));
+                const unsigned long long f = static_cast<unsigned long long>(r) * w + c;
+                T x;
+                if (a.flags & F_SIGNED_IN)
+                {
+                    const S sv = static_cast<const S*>(a.in)[f];
+                    x = (sv < 0) ? static_cast<T>(m.q + static_cast<T>(sv)) : static_cast<T>(sv);
+                }
+                else
+                    x = static_cast<const T*>(a.in)[f];
+                a.out[f] = x;
+            }
+            __syncthreads();
+            for (int st = 0; st < n; st++)
+            {
+                const int P = INV ? st : (n - 1 - st); // butterfly distance 2^P rows
+                for (unsigned b = threadIdx.x; b < half; b += 256)
+                {
+                    const unsigned c = col0 + (b & (cols - 1));
+                    const unsigned k = b >> cols_log;                     // butterfly index in the column
+                    const unsigned lo = k & ((1u << P) - 1), grp = k >> P;
+                    const unsigned r0 = (grp << (P + 1)) | lo;
+                    unsigned ti = grp;
+                    if (a.flags & F_NEGACYCLIC)
+                        ti += 1u << (n - 1 - P);
+                    const T tw = a.roots[ti];
+                    const unsigned long long f0 = static_cast<unsigned long long>(r0) * w + c;
+                    const unsigned long long f1 = f0 + (static_cast<unsigned long long>(1u << P) * w);
+                    T U = a.out[f0], V = a.out[f1];
+                    if (INV)
+                        dev::gs_butterfly(U, V, tw, m);
+                    else
+                        dev::ct_butterfly(U, V, tw, m);
+                    a.out[f0] = U;
+                    a.out[f1] = V;
+                }
+                __syncthreads();
+            }
+            if (a.flags & F_SCALE)
+                for (unsigned e = threadIdx.x; e < (nrow << cols_log); e += 256)
+                {
+                    const unsigned r = e >> cols_log, c = col0 + (e & (cols - 1));
+                    const unsigned long long f = static_cast<unsigned long long>(r) * w + c;
+                    T x = m.mul(a.out[f], ninv);
+                    if (a.flags & F_CENTERED)
+                        x = (x > (m.q >> 1)) ? static_cast<T>(x - m.q) : x;
+                    a.out[f] = x;
+                }
+        }
+
     } // namespace kern
 } // namespace gpuntt

@@ -51,9 +51,7 @@ namespace gpuntt
                 case PerCoefficient:
                     if (n_power <= 0 || n_power >= 10)
                         throw std::invalid_argument("Invalid n_power range!");
-                    // column-wise layout (reference ntt.cu:1554-2074) is scheduled after the
-                    // PerPolynomial path
-                    throw std::invalid_argument("PerCoefficient ntt_layout is not implemented yet!");
+                    break;
                 default:
                     throw std::invalid_argument("Invalid ntt_layout!");
             }
@@ -145,6 +143,66 @@ namespace gpuntt
             return a;
         }
 
+        // ---- PerCoefficient (column-wise) layout ------------------------------------------
+        // The matrix is N rows (coefficient index) x batch columns (polynomials), row-major; every
+        // column is transformed (reference ForwardCoreTranspose / InverseCoreTranspose,
+        // ntt.cu:1554-2074, hosts :2228-2250; checked like test_merge_ntt.cu:343-474).  With a
+        // power-of-two batch the element (c, x) sits at flat index (c << log2 batch) | x, i.e. the
+        // columns are exactly a STRIDED tile pass over one virtual ring of N * batch coefficients
+        // whose stage bits start at bit log2(batch) -- no transpose, rows stay coalesced.
+        template <typename TU, bool INV>
+        void run_percoefficient(kern::PassArgs<TU> a, int n_power, int batch_size, unsigned in_flags,
+                                unsigned out_flags, hipStream_t stream)
+        {
+            if (batch_size <= 0)
+                return;
+            if ((batch_size & (batch_size - 1)) != 0)
+                throw std::invalid_argument("PerCoefficient batch_size must be a power of two!");
+            if (a.mod_count > 1)
+                throw std::invalid_argument("PerCoefficient with mod_count > 1 is not supported!");
+            int log_w = 0;
+            while ((1 << log_w) < batch_size)
+                log_w++;
+            const int nv = n_power + log_w; // virtual ring
+            a.n = nv;
+            a.poly_shift = nv;
+            a.root_shift = -1;
+            a.total = 1ull << nv;
+            // stages split into strided passes of <= 8, highest first (forward order)
+            host::Plan pl{};
+            const int np = (n_power + 7) / 8;
+            int top = n_power;
+            bool fits = (nv >= kern::TL);
+            for (int i = 0; i < np; i++)
+            {
+                const int k = n_power / np + ((i < n_power % np) ? 1 : 0);
+                top -= k;
+                pl.pass[pl.count++] = host::Pass{false, k, log_w + top};
+                if (kern::TL - k > log_w + top)
+                    fits = false; // a tile row would be wider than the matrix row
+            }
+            if (!fits)
+            {
+                a.flags |= in_flags | out_flags;
+                host::launch_column_small<TU, INV>(a, n_power, log_w, stream);
+                return;
+            }
+            const void* src = a.in;
+            for (int i = 0; i < pl.count; i++)
+            {
+                kern::PassArgs<TU> b = a;
+                const host::Pass& p = INV ? pl.pass[pl.count - 1 - i] : pl.pass[i];
+                b.in = src;
+                b.p_lo = p.p_lo;
+                if (i == 0)
+                    b.flags |= in_flags;
+                if (i == pl.count - 1)
+                    b.flags |= out_flags;
+                host::launch_pass<TU, INV>(p, b, stream);
+                src = a.out;
+            }
+        }
+
         template <typename TU> inline void set_multi(kern::PassArgs<TU>& a)
         {
             if (a.mods != nullptr && a.mod_count > 1 && a.poly_shift < kern::TL)
@@ -163,6 +221,14 @@ namespace gpuntt
         using TU = typename std::make_unsigned<T>::type;
         check_layout_and_range(cfg.ntt_layout, cfg.n_power);
         const unsigned in_flags = std::is_signed<T>::value ? kern::F_SIGNED_IN : 0u;
+        if (cfg.ntt_layout == PerCoefficient)
+        {
+            kern::PassArgs<TU> a = base_args<TU>(device_in, device_out, root_of_unity_table, cfg.n_power,
+                                                 cfg.reduction_poly, batch_size);
+            a.mod = modulus;
+            run_percoefficient<TU, false>(a, cfg.n_power, batch_size, in_flags, 0u, cfg.stream);
+            return;
+        }
         if (batch_size > 0 && modulus.value >= 3 && modulus.bit <= TU(lazy::Mod<TU>::MAX_BIT) &&
             lazy_eligible<TU>(cfg.n_power, batch_size, 1))
         {
@@ -189,6 +255,16 @@ namespace gpuntt
         check_layout_and_range(cfg.ntt_layout, cfg.n_power);
         const unsigned out_flags =
             kern::F_SCALE | (std::is_signed<T>::value ? kern::F_CENTERED : 0u);
+        if (cfg.ntt_layout == PerCoefficient)
+        {
+            kern::PassArgs<TU> a =
+                base_args<TU>(device_in, reinterpret_cast<TU*>(device_out), root_of_unity_table,
+                              cfg.n_power, cfg.reduction_poly, batch_size);
+            a.mod = modulus;
+            a.ninv = cfg.mod_inverse;
+            run_percoefficient<TU, true>(a, cfg.n_power, batch_size, 0u, out_flags, cfg.stream);
+            return;
+        }
         if (batch_size > 0 && modulus.value >= 3 && modulus.bit <= TU(lazy::Mod<TU>::MAX_BIT) &&
             lazy_eligible<TU>(cfg.n_power, batch_size, 1) && cfg.mod_inverse < modulus.value)
         {
@@ -235,6 +311,15 @@ namespace gpuntt
             throw std::invalid_argument("Invalid mod_count!");
         const unsigned in_flags = std::is_signed<T>::value ? kern::F_SIGNED_IN : 0u;
         const unsigned* skip_flag = nullptr;
+        if (cfg.ntt_layout == PerCoefficient)
+        {
+            kern::PassArgs<TU> a = base_args<TU>(device_in, device_out, root_of_unity_table, cfg.n_power,
+                                                 cfg.reduction_poly, batch_size);
+            a.mods = modulus;
+            a.mod_count = mod_count;
+            run_percoefficient<TU, false>(a, cfg.n_power, batch_size, in_flags, 0u, cfg.stream);
+            return;
+        }
         if (batch_size > 0 && lazy_eligible<TU>(cfg.n_power, batch_size, mod_count))
         {
             kern::LazyArgsT<TU> la =
@@ -266,6 +351,17 @@ namespace gpuntt
         const unsigned out_flags =
             kern::F_SCALE | (std::is_signed<T>::value ? kern::F_CENTERED : 0u);
         const unsigned* skip_flag = nullptr;
+        if (cfg.ntt_layout == PerCoefficient)
+        {
+            kern::PassArgs<TU> a =
+                base_args<TU>(device_in, reinterpret_cast<TU*>(device_out), root_of_unity_table,
+                              cfg.n_power, cfg.reduction_poly, batch_size);
+            a.mods = modulus;
+            a.mod_count = mod_count;
+            a.ninv_arr = cfg.mod_inverse;
+            run_percoefficient<TU, true>(a, cfg.n_power, batch_size, 0u, out_flags, cfg.stream);
+            return;
+        }
         if (batch_size > 0 && cfg.mod_inverse != nullptr &&
             lazy_eligible<TU>(cfg.n_power, batch_size, mod_count))
         {

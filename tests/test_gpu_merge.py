@@ -349,3 +349,40 @@ def test_small_and_odd_sized_moduli_u64(g):
             want = c.P.merge_ntt(x, c.oprm)
             assert np.array_equal(c.gpu_forward(x), want), (bits, logn, poly)
             assert np.array_equal(c.gpu_inverse(want), x), (bits, logn, poly)
+
+
+@pytest.mark.parametrize("bits", [32, 64])
+def test_percoefficient_layout(g, bits):
+    """Column-wise transforms (cfg.ntt_layout = PerCoefficient): the N x batch matrix is transformed
+    along its columns in place.  The reference only checks this GPU-vs-GPU against the transposed
+    PerPolynomial result (test_merge_ntt.cu:343-474, test_merge_intt.cu:381-515); here it is pinned
+    to the oracle: column x of the output == NTTCPU::ntt(column x of the input)."""
+    import torch
+    for logn, w, poly in ((9, 1024, O.X_N_plus), (7, 128, O.X_N_minus), (4, 256, O.X_N_plus),
+                          (9, 256, O.X_N_minus), (5, 16, O.X_N_plus), (3, 2, O.X_N_minus), (8, 64, O.X_N_plus),
+                          (1, 1, O.X_N_minus), (9, 8, O.X_N_plus)):
+        c = MergeCase(g, bits, logn, poly)
+        n = c.n
+        cols = c.random(w, 900 + logn + w).reshape(w, n)            # row p = polynomial p
+        mat = np.ascontiguousarray(cols.T)                          # N x W, element (coef, poly)
+        want_f = np.ascontiguousarray(c.P.merge_ntt(cols.reshape(-1), c.oprm).reshape(w, n).T)
+        want_i = np.ascontiguousarray(c.P.merge_ntt(cols.reshape(-1), c.oprm, inverse=True).reshape(w, n).T)
+        cfg = g.ntt_configuration(n_power=logn, ntt_layout=g.PerCoefficient, reduction_poly=poly)
+        d = g.to_device(mat.reshape(-1))
+        o = torch.zeros_like(d)
+        g.GPU_NTT(d, o, c.fwd_dev, c.prm.modulus, cfg, w)
+        torch.cuda.synchronize()
+        assert np.array_equal(g.to_host(o).reshape(n, w), want_f), ("fwd", bits, logn, w)
+        icfg = g.ntt_configuration(n_power=logn, ntt_type=g.INVERSE, ntt_layout=g.PerCoefficient,
+                                   reduction_poly=poly, mod_inverse=c.prm.n_inv)
+        g.GPU_INTT_Inplace(d, c.inv_dev, c.prm.modulus, icfg, w)
+        torch.cuda.synchronize()
+        assert np.array_equal(g.to_host(d).reshape(n, w), want_i), ("inv", bits, logn, w)
+    c = MergeCase(g, bits, 4, O.X_N_minus)
+    d = g.to_device(c.random(3, 1))
+    with pytest.raises(ValueError, match="power of two"):
+        g.GPU_NTT_Inplace(d, c.fwd_dev, c.prm.modulus,
+                          g.ntt_configuration(n_power=4, ntt_layout=g.PerCoefficient), 3)
+    with pytest.raises(ValueError, match="Invalid n_power range!"):
+        g.GPU_NTT_Inplace(d, c.fwd_dev, c.prm.modulus,
+                          g.ntt_configuration(n_power=10, ntt_layout=g.PerCoefficient), 4)
