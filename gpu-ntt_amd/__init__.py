@@ -84,8 +84,8 @@ def load_library():
 # every symbol include/gpuntt_c.h declares
 EXPORTED_SYMBOLS = ["gpuntt_last_error", "gpuntt_version"] + [
     "gpuntt_%s_%s" % (f, s)
-    for f in ("modulus", "ntt", "intt", "ntt_rns", "intt_rns", "4step", "4step_rns",
-              "transpose", "merge_params", "4step_params")
+    for f in ("modulus", "ntt", "intt", "ntt_rns", "intt_rns", "ntt_modulus_ordered",
+              "ntt_poly_ordered", "4step", "4step_rns", "transpose", "merge_params", "4step_params")
     for s in ("u32", "u64")]
 
 
@@ -320,6 +320,32 @@ def GPU_NTT_Inplace(device_inout, root_of_unity_table, modulus, cfg, batch_size,
 
 def GPU_INTT_Inplace(device_inout, root_of_unity_table, modulus, cfg, batch_size, mod_count=None):
     GPU_INTT(device_inout, device_inout, root_of_unity_table, modulus, cfg, batch_size, mod_count)
+
+
+def _ordered(fname, device_in, device_out, root_of_unity_table, modulus, cfg, batch_size, mod_count, order):
+    lib = load_library()
+    _require_gpu(device_in, device_out, root_of_unity_table, modulus, order)
+    bits = device_in.element_size() * 8
+    fn = getattr(lib, "gpuntt_%s_u%d" % (fname, bits))
+    _check(fn(_ptr(device_in), _ptr(device_out), _ptr(root_of_unity_table), _ptr(modulus), cfg.n_power,
+              cfg.ntt_type, cfg.reduction_poly, _ptr(cfg.mod_inverse), _stream(cfg.stream), batch_size,
+              int(mod_count), _ptr(order)))
+
+
+def GPU_NTT_Modulus_Ordered(device_in, device_out, root_of_unity_table, modulus, cfg, batch_size,
+                            mod_count, order):
+    """polynomial p uses prime order[p % mod_count] (reference ntt.cuh:515-529); cfg.ntt_type picks
+    FORWARD / INVERSE; `order` is an int32 device tensor."""
+    _ordered("ntt_modulus_ordered", device_in, device_out, root_of_unity_table, modulus, cfg,
+             batch_size, mod_count, order)
+
+
+def GPU_NTT_Poly_Ordered(device_in, device_out, root_of_unity_table, modulus, cfg, batch_size,
+                         mod_count, order):
+    """polynomial p is the one in slot order[p] and uses modulus p % mod_count
+    (reference ntt.cuh:589-603)."""
+    _ordered("ntt_poly_ordered", device_in, device_out, root_of_unity_table, modulus, cfg, batch_size,
+             mod_count, order)
 
 
 def GPU_Transpose(polynomial_in, polynomial_out, row, col, n_power, batch_size):

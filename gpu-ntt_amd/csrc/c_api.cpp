@@ -167,6 +167,29 @@ namespace
         });
     }
 
+    template <typename T, typename CM>
+    int ordered(bool poly_ordered, const T* in, T* out, const T* roots, const CM* modulus, int n_power,
+                int ntt_type, int poly, const T* mod_inverse, void* stream, int batch, int mod_count,
+                const int* order)
+    {
+        return guarded([&] {
+            ntt_rns_configuration<T> cfg = {n_power,
+                                            static_cast<type>(ntt_type),
+                                            PerPolynomial,
+                                            static_cast<ReductionPolynomial>(poly),
+                                            false,
+                                            const_cast<T*>(mod_inverse),
+                                            static_cast<hipStream_t>(stream)};
+            auto* mods = reinterpret_cast<Modulus<T>*>(const_cast<CM*>(modulus));
+            if (poly_ordered)
+                GPU_NTT_Poly_Ordered<T>(const_cast<T*>(in), out, const_cast<T*>(roots), mods, cfg, batch,
+                                        mod_count, const_cast<int*>(order));
+            else
+                GPU_NTT_Modulus_Ordered<T>(const_cast<T*>(in), out, const_cast<T*>(roots), mods, cfg, batch,
+                                           mod_count, const_cast<int*>(order));
+        });
+    }
+
     template <typename T>
     int merge_params(int logn, int poly, const T* factors, uint64_t* info, T* fwd, T* inv)
     {
@@ -298,6 +321,22 @@ extern "C"
     {                                                                                             \
         return intt_rns<T>(in, out, inverse_roots, modulus, n_power, ntt_layout, reduction_poly,  \
                            mod_inverse, output_signed, stream, batch_size, mod_count);            \
+    }                                                                                             \
+    int gpuntt_ntt_modulus_ordered_##S(const T* in, T* out, const T* roots, const CM* modulus,    \
+                                       int n_power, int ntt_type, int reduction_poly,             \
+                                       const T* mod_inverse, void* stream, int batch_size,        \
+                                       int mod_count, const int* order)                           \
+    {                                                                                             \
+        return ordered<T>(false, in, out, roots, modulus, n_power, ntt_type, reduction_poly,      \
+                          mod_inverse, stream, batch_size, mod_count, order);                     \
+    }                                                                                             \
+    int gpuntt_ntt_poly_ordered_##S(const T* in, T* out, const T* roots, const CM* modulus,       \
+                                    int n_power, int ntt_type, int reduction_poly,                \
+                                    const T* mod_inverse, void* stream, int batch_size,           \
+                                    int mod_count, const int* order)                              \
+    {                                                                                             \
+        return ordered<T>(true, in, out, roots, modulus, n_power, ntt_type, reduction_poly,       \
+                          mod_inverse, stream, batch_size, mod_count, order);                     \
     }                                                                                             \
     int gpuntt_4step_##S(const T* in, T* out, const T* n1_table, const T* n2_table,               \
                          const T* w_table, CM modulus, int n_power, int ntt_type, T mod_inverse,  \

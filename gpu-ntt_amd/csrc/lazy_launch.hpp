@@ -30,13 +30,14 @@ namespace gpuntt
         template <typename T>
         void launch_prep(const T* roots, lazy::Tw<T>* ws, const Modulus<T>* mods, T q, int mod_count, int n,
                          bool negacyclic, int perm_tile_log, const T* ninv_arr, lazy::Tw<T>* ws_ninv,
-                         unsigned* go_flag, lazy::NormConst* norm_arr, hipStream_t stream);
+                         unsigned* go_flag, lazy::NormConst* norm_arr, hipStream_t stream,
+                         const int* mod_order = nullptr);
         extern template void launch_prep<uint64_t>(const uint64_t*, lazy::Tw64*, const Modulus<uint64_t>*,
                                                    uint64_t, int, int, bool, int, const uint64_t*,
-                                                   lazy::Tw64*, unsigned*, lazy::NormConst*, hipStream_t);
+                                                   lazy::Tw64*, unsigned*, lazy::NormConst*, hipStream_t, const int*);
         extern template void launch_prep<uint32_t>(const uint32_t*, lazy::Tw32*, const Modulus<uint32_t>*,
                                                    uint32_t, int, int, bool, int, const uint32_t*,
-                                                   lazy::Tw32*, unsigned*, lazy::NormConst*, hipStream_t);
+                                                   lazy::Tw32*, unsigned*, lazy::NormConst*, hipStream_t, const int*);
 
         template <typename T>
         void launch_prep_pairs(const T* src, lazy::Tw<T>* dst, unsigned long long count, T q, hipStream_t stream);

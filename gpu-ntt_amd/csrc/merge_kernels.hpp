@@ -62,6 +62,8 @@ namespace gpuntt
             T ninv;
             const T* w_table;       // 4-step W matrix (F_FOURSTEP_T) or nullptr
             const unsigned* skip_flag; // device word or nullptr: != 0 -> the fast path owns this call
+            const int* mod_order;  // *_Modulus_Ordered: polynomial p uses prime mod_order[p % mod_count]
+            const int* poly_order; // *_Poly_Ordered: polynomial p lives in slot poly_order[p] of in/out
             unsigned long long total; // batch * N coefficients
             int n;          // log2 of the transform length (twiddle indexing)
             int poly_shift; // log2 of the polynomial length (modulus selection: flat >> poly_shift)
@@ -158,7 +160,9 @@ namespace gpuntt
             Ctx<T> c;
             if (a.mods != nullptr)
             {
-                const int mi = static_cast<int>(poly % static_cast<unsigned>(a.mod_count));
+                int mi = static_cast<int>(poly % static_cast<unsigned>(a.mod_count));
+                if (a.mod_order != nullptr)
+                    mi = a.mod_order[mi]; // reference ForwardCoreModulusOrdered, ntt.cu:3117-3118
                 const Modulus<T> md = a.mods[mi];
                 c.m = dev::ModCtx<T>{md.value, md.bit, md.mu};
                 c.ninv = (a.ninv_arr != nullptr) ? a.ninv_arr[mi] : a.ninv;
@@ -173,12 +177,24 @@ namespace gpuntt
             return c;
         }
 
+        // logical flat index (polynomial p, coefficient i) -> memory index; only *_Poly_Ordered
+        // calls remap the polynomial slot (reference ForwardCorePolyOrdered, ntt.cu:3797-3798)
+        template <typename T>
+        __device__ __forceinline__ unsigned long long phys(const PassArgs<T>& a, unsigned long long flat)
+        {
+            if (a.poly_order == nullptr)
+                return flat;
+            const unsigned long long slot = static_cast<unsigned>(a.poly_order[flat >> a.poly_shift]);
+            return (slot << a.poly_shift) | (flat & ((1ull << a.poly_shift) - 1));
+        }
+
         template <typename T>
         __device__ __forceinline__ T load_in(const PassArgs<T>& a, unsigned long long flat, T q)
         {
             using S = typename std::make_signed<T>::type;
             if (flat >= a.total)
                 return 0;
+            flat = phys(a, flat);
             if (a.flags & F_SIGNED_IN)
             {
                 S v = static_cast<const S*>(a.in)[flat];
@@ -354,7 +370,7 @@ namespace gpuntt
                         {
                             const unsigned long long f = map.flat(elem_of<WL>(t, j));
                             if (f < a.total)
-                                a.out[f] = finish(v[j], f);
+                                a.out[phys(a, f)] = finish(v[j], f);
                         }
                     }
                     else
@@ -369,7 +385,7 @@ namespace gpuntt
                             const int e = t + NT * j;
                             const unsigned long long f = map.flat(e);
                             if (f < a.total)
-                                a.out[f] = finish(lds[lds_pad(e)], f);
+                                a.out[phys(a, f)] = finish(lds[lds_pad(e)], f);
                         }
                     }
                 }

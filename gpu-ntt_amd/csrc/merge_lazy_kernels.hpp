@@ -38,6 +38,8 @@ namespace gpuntt
             lazy::NormConst norm;            // single modulus: final-normalisation constants
             const lazy::NormConst* norm_arr; // RNS: per modulus (written by the prep kernel) or nullptr
             const unsigned* go_flag;         // RNS: device word, 1 = every modulus has lazy headroom
+            const int* mod_order;            // *_Modulus_Ordered: prime of slot mi is mod_order[mi]
+            const int* poly_order;           // *_Poly_Ordered: polynomial p lives in slot poly_order[p]
             const lazy::Tw<T>* w_pairs;      // 4-step phase 1: prepared W matrix (N pairs)
             int n2_log;                      // 4-step phase 1: log2 n2
             int batch;                       // 4-step phase 1: polynomials (block order is poly-minor)
@@ -105,6 +107,14 @@ namespace gpuntt
                     return p;
                 else
                     return p_lo + (p - L);
+            }
+            // *_Poly_Ordered: move the tile to the memory slot of its polynomial (tiles never straddle
+            // polynomials on this path: the host requires n >= TLOG)
+            __device__ __forceinline__ void remap_poly(const int* order, int n)
+            {
+                const unsigned long long poly = base >> n;
+                base = (static_cast<unsigned long long>(static_cast<unsigned>(order[poly])) << n) |
+                       (base & ((1ull << n) - 1));
             }
             // flat(e) = base + part(e), and part() is additive over disjoint tile bits: the part of
             // the register bits is block-uniform (goes into the scalar base address), the part of
@@ -247,10 +257,12 @@ namespace gpuntt
             constexpr bool MULTI_POLY = CONTIG && (K < TL) && (IN_BOUND == 1) && (LAST || FST);
 
             const int t = threadIdx.x;
-            const LTileMap<TLOG, CONTIG, K> map =
+            LTileMap<TLOG, CONTIG, K> map =
                 FST ? LTileMap<TLOG, CONTIG, K>((fst_poly << a.poly_shift) +
                                                 (static_cast<unsigned long long>(fst_tile) << TL))
                     : LTileMap<TLOG, CONTIG, K>(a.n, a.p_lo);
+            if (a.poly_order != nullptr)
+                map.remap_poly(a.poly_order, a.n); // twiddle indices use flat & (N-1): unaffected
             M m;
             m.set(q_value, (a.norm_arr != nullptr) ? a.norm_arr[mi] : a.norm);
             const dev::ModCtx<T> em{q_value, q_bit, q_mu};
@@ -618,7 +630,7 @@ namespace gpuntt
                 const LTileMap<TLOG, CONTIG, K> map(a.n, a.p_lo);
                 const unsigned long long poly = map.flat(0) >> a.poly_shift;
                 mi = static_cast<int>(poly % static_cast<unsigned>(a.mod_count));
-                const Modulus<T> md = a.mods[mi];
+                const Modulus<T> md = a.mods[a.mod_order != nullptr ? a.mod_order[mi] : mi];
                 qv = md.value;
                 qb = md.bit;
                 qm = md.mu;

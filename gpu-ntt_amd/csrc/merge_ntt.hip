@@ -105,7 +105,7 @@ namespace gpuntt
         inline kern::LazyArgsT<TU> lazy_args(const void* in, TU* out, const TU* roots, const Modulus<TU>& m,
                                             const Modulus<TU>* mods, int mod_count, const TU* ninv_dev,
                                             int n_power, ReductionPolynomial poly, int batch_size,
-                                            hipStream_t stream)
+                                            hipStream_t stream, const int* mod_order = nullptr)
         {
             using TW = lazy::Tw<TU>;
             const bool neg = (poly == ReductionPolynomial::X_N_plus);
@@ -120,7 +120,7 @@ namespace gpuntt
             unsigned* go_flag = mods ? reinterpret_cast<unsigned*>(tail_p) : nullptr;
             auto* norm_arr = mods ? reinterpret_cast<lazy::NormConst*>(tail_p + 16) : nullptr;
             host::launch_prep<TU>(roots, ws, mods, m.value, mod_count, n_power, neg, perm_tile_log, ninv_dev,
-                                  ninv_dev ? ws_ninv : nullptr, go_flag, norm_arr, stream);
+                                  ninv_dev ? ws_ninv : nullptr, go_flag, norm_arr, stream, mod_order);
             kern::LazyArgsT<TU> a{};
             a.in = in;
             a.out = out;
@@ -132,6 +132,8 @@ namespace gpuntt
             a.ninv_arr = ninv_dev ? ws_ninv : nullptr;
             a.ninv = TW{0, 0};
             a.go_flag = go_flag;
+            a.mod_order = mod_order;
+            a.poly_order = nullptr;
             a.norm = lazy::make_norm_const(static_cast<uint64_t>(m.value), static_cast<uint64_t>(m.bit));
             a.norm_arr = norm_arr;
             a.total = static_cast<unsigned long long>(batch_size) << n_power;
@@ -400,6 +402,103 @@ namespace gpuntt
         GPU_INTT<T>(device_inout, device_inout, root_of_unity_table, modulus, cfg, batch_size,
                     mod_count);
     }
+
+    // ---------------------------------------------------------------- ordered RNS ----
+    namespace
+    {
+        template <typename T>
+        void ordered_run(T* device_in, T* device_out, Root<T>* table, Modulus<T>* modulus,
+                         const ntt_rns_configuration<T>& cfg, int batch_size, int mod_count,
+                         const int* mod_order, const int* poly_order)
+        {
+            // reference ntt.cu:3607-3610 / 4288-4291
+            if (cfg.n_power <= 9 || cfg.n_power >= 29)
+                throw std::invalid_argument("Invalid n_power range!");
+            if (mod_count <= 0 || modulus == nullptr || (mod_order == nullptr && poly_order == nullptr))
+                throw std::invalid_argument("Invalid mod_count!");
+            if (cfg.ntt_type != FORWARD && cfg.ntt_type != INVERSE)
+                return; // reference: `default: break`
+            if (batch_size <= 0)
+                return;
+            const bool inv = (cfg.ntt_type == INVERSE);
+            const unsigned* skip_flag = nullptr;
+            // fast path: whole tiles inside one polynomial
+            if (cfg.n_power >= host::lazy_tile_log<T>(cfg.n_power) &&
+                lazy_eligible<T>(cfg.n_power, batch_size, mod_count) && (!inv || cfg.mod_inverse != nullptr))
+            {
+                kern::LazyArgsT<T> la =
+                    lazy_args<T>(device_in, device_out, table, Modulus<T>(), modulus, mod_count,
+                                 inv ? cfg.mod_inverse : nullptr, cfg.n_power, cfg.reduction_poly,
+                                 batch_size, cfg.stream, mod_order);
+                la.poly_order = poly_order;
+                if (inv)
+                    host::run_transform_lazy<T, true>(la, 0u, kern::F_SCALE, cfg.stream);
+                else
+                    host::run_transform_lazy<T, false>(la, 0u, 0u, cfg.stream);
+                skip_flag = la.go_flag;
+            }
+            kern::PassArgs<T> a = base_args<T>(device_in, device_out, table, cfg.n_power,
+                                               cfg.reduction_poly, batch_size);
+            a.mods = modulus;
+            a.mod_count = mod_count;
+            a.ninv_arr = cfg.mod_inverse;
+            a.skip_flag = skip_flag;
+            a.mod_order = mod_order;
+            a.poly_order = poly_order;
+            set_multi(a);
+            if (inv)
+                host::run_transform<T, true>(a, 0u, kern::F_SCALE, cfg.stream);
+            else
+                host::run_transform<T, false>(a, 0u, 0u, cfg.stream);
+        }
+    } // namespace
+
+    template <typename T>
+    __host__ void GPU_NTT_Modulus_Ordered(T* device_in, T* device_out, Root<T>* root_of_unity_table,
+                                          Modulus<T>* modulus, ntt_rns_configuration<T> cfg,
+                                          int batch_size, int mod_count, int* order)
+    {
+        ordered_run<T>(device_in, device_out, root_of_unity_table, modulus, cfg, batch_size, mod_count,
+                       order, nullptr);
+    }
+    template <typename T>
+    __host__ void GPU_NTT_Modulus_Ordered_Inplace(T* device_inout, Root<T>* root_of_unity_table,
+                                                  Modulus<T>* modulus, ntt_rns_configuration<T> cfg,
+                                                  int batch_size, int mod_count, int* order)
+    {
+        ordered_run<T>(device_inout, device_inout, root_of_unity_table, modulus, cfg, batch_size,
+                       mod_count, order, nullptr);
+    }
+    template <typename T>
+    __host__ void GPU_NTT_Poly_Ordered(T* device_in, T* device_out, Root<T>* root_of_unity_table,
+                                       Modulus<T>* modulus, ntt_rns_configuration<T> cfg,
+                                       int batch_size, int mod_count, int* order)
+    {
+        ordered_run<T>(device_in, device_out, root_of_unity_table, modulus, cfg, batch_size, mod_count,
+                       nullptr, order);
+    }
+    template <typename T>
+    __host__ void GPU_NTT_Poly_Ordered_Inplace(T* device_inout, Root<T>* root_of_unity_table,
+                                               Modulus<T>* modulus, ntt_rns_configuration<T> cfg,
+                                               int batch_size, int mod_count, int* order)
+    {
+        ordered_run<T>(device_inout, device_inout, root_of_unity_table, modulus, cfg, batch_size,
+                       mod_count, nullptr, order);
+    }
+
+#define GPUNTT_INSTANTIATE_ORDERED(T)                                                          \
+    template __host__ void GPU_NTT_Modulus_Ordered<T>(T*, T*, Root<T>*, Modulus<T>*,           \
+                                                      ntt_rns_configuration<T>, int, int, int*); \
+    template __host__ void GPU_NTT_Modulus_Ordered_Inplace<T>(T*, Root<T>*, Modulus<T>*,       \
+                                                              ntt_rns_configuration<T>, int, int, \
+                                                              int*);                           \
+    template __host__ void GPU_NTT_Poly_Ordered<T>(T*, T*, Root<T>*, Modulus<T>*,              \
+                                                   ntt_rns_configuration<T>, int, int, int*);  \
+    template __host__ void GPU_NTT_Poly_Ordered_Inplace<T>(T*, Root<T>*, Modulus<T>*,          \
+                                                           ntt_rns_configuration<T>, int, int, int*);
+    GPUNTT_INSTANTIATE_ORDERED(Data32)
+    GPUNTT_INSTANTIATE_ORDERED(Data64)
+#undef GPUNTT_INSTANTIATE_ORDERED
 
     // ------------------------------------------------- exported symbol set ----
 #define GPUNTT_INSTANTIATE(T, TU)                                                              \

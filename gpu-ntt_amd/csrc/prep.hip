@@ -42,7 +42,8 @@ namespace gpuntt
                                                              const T* __restrict__ ninv_arr,
                                                              lazy::Tw<T>* __restrict__ ws_ninv,
                                                              unsigned* __restrict__ go_flag,
-                                                             lazy::NormConst* __restrict__ norm_arr)
+                                                             lazy::NormConst* __restrict__ norm_arr,
+                                                             const int* __restrict__ mod_order)
         {
             const unsigned long long gid = blockIdx.x * 256ull + threadIdx.x;
             if (gid == 0 && go_flag != nullptr)
@@ -50,24 +51,29 @@ namespace gpuntt
                 // every modulus must leave the lazy kernels their headroom
                 unsigned ok = 1u;
                 for (int i = 0; i < mod_count; i++)
-                    if (mods[i].bit > static_cast<T>(lazy::Mod<T>::MAX_BIT) || mods[i].value < 3)
+                {
+                    const Modulus<T> md = mods[mod_order != nullptr ? mod_order[i] : i];
+                    if (md.bit > static_cast<T>(lazy::Mod<T>::MAX_BIT) || md.value < 3)
                         ok = 0u;
+                    if (norm_arr != nullptr)
+                        norm_arr[i] = lazy::make_norm_const(md.value, md.bit);
+                }
                 *go_flag = ok;
-                if (norm_arr != nullptr)
-                    for (int i = 0; i < mod_count; i++)
-                        norm_arr[i] = lazy::make_norm_const(mods[i].value, mods[i].bit);
             }
             const unsigned long long per_mod = 1ull << n;
             if (gid >= per_mod * mod_count)
                 return;
             const int mi = static_cast<int>(gid >> n);
+            // prepared tables are indexed by the compact slot mi; the caller's moduli, tables and
+            // n^-1 values by the prime index (identical unless *_Modulus_Ordered remaps it)
+            const int prime = (mod_order != nullptr) ? mod_order[mi] : mi;
             const unsigned slot = static_cast<unsigned>(gid & (per_mod - 1));
-            const T q = (mods != nullptr) ? mods[mi].value : q_single;
+            const T q = (mods != nullptr) ? mods[prime].value : q_single;
             if (slot == 0)
             {
                 if (ninv_arr != nullptr && ws_ninv != nullptr)
                 {
-                    const T v = ninv_arr[mi];
+                    const T v = ninv_arr[prime];
                     ws_ninv[mi] = lazy::Tw<T>{v, shoup_quotient<T>(v, q)};
                 }
                 ws[gid] = lazy::Tw<T>{0, 0};
@@ -86,7 +92,7 @@ namespace gpuntt
                 i = tile * (rp * nt) + t * rp + kk;
             }
             const unsigned src = negacyclic ? ((1u << S) + i) : i;
-            const T w = roots[(static_cast<unsigned long long>(mi) << n) + src];
+            const T w = roots[(static_cast<unsigned long long>(prime) << n) + src];
             ws[gid] = lazy::Tw<T>{w, shoup_quotient<T>(w, q)};
         }
 
@@ -157,12 +163,12 @@ namespace gpuntt
         template <typename T>
         void launch_prep(const T* roots, lazy::Tw<T>* ws, const Modulus<T>* mods, T q, int mod_count, int n,
                          bool negacyclic, int perm_tile_log, const T* ninv_arr, lazy::Tw<T>* ws_ninv,
-                         unsigned* go_flag, lazy::NormConst* norm_arr, hipStream_t stream)
+                         unsigned* go_flag, lazy::NormConst* norm_arr, hipStream_t stream, const int* mod_order)
         {
             const unsigned long long entries = static_cast<unsigned long long>(mod_count) << n;
             const unsigned grid = static_cast<unsigned>((entries + 255) / 256);
             hipLaunchKernelGGL((kern::prep_twiddles<T>), dim3(grid), dim3(256), 0, stream, roots, ws, mods, q,
-                               mod_count, n, negacyclic ? 1 : 0, perm_tile_log, ninv_arr, ws_ninv, go_flag, norm_arr);
+                               mod_count, n, negacyclic ? 1 : 0, perm_tile_log, ninv_arr, ws_ninv, go_flag, norm_arr, mod_order);
             GPUNTT_HIP_CHECK(hipGetLastError());
         }
         template <typename T>
@@ -178,8 +184,8 @@ namespace gpuntt
                                                   hipStream_t);
 
         template void launch_prep<uint64_t>(const uint64_t*, lazy::Tw64*, const Modulus<uint64_t>*, uint64_t, int,
-                                            int, bool, int, const uint64_t*, lazy::Tw64*, unsigned*, lazy::NormConst*, hipStream_t);
+                                            int, bool, int, const uint64_t*, lazy::Tw64*, unsigned*, lazy::NormConst*, hipStream_t, const int*);
         template void launch_prep<uint32_t>(const uint32_t*, lazy::Tw32*, const Modulus<uint32_t>*, uint32_t, int,
-                                            int, bool, int, const uint32_t*, lazy::Tw32*, unsigned*, lazy::NormConst*, hipStream_t);
+                                            int, bool, int, const uint32_t*, lazy::Tw32*, unsigned*, lazy::NormConst*, hipStream_t, const int*);
     } // namespace host
 } // namespace gpuntt

@@ -100,4 +100,28 @@ namespace gpuntt
                                    Modulus<T>* modulus, ntt_rns_configuration<T> cfg,
                                    int batch_size, int mod_count);
 
+    // ---- RNS with an indirection table (reference ntt.cuh:495-603, hosts ntt.cu:3600-3776,
+    //      4281-4459).  n_power in [10, 28]; cfg.ntt_type selects FORWARD / INVERSE; `order` is a
+    //      device array.
+    //  Modulus_Ordered: polynomial p uses prime order[p % mod_count] -- its modulus, its table
+    //                   slot (prime << n_power) and, for INVERSE, cfg.mod_inverse[prime];
+    //  Poly_Ordered   : polynomial p is the one stored in slot order[p] of device_in / device_out
+    //                   and uses modulus p % mod_count.
+    template <typename T>
+    __host__ void GPU_NTT_Modulus_Ordered(T* device_in, T* device_out, Root<T>* root_of_unity_table,
+                                          Modulus<T>* modulus, ntt_rns_configuration<T> cfg,
+                                          int batch_size, int mod_count, int* order);
+    template <typename T>
+    __host__ void GPU_NTT_Modulus_Ordered_Inplace(T* device_inout, Root<T>* root_of_unity_table,
+                                                  Modulus<T>* modulus, ntt_rns_configuration<T> cfg,
+                                                  int batch_size, int mod_count, int* order);
+    template <typename T>
+    __host__ void GPU_NTT_Poly_Ordered(T* device_in, T* device_out, Root<T>* root_of_unity_table,
+                                       Modulus<T>* modulus, ntt_rns_configuration<T> cfg,
+                                       int batch_size, int mod_count, int* order);
+    template <typename T>
+    __host__ void GPU_NTT_Poly_Ordered_Inplace(T* device_inout, Root<T>* root_of_unity_table,
+                                               Modulus<T>* modulus, ntt_rns_configuration<T> cfg,
+                                               int batch_size, int mod_count, int* order);
+
 } // namespace gpuntt

@@ -13,6 +13,8 @@
  *       (in == out gives the *_Inplace overloads, ntt.cuh:331-340,411-421;
  *        input_signed / output_signed select the Data32s/Data64s instantiations,
  *        src/lib/ntt_merge/ntt.cu:4948-5082)
+ *   gpuntt_ntt_modulus_ordered_{u32,u64} / gpuntt_ntt_poly_ordered_{u32,u64}
+ *                               GPU_NTT_Modulus_Ordered / GPU_NTT_Poly_Ordered   ntt.cuh:495-603
  *   gpuntt_4step_{u32,u64}      GPU_4STEP_NTT<T> single      src/include/gpuntt/ntt_4step/ntt_4step.cuh:278-283
  *   gpuntt_4step_rns_{u32,u64}  GPU_4STEP_NTT<T> RNS         ntt_4step.cuh:301-307
  *   gpuntt_transpose_{u32,u64}  GPU_Transpose<T>             ntt_4step.cuh:46-49
@@ -95,6 +97,26 @@ extern "C"
                             const gpuntt_modulus64* modulus, int n_power, int ntt_layout,
                             int reduction_poly, const uint64_t* mod_inverse, int output_signed,
                             void* stream, int batch_size, int mod_count);
+
+    /* ---- ordered RNS entry points (reference ntt.cuh:495-603): ntt_type selects the direction,
+     *      `order` is a device int array; mod_inverse (device, indexed by prime) is used for
+     *      GPUNTT_INVERSE only.  n_power in [10, 28]. */
+    int gpuntt_ntt_modulus_ordered_u32(const uint32_t* in, uint32_t* out, const uint32_t* roots,
+                                       const gpuntt_modulus32* modulus, int n_power, int ntt_type,
+                                       int reduction_poly, const uint32_t* mod_inverse, void* stream,
+                                       int batch_size, int mod_count, const int* order);
+    int gpuntt_ntt_modulus_ordered_u64(const uint64_t* in, uint64_t* out, const uint64_t* roots,
+                                       const gpuntt_modulus64* modulus, int n_power, int ntt_type,
+                                       int reduction_poly, const uint64_t* mod_inverse, void* stream,
+                                       int batch_size, int mod_count, const int* order);
+    int gpuntt_ntt_poly_ordered_u32(const uint32_t* in, uint32_t* out, const uint32_t* roots,
+                                    const gpuntt_modulus32* modulus, int n_power, int ntt_type,
+                                    int reduction_poly, const uint32_t* mod_inverse, void* stream,
+                                    int batch_size, int mod_count, const int* order);
+    int gpuntt_ntt_poly_ordered_u64(const uint64_t* in, uint64_t* out, const uint64_t* roots,
+                                    const gpuntt_modulus64* modulus, int n_power, int ntt_type,
+                                    int reduction_poly, const uint64_t* mod_inverse, void* stream,
+                                    int batch_size, int mod_count, const int* order);
 
     /* ---- 4-Step NTT (cyclic, 12 <= n_power <= 24, in != out) ------------------------ */
     int gpuntt_4step_u32(const uint32_t* in, uint32_t* out, const uint32_t* n1_table,

@@ -386,3 +386,60 @@ def test_percoefficient_layout(g, bits):
     with pytest.raises(ValueError, match="Invalid n_power range!"):
         g.GPU_NTT_Inplace(d, c.fwd_dev, c.prm.modulus,
                           g.ntt_configuration(n_power=10, ntt_layout=g.PerCoefficient), 4)
+
+
+def _prime_stack(g, bits, logn, poly, count):
+    """`count` primes with their tables stacked at i << n_power (+ device moduli / n^-1 arrays)."""
+    from gpu_utils import find_ntt_factors
+    fl = [find_ntt_factors(60 if bits == 64 else 30, logn, skip=i) for i in range(count)]
+    return _rns_setup(g, bits, logn, poly, fl)
+
+
+@pytest.mark.parametrize("bits", [32, 64])
+def test_modulus_ordered_and_poly_ordered(g, bits):
+    """GPU_NTT_Modulus_Ordered / GPU_NTT_Poly_Ordered (reference ntt.cuh:495-603; no reference test
+    exists, pinned per polynomial through the oracle)."""
+    import torch
+    for logn, poly in ((10, O.X_N_plus), (12, O.X_N_minus), (13, O.X_N_plus), (15, O.X_N_minus)):
+        n = 1 << logn
+        cases, fwd, inv, mods, ninv = _prime_stack(g, bits, logn, poly, 6)
+        # ---- modulus ordered: primes 1, 3, 4 of the 6-prime stack, batch 7
+        order = [1, 3, 4]
+        d_order = torch.tensor(order, dtype=torch.int32, device="cuda")
+        batch, mc = 7, 3
+        prime_of = [order[p % mc] for p in range(batch)]
+        x = np.concatenate([cases[pr].P.splitmix(300 + p, 0, n, cases[pr].q) for p, pr in enumerate(prime_of)])
+        want = np.concatenate([cases[pr].P.merge_ntt(x[p * n:(p + 1) * n], cases[pr].oprm)
+                               for p, pr in enumerate(prime_of)])
+        d = g.to_device(x)
+        o = torch.zeros_like(d)
+        cfg = g.ntt_rns_configuration(n_power=logn, ntt_type=g.FORWARD, reduction_poly=poly)
+        g.GPU_NTT_Modulus_Ordered(d, o, fwd, mods, cfg, batch, mc, d_order)
+        torch.cuda.synchronize()
+        assert np.array_equal(g.to_host(o), want), ("mod-ordered fwd", bits, logn)
+        icfg = g.ntt_rns_configuration(n_power=logn, ntt_type=g.INVERSE, reduction_poly=poly, mod_inverse=ninv)
+        g.GPU_NTT_Modulus_Ordered(o, o, inv, mods, icfg, batch, mc, d_order)
+        torch.cuda.synchronize()
+        assert np.array_equal(g.to_host(o), x), ("mod-ordered inv", bits, logn)
+
+        # ---- poly ordered: 8 of 10 stored polynomials, 4 moduli (reference example 3 pattern)
+        slots = [9, 4, 8, 3, 0, 6, 1, 2]
+        d_slots = torch.tensor(slots, dtype=torch.int32, device="cuda")
+        batch, mc, stored = 8, 4, 10
+        buf = np.zeros(stored * n, dtype=cases[0].P.T)
+        for p, sl in enumerate(slots):
+            buf[sl * n:(sl + 1) * n] = cases[p % mc].P.splitmix(500 + p, 0, n, cases[p % mc].q)
+        for sl in (5, 7):  # untouched slots keep arbitrary content
+            buf[sl * n:(sl + 1) * n] = 12345
+        want = buf.copy()
+        for p, sl in enumerate(slots):
+            want[sl * n:(sl + 1) * n] = cases[p % mc].P.merge_ntt(buf[sl * n:(sl + 1) * n], cases[p % mc].oprm)
+        d = g.to_device(buf)
+        g.GPU_NTT_Poly_Ordered(d, d, fwd, mods, cfg, batch, mc, d_slots)
+        torch.cuda.synchronize()
+        assert np.array_equal(g.to_host(d), want), ("poly-ordered fwd", bits, logn)
+        g.GPU_NTT_Poly_Ordered(d, d, inv, mods, icfg, batch, mc, d_slots)
+        torch.cuda.synchronize()
+        assert np.array_equal(g.to_host(d), buf), ("poly-ordered inv", bits, logn)
+    with pytest.raises(ValueError, match="Invalid n_power range!"):
+        g.GPU_NTT_Modulus_Ordered(d, d, fwd, mods, g.ntt_rns_configuration(n_power=9), 1, 1, d_order)
