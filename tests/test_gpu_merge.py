@@ -443,3 +443,16 @@ def test_modulus_ordered_and_poly_ordered(g, bits):
         assert np.array_equal(g.to_host(d), buf), ("poly-ordered inv", bits, logn)
     with pytest.raises(ValueError, match="Invalid n_power range!"):
         g.GPU_NTT_Modulus_Ordered(d, d, fwd, mods, g.ntt_rns_configuration(n_power=9), 1, 1, d_order)
+
+
+@pytest.mark.parametrize("bits,logn", [(64, 22), (64, 24), (32, 23), (64, 25), (32, 25)])
+def test_large_rings(g, bits, logn):
+    """Three-sweep plans (2^21..2^24, fast path) and rings above the fast path's table limit
+    (2^25+, generic kernels; the reference needs its grid-swapped ForwardCore_ there,
+    ntt.cu:763-1084).  Batch 2 so the fast path is eligible where it applies."""
+    c = MergeCase(g, bits, logn, O.X_N_minus if logn % 2 else O.X_N_plus)
+    x = c.random(2, 77 + logn)
+    y = c.gpu_forward(x, inplace=True)
+    n = c.n
+    assert np.array_equal(y[n:], c.P.merge_ntt(x[n:], c.oprm))
+    assert np.array_equal(c.gpu_inverse(y, inplace=True), x)
