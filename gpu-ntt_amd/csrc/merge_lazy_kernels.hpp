@@ -52,6 +52,14 @@ namespace gpuntt
         };
         using LazyArgs = LazyArgsT<uint64_t>;
 
+        // lds_pad(elem_of<WL>(t, j)) == lds_pad(elem_of<WL>(t, 0)) + lds_joff<WL>(j): the register part
+        // of every LDS index is a compile-time constant (ds_read/ds_write immediate offset), so a
+        // round's 16 accesses share one per-thread base address
+        template <int WL> constexpr int lds_joff(int j)
+        {
+            return (j << WL) + ((WL >= 4) ? (j << (WL >= 4 ? WL - 4 : 0)) : (j >> (WL < 4 ? 4 - WL : 0)));
+        }
+
         // ---- tile geometry of the fast kernels: 2^TLOG coefficients, 2^(TLOG-R) threads --------
         template <int TLOG> struct LTile
         {
@@ -360,6 +368,7 @@ namespace gpuntt
                 constexpr int FIRST_POS = SCH::first_pos(r);
                 constexpr int WL = SCH::wl_of(r);
                 constexpr bool DIRECT_IO = (WL >= 4);
+                constexpr bool UNIFORM_R = (WL + R == TL) || (WL >= 6); // scalar twiddles this round
 
                 // ---- gather -----------------------------------------------------------
                 if constexpr (r == 0)
@@ -402,9 +411,10 @@ namespace gpuntt
 #pragma unroll
                             for (int j = 0; j < EPT; j++)
                                 tmp[j] = (src + (map.base + static_cast<unsigned>(NT * j)))[t];
+                            T* lc = lds + lds_pad(t);
 #pragma unroll
                             for (int j = 0; j < EPT; j++)
-                                lds[lds_pad(t + NT * j)] = tmp[j];
+                                lc[NT * j + ((NT * j) >> 4)] = tmp[j];
                         }
                         else
                         {
@@ -413,16 +423,18 @@ namespace gpuntt
                                 lds[lds_pad(t + NT * j)] = load_guarded(map.flat(t + NT * j));
                         }
                         __syncthreads();
+                        const T* lw = lds + lds_pad(elem_of<WL>(t, 0));
 #pragma unroll
                         for (int j = 0; j < EPT; j++)
-                            v[j] = lds[lds_pad(elem_of<WL>(t, j))];
+                            v[j] = lw[lds_joff<WL>(j)];
                     }
                 }
                 else
                 {
+                    const T* lw = lds + lds_pad(elem_of<WL>(t, 0));
 #pragma unroll
                     for (int j = 0; j < EPT; j++)
-                        v[j] = lds[lds_pad(elem_of<WL>(t, j))];
+                        v[j] = lw[lds_joff<WL>(j)];
                 }
 
                 TW tw_cur[TW_PER_ROUND];
@@ -462,7 +474,14 @@ namespace gpuntt
                             T U = v[j0];
                             if constexpr (ku != 0)
                                 U = m.template csub<ku>(U);
-                            const T Tm = m.mul(v[j1], tw);
+                            T Tm;
+                            // first stage of a cyclic transform: table[0] = omega^0 = 1 for every
+                            // butterfly (block-uniform scalar test, so tables that differ still work);
+                            // V is a canonical input there, so V itself is the product
+                            if constexpr (UNIFORM_R && r == 0 && s == 0 && IN_BOUND <= M::TB && !FST)
+                                Tm = (tw.w == 1) ? v[j1] : m.mul(v[j1], tw);
+                            else
+                                Tm = m.mul(v[j1], tw);
                             v[j0] = U + Tm;
                             v[j1] = U + m.kq(M::TB) - Tm;
                         }
@@ -571,15 +590,17 @@ namespace gpuntt
                     }
                     else
                     {
+                        T* lw = lds + lds_pad(elem_of<WL>(t, 0));
 #pragma unroll
                         for (int j = 0; j < EPT; j++)
-                            lds[lds_pad(elem_of<WL>(t, j))] = v[j];
+                            lw[lds_joff<WL>(j)] = v[j];
                         __syncthreads();
                         if (full_tile)
                         {
+                            const T* lc = lds + lds_pad(t);
 #pragma unroll
                             for (int j = 0; j < EPT; j++)
-                                (a.out + (map.base + static_cast<unsigned>(NT * j)))[t] = lds[lds_pad(t + NT * j)];
+                                (a.out + (map.base + static_cast<unsigned>(NT * j)))[t] = lc[NT * j + ((NT * j) >> 4)];
                         }
                         else
                         {
@@ -598,9 +619,10 @@ namespace gpuntt
                     // next round's twiddles are requested before the exchange barrier
                     if constexpr (TW_AHEAD)
                         load_twiddles(std::integral_constant<int, r + 1>{}, tw_next);
+                    T* lw = lds + lds_pad(elem_of<WL>(t, 0));
 #pragma unroll
                     for (int j = 0; j < EPT; j++)
-                        lds[lds_pad(elem_of<WL>(t, j))] = v[j];
+                        lw[lds_joff<WL>(j)] = v[j];
                     __syncthreads();
                 }
             });
