@@ -174,9 +174,10 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_call": alg_bytes,
                          "call_ms_hip_events": call_ms,
-                         "note": "one call = every launch of one GPU_NTT (twiddle prep + 4-stage strided "
-                                 "pass + 12-stage contiguous pass = 2 HBM sweeps); the contiguous pass "
-                                 "dominates and is VALU-issue bound; per-kernel averages in profiles/"},
+                         "note": "one call = every launch of one GPU_NTT (twiddle prep + 6-stage strided "
+                                 "pass + 10-stage contiguous pass = 2 HBM sweeps, traffic = PMC bytes per "
+                                 "call); the contiguous pass dominates and is VALU-issue bound; per-kernel "
+                                 "averages in profiles/"},
         }
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(prm.modulus.value, x[:args.cpu_polys * n], y_first, LOGN)
