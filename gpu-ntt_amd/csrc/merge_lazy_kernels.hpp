@@ -18,12 +18,6 @@ namespace gpuntt
 {
     namespace kern
     {
-        enum : unsigned
-        {
-            F_PERM_LOW = 64u // (informational) prepared table permutes the distance-1/2/4 stages;
-                             // implied by n >= 12, i.e. by the CONTIG K = 12 kernel itself
-        };
-
         template <typename T> struct LazyArgsT
         {
             const void* in;

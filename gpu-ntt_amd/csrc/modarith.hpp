@@ -1,13 +1,10 @@
 // modarith.hpp -- device-side modular arithmetic cores used by the NTT kernels (gfx950).
 //
-// Two interchangeable multiply cores, both yielding values congruent to a*b (mod q):
-//   * BarrettCore<T>: the reference's {value, bit, mu} Barrett contract
-//     (reference src/include/gpuntt/common/modular_arith.cuh:312-339); needs nothing but the
-//     caller's Modulus<T> and the caller's plain twiddle table.
-//   * ShoupCore<T>  : precomputed-quotient (Shoup) multiply by a fixed twiddle w with
-//     companion w' = floor(w * 2^W / q) produced by the library's twiddle-prep kernel.
-// Kernel outputs are always canonical residues in [0, q), so both give bit-identical
-// transforms.
+// Arithmetic of the GENERIC kernels (merge_kernels.hpp): the reference's {value, bit, mu}
+// Barrett contract (reference src/include/gpuntt/common/modular_arith.cuh:312-339), which needs
+// nothing but the caller's Modulus<T> and the caller's plain twiddle table.  The fast kernels use
+// the precomputed-quotient arithmetic of lazy.hpp instead; both produce canonical residues in
+// [0, q), hence bit-identical transforms.
 #pragma once
 
 #include <hip/hip_runtime.h>

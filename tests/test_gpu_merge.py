@@ -456,3 +456,51 @@ def test_large_rings(g, bits, logn):
     n = c.n
     assert np.array_equal(y[n:], c.P.merge_ntt(x[n:], c.oprm))
     assert np.array_equal(c.gpu_inverse(y, inplace=True), x)
+
+
+def test_hip_graph_capture_and_replay(g):
+    """A whole GPU_NTT + GPU_INTT pair (prep kernel + tile passes) captured into a hipGraph on a
+    side stream and replayed; the twiddle workspace of that stream is created by one eager call
+    first (the only allocation the library ever makes)."""
+    import torch
+    c = MergeCase(g, 64, 14, O.X_N_plus)
+    batch = 16
+    x = c.random(batch, 4321)
+    s = torch.cuda.Stream()
+    d = g.to_device(x)
+    o = torch.zeros_like(d)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s):
+        g.GPU_NTT(d, o, c.fwd_dev, c.prm.modulus, c.cfg(stream=s), batch)  # warms the workspace
+    s.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=s):
+        cs = torch.cuda.current_stream()
+        g.GPU_NTT(d, o, c.fwd_dev, c.prm.modulus, c.cfg(stream=cs), batch)
+        g.GPU_INTT_Inplace(o, c.inv_dev, c.prm.modulus, c.cfg(True, stream=cs), batch)
+    o.zero_()
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(g.to_host(o), x)
+
+
+def test_two_streams_concurrently(g):
+    """Independent calls on two streams (each with its own twiddle workspace) interleaved from one
+    host thread, different rings and moduli."""
+    import torch
+    ca, cb = MergeCase(g, 64, 16, O.X_N_minus), MergeCase(g, 32, 15, O.X_N_plus)
+    xa, xb = ca.random(32, 1), cb.random(64, 2)
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    da, db = g.to_device(xa), g.to_device(xb)
+    torch.cuda.synchronize()
+    for _ in range(4):
+        g.GPU_NTT_Inplace(da, ca.fwd_dev, ca.prm.modulus, ca.cfg(stream=sa), 32)
+        g.GPU_NTT_Inplace(db, cb.fwd_dev, cb.prm.modulus, cb.cfg(stream=sb), 64)
+        g.GPU_INTT_Inplace(da, ca.inv_dev, ca.prm.modulus, ca.cfg(True, stream=sa), 32)
+        g.GPU_INTT_Inplace(db, cb.inv_dev, cb.prm.modulus, cb.cfg(True, stream=sb), 64)
+    g.GPU_NTT_Inplace(da, ca.fwd_dev, ca.prm.modulus, ca.cfg(stream=sa), 32)
+    g.GPU_NTT_Inplace(db, cb.fwd_dev, cb.prm.modulus, cb.cfg(stream=sb), 64)
+    torch.cuda.synchronize()
+    assert np.array_equal(g.to_host(da), ca.P.merge_ntt(xa, ca.oprm))
+    assert np.array_equal(g.to_host(db), cb.P.merge_ntt(xb, cb.oprm))

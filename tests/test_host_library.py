@@ -91,6 +91,13 @@ def test_argument_errors_without_gpu(g):
     assert lib.gpuntt_ntt_u64(None, None, None, m, 12, 9, 1, 0, None, 1) == -1
     assert lib.gpuntt_last_error() == b"Invalid ntt_layout!"
     assert lib.gpuntt_ntt_rns_u64(None, None, None, None, 12, 0, 1, 0, None, 1, 0) == -1
+    # ordered entry points: n_power in [10, 28] (reference ntt.cu:3607-3610, 4288-4291)
+    dummy = ctypes.c_void_p(8)
+    for fn in (lib.gpuntt_ntt_modulus_ordered_u64, lib.gpuntt_ntt_poly_ordered_u64,
+               lib.gpuntt_ntt_modulus_ordered_u32, lib.gpuntt_ntt_poly_ordered_u32):
+        for bad in (9, 29):
+            assert fn(None, None, None, dummy, bad, 0, 1, None, None, 1, 1, dummy) == -1
+            assert lib.gpuntt_last_error() == b"Invalid n_power range!"
     # PerCoefficient range check (reference ntt.cu:2230-2233)
     assert lib.gpuntt_ntt_u64(None, None, None, m, 10, 1, 1, 0, None, 1) == -1
     assert lib.gpuntt_last_error() == b"Invalid n_power range!"
