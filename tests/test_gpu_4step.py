@@ -18,6 +18,8 @@ pytestmark = pytest.mark.gpu
 def g(pkg):
     import torch
     assert torch.cuda.is_available()
+    if not os.path.exists(pkg.LIB_PATH):  # fresh checkout: hipcc is part of the image
+        pkg.build_library()
     pkg.load_library()
     return pkg
 
