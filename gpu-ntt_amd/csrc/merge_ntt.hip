@@ -94,7 +94,12 @@ namespace gpuntt
                 return false;
             if (forced_path() == 2)
                 return true;
-            // the per-call twiddle preparation touches N entries: not worth it for tiny jobs
+            // Single modulus: measured at batch = 1 (profiles/batch1_r01.txt) the prepared-twiddle
+            // kernels win from 2^5 (64-bit) / 2^11 (32-bit) upwards even though they cost one
+            // extra launch; below that one generic launch is the whole job.
+            if (mod_count == 1 && n_power >= (sizeof(TU) == 8 ? 5 : 11))
+                return true;
+            // RNS stacks pay for the dual launch: not worth it for tiny jobs
             return (static_cast<unsigned long long>(batch_size) << n_power) >= (1ull << 15) &&
                    batch_size >= 2;
         }

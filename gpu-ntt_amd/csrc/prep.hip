@@ -5,9 +5,11 @@
 // stream, the table the fast kernels read: Shoup pairs {w, floor(w * 2^64 / q)} laid out by
 // stage (stage with m = 2^S groups occupies slots [2^S, 2^(S+1)) for both reduction
 // polynomials), with the distance-1/2/4 stages permuted to [tile][k][thread] so the last
-// contiguous round loads them fully coalesced.  Cost: N-1 64-step divisions per modulus,
-// ~1 us of chip time at N = 2^16 -- nothing is cached between calls, so a caller that
-// rewrites its table in place is always honoured.
+// contiguous round loads them fully coalesced.  The quotients come from one multiplication by
+// the modulus' normalised reciprocal plus a two-step correction (~40 instructions per entry; the
+// reciprocal itself is a host division for a single modulus, one restoring division per block for
+// an RNS stack).  Nothing is cached between calls, so a caller that rewrites its table in place
+// is always honoured.
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -33,11 +35,46 @@ namespace gpuntt
             return quo;
         }
 
+        // Normalised reciprocal R = floor(2^(W-1+b) / q), b = bit length of q: in [2^(W-1), 2^W) for
+        // every q that is not a power of two.  0 = "none" (power of two / q < 3): callers then
+        // fall back to the restoring division.
+        template <typename T> __device__ __forceinline__ T recip_norm(T q)
+        {
+            if (q < 3 || (q & (q - 1)) == 0)
+                return 0;
+            constexpr int W = static_cast<int>(8 * sizeof(T));
+            const int b = W - ((W == 64) ? __clzll(static_cast<long long>(q)) : __clz(static_cast<int>(q)));
+            return shoup_quotient<T>(static_cast<T>(1) << (b - 1), q);
+        }
+
+        // floor(w * 2^W / q) for w < q < 2^(W-2) from R = recip_norm(q):
+        //   est = (w * R) >> (b-1) lies in {Q-2, Q-1, Q}  (R > 2^(W-1+b)/q - 1 and w < 2^b),
+        //   and the remainder w*2^W - est*q < 3q < 2^W is exact in W bits, so two conditional
+        //   subtractions finish it.
+        template <typename T> __device__ __forceinline__ T shoup_quotient_r(T w, T q, T rinv)
+        {
+            if (rinv == 0)
+                return shoup_quotient<T>(w, q);
+            constexpr int W = static_cast<int>(8 * sizeof(T));
+            const int sh = W - 1 - ((W == 64) ? __clzll(static_cast<long long>(q)) : __clz(static_cast<int>(q)));
+            const T hi = dev::mulhi(w, rinv), lo = w * rinv;
+            T quo = (lo >> sh) | (hi << (W - sh)); // 1 <= sh <= W-3
+            T rem = static_cast<T>(0) - quo * q;
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+            {
+                const bool ge = rem >= q;
+                rem = ge ? rem - q : rem;
+                quo += ge ? 1u : 0u;
+            }
+            return quo;
+        }
+
         template <typename T>
         __global__ __launch_bounds__(256) void prep_twiddles(const T* __restrict__ roots,
                                                              lazy::Tw<T>* __restrict__ ws,
                                                              const Modulus<T>* __restrict__ mods, T q_single,
-                                                             int mod_count, int n, int negacyclic,
+                                                             T rinv_single, int mod_count, int n, int negacyclic,
                                                              int perm_tile_log,
                                                              const T* __restrict__ ninv_arr,
                                                              lazy::Tw<T>* __restrict__ ws_ninv,
@@ -61,6 +98,19 @@ namespace gpuntt
                 *go_flag = ok;
             }
             const unsigned long long per_mod = 1ull << n;
+            // RNS stacks: the reciprocal of the block's modulus is derived once per block (a block
+            // never straddles two moduli when n >= 8; below that every thread derives its own)
+            __shared__ T s_rinv;
+            const bool block_recip = (mods != nullptr) && n >= 8;
+            if (block_recip)
+            {
+                if (threadIdx.x == 0)
+                {
+                    const int bm = static_cast<int>((blockIdx.x * 256ull) >> n);
+                    s_rinv = recip_norm<T>(mods[mod_order != nullptr ? mod_order[bm] : bm].value);
+                }
+                __syncthreads();
+            }
             if (gid >= per_mod * mod_count)
                 return;
             const int mi = static_cast<int>(gid >> n);
@@ -69,12 +119,13 @@ namespace gpuntt
             const int prime = (mod_order != nullptr) ? mod_order[mi] : mi;
             const unsigned slot = static_cast<unsigned>(gid & (per_mod - 1));
             const T q = (mods != nullptr) ? mods[prime].value : q_single;
+            const T rinv = (mods == nullptr) ? rinv_single : (block_recip ? s_rinv : recip_norm<T>(q));
             if (slot == 0)
             {
                 if (ninv_arr != nullptr && ws_ninv != nullptr)
                 {
                     const T v = ninv_arr[prime];
-                    ws_ninv[mi] = lazy::Tw<T>{v, shoup_quotient<T>(v, q)};
+                    ws_ninv[mi] = lazy::Tw<T>{v, shoup_quotient_r<T>(v, q, rinv)};
                 }
                 ws[gid] = lazy::Tw<T>{0, 0};
                 return;
@@ -93,19 +144,19 @@ namespace gpuntt
             }
             const unsigned src = negacyclic ? ((1u << S) + i) : i;
             const T w = roots[(static_cast<unsigned long long>(prime) << n) + src];
-            ws[gid] = lazy::Tw<T>{w, shoup_quotient<T>(w, q)};
+            ws[gid] = lazy::Tw<T>{w, shoup_quotient_r<T>(w, q, rinv)};
         }
 
         // plain residues -> Shoup pairs, same order (4-step W matrix)
         template <typename T>
         __global__ __launch_bounds__(256) void prep_pairs(const T* __restrict__ src, lazy::Tw<T>* __restrict__ dst,
-                                                          unsigned long long count, T q)
+                                                          unsigned long long count, T q, T rinv)
         {
             const unsigned long long gid = blockIdx.x * 256ull + threadIdx.x;
             if (gid >= count)
                 return;
             const T w = src[gid];
-            dst[gid] = lazy::Tw<T>{w, shoup_quotient<T>(w, q)};
+            dst[gid] = lazy::Tw<T>{w, shoup_quotient_r<T>(w, q, rinv)};
         }
     } // namespace kern
 
@@ -121,6 +172,18 @@ namespace gpuntt
             std::mutex g_ws_mutex;
             std::map<std::pair<int, hipStream_t>, Slot> g_ws;
         } // namespace
+
+        // host twin of kern::recip_norm
+        template <typename T> static T recip_norm_host(T q)
+        {
+            if (q < 3 || (q & (q - 1)) == 0)
+                return 0;
+            constexpr int W = static_cast<int>(8 * sizeof(T));
+            int b = 0;
+            while (b < W && (static_cast<unsigned long long>(q) >> b) != 0)
+                b++;
+            return static_cast<T>((static_cast<unsigned __int128>(1) << (W - 1 + b)) / q);
+        }
 
         int lazy_contig_k(int n)
         {
@@ -168,14 +231,15 @@ namespace gpuntt
             const unsigned long long entries = static_cast<unsigned long long>(mod_count) << n;
             const unsigned grid = static_cast<unsigned>((entries + 255) / 256);
             hipLaunchKernelGGL((kern::prep_twiddles<T>), dim3(grid), dim3(256), 0, stream, roots, ws, mods, q,
-                               mod_count, n, negacyclic ? 1 : 0, perm_tile_log, ninv_arr, ws_ninv, go_flag, norm_arr, mod_order);
+                               (mods == nullptr) ? recip_norm_host<T>(q) : static_cast<T>(0), mod_count, n, negacyclic ? 1 : 0, perm_tile_log, ninv_arr, ws_ninv, go_flag, norm_arr, mod_order);
             GPUNTT_HIP_CHECK(hipGetLastError());
         }
         template <typename T>
         void launch_prep_pairs(const T* src, lazy::Tw<T>* dst, unsigned long long count, T q, hipStream_t stream)
         {
             const unsigned grid = static_cast<unsigned>((count + 255) / 256);
-            hipLaunchKernelGGL((kern::prep_pairs<T>), dim3(grid), dim3(256), 0, stream, src, dst, count, q);
+            hipLaunchKernelGGL((kern::prep_pairs<T>), dim3(grid), dim3(256), 0, stream, src, dst, count, q,
+                               recip_norm_host<T>(q));
             GPUNTT_HIP_CHECK(hipGetLastError());
         }
         template void launch_prep_pairs<uint64_t>(const uint64_t*, lazy::Tw64*, unsigned long long, uint64_t,

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Latency of single-polynomial transforms (the reference's own benchmark axis: batch = 1,
+logN 12..24, benchmark/bench_merge_ntt.cu:57-75).  Run once per kernel family:
+    GPUNTT_PATH=generic python tools/bench_batch1.py ; GPUNTT_PATH=fast python tools/bench_batch1.py"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from bench_configs import time_ms  # noqa: E402
+from __graft_entry__ import _load_pkg  # noqa: E402
+import numpy as np  # noqa: E402
+
+g = _load_pkg()
+g.load_library()
+import torch  # noqa: E402
+
+for bits in (64, 32):
+    for logn in range(int(os.environ.get('LOGN_MIN', '12')), 25):
+        prm = g.NTTParameters(logn, g.X_N_minus, bits)
+        n = 1 << logn
+        x = (np.arange(n, dtype=np.uint64) * 2654435761 % prm.modulus.value).astype(g.np_dtype(bits))
+        d = g.to_device(x)
+        tab = g.to_device(prm.forward_table_device_order)
+        cfg = g.ntt_configuration(n_power=logn, reduction_poly=g.X_N_minus)
+        fn = lambda: g.GPU_NTT_Inplace(d, tab, prm.modulus, cfg, 1)  # noqa: E731
+        ms = time_ms(fn, 200 if logn < 20 else 50, warm=10)
+        print(json.dumps({"path": os.environ.get("GPUNTT_PATH", "auto"), "dtype": "u%d" % bits, "log2N": logn,
+                          "batch": 1, "us": round(ms * 1e3, 2)}), flush=True)
