@@ -14,11 +14,23 @@ namespace gpuntt
         constexpr int LAZY_MAX_N_POWER = 24; // prepared table = 2 words * N per modulus
 
         // tile size (log2) used by the fast kernels for element type T and ring size 2^n:
-        // 64-bit: 4096 coefficients (32 KiB of LDS); 32-bit: 16384 coefficients (64 KiB) once the
-        // ring no longer fits a 4096 tile, so rings up to 2^14 are a single HBM sweep
-        template <typename T> constexpr int lazy_tile_log(int n)
+        // 64-bit: 4096 coefficients (32 KiB of LDS).  32-bit: 16384 coefficients (64 KiB) for rings
+        // of 2^13 and 2^14, which makes them a single HBM sweep.  Larger 32-bit rings take the tile
+        // that needs fewer sweeps (2^20..2^22: 16384) and, at equal sweep count, the 4096 tile, whose
+        // kernels are 10-20 % faster per stage (4 blocks per CU, strided pass carrying up to 8
+        // stages): measured in profiles/u32_tile_ab_r01.txt.  GPUNTT_U32_TILE=12|14 overrides the
+        // choice above 2^14 (A/B timing).
+        int lazy_u32_tile_override();
+        template <typename T> inline int lazy_tile_log(int n)
         {
-            return (sizeof(T) == 4 && n > 12) ? 14 : 12;
+            if (sizeof(T) != 4 || n <= 12)
+                return 12;
+            if (n <= 14)
+                return 14;
+            const int forced = lazy_u32_tile_override();
+            if (forced != 0)
+                return forced;
+            return (n >= 20 && n <= 22) ? 14 : 12;
         }
 
         // per-(device, stream) scratch for prepared twiddles; grows on demand, stream-ordered reuse

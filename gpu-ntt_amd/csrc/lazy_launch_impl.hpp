@@ -67,7 +67,7 @@ namespace gpuntt
                 {
                     if constexpr (!INV)
                     {
-                        if constexpr (TLOG == 12 && sizeof(T) == 8)
+                        if constexpr (TLOG == 12)
                             switch (p.k)
                             {
                                 case 8: GPUNTT_ONE(true, 8, LIM, true);
@@ -86,7 +86,7 @@ namespace gpuntt
                 {
                     if constexpr (INV)
                     {
-                        if constexpr (TLOG == 12 && sizeof(T) == 8)
+                        if constexpr (TLOG == 12)
                             switch (p.k)
                             {
                                 case 8: GPUNTT_ONE(true, 8, 1, false);
@@ -104,7 +104,7 @@ namespace gpuntt
                 throw std::invalid_argument("internal: unsupported contiguous pass in the fast path");
             }
             // strided passes exist only for rings larger than the tile
-            if constexpr ((TLOG == 12 && sizeof(T) == 8) || TLOG == 14)
+            if constexpr (TLOG == 12 || TLOG == 14)
             {
                 if constexpr (!INV)
                 {

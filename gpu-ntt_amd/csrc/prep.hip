@@ -201,6 +201,16 @@ namespace gpuntt
             return 12;
         }
 
+        int lazy_u32_tile_override()
+        {
+            static const int forced = [] {
+                const char* e = std::getenv("GPUNTT_U32_TILE");
+                const int v = e ? std::atoi(e) : 0;
+                return (v == 12 || v == 14) ? v : 0;
+            }();
+            return forced;
+        }
+
         void* lazy_workspace(hipStream_t stream, size_t bytes)
         {
             int dev = 0;

@@ -149,6 +149,12 @@ def main():
         merge_case(g, 32, 14, 1024, g.X_N_minus, args.iters, "C4 Merge u32 2^14 x1024 (per-GPU shard of 8192)")
         merge_case(g, 32, 14, 8192, g.X_N_minus, args.iters, "C4full Merge u32 2^14 x8192 (whole batch on one GPU)")
         rns_case(g, 16, 512, args.iters, "C5 RNS Merge u64 2^16 x512, 8 primes, X^N+1", golden)
+    if args.what in ("sweep32", "sweep64"):
+        bits = int(args.what[-2:])
+        for logn in range(12, 25):
+            batch = max(1, 1 << (26 - logn))
+            merge_case(g, bits, logn, batch, g.X_N_minus, max(3, args.iters // 2), "sweep-merge")
+            merge_case(g, bits, logn, batch, g.X_N_minus, max(3, args.iters // 2), "sweep-merge-inv", inverse=True)
     if args.what in ("sweep", "all"):
         for bits in (64, 32):
             for logn in range(12, 25):
