@@ -147,7 +147,8 @@ namespace gpuntt
             host::launch_prep_pairs<T>(w_table, ws_w, n, mod.value, stream);
             const int tl2 = host::lazy_tile_log<T>(log_n2);
             host::launch_prep<T>(n2_table, ws_n2, nullptr, mod.value, 1, log_n2, false,
-                                 (log_n2 >= tl2) ? tl2 : 0, nullptr, nullptr, nullptr, nullptr, stream);
+                                 (log_n2 >= tl2) ? tl2 : 0, nullptr, nullptr, nullptr, nullptr, stream, nullptr,
+                                 INV ? &ninv : nullptr); // inverse: n^-1 rides on the last row stage
 
             kern::LazyArgsT<T> a{};
             a.in = in;

@@ -38,18 +38,23 @@ namespace gpuntt
 
         // fills ws[0 .. mod_count*N) with Shoup pairs of the caller's table (device order) and
         // ws_ninv[0 .. mod_count) with the pairs of n^-1 (RNS only); perm_tile_log > 0 permutes
-        // the distance-1/2/4 stages for tiles of that size
+        // the distance-1/2/4 stages for tiles of that size.  Inverse transforms fold n^-1 into the
+        // twiddle of their final stage: fold_ninv_single points at the host value (single
+        // modulus), fold_ninv_rns takes it from ninv_arr.
         template <typename T>
         void launch_prep(const T* roots, lazy::Tw<T>* ws, const Modulus<T>* mods, T q, int mod_count, int n,
                          bool negacyclic, int perm_tile_log, const T* ninv_arr, lazy::Tw<T>* ws_ninv,
                          unsigned* go_flag, lazy::NormConst* norm_arr, hipStream_t stream,
-                         const int* mod_order = nullptr);
+                         const int* mod_order = nullptr, const T* fold_ninv_single = nullptr,
+                         bool fold_ninv_rns = false);
         extern template void launch_prep<uint64_t>(const uint64_t*, lazy::Tw64*, const Modulus<uint64_t>*,
                                                    uint64_t, int, int, bool, int, const uint64_t*,
-                                                   lazy::Tw64*, unsigned*, lazy::NormConst*, hipStream_t, const int*);
+                                                   lazy::Tw64*, unsigned*, lazy::NormConst*, hipStream_t, const int*,
+                                                   const uint64_t*, bool);
         extern template void launch_prep<uint32_t>(const uint32_t*, lazy::Tw32*, const Modulus<uint32_t>*,
                                                    uint32_t, int, int, bool, int, const uint32_t*,
-                                                   lazy::Tw32*, unsigned*, lazy::NormConst*, hipStream_t, const int*);
+                                                   lazy::Tw32*, unsigned*, lazy::NormConst*, hipStream_t, const int*,
+                                                   const uint32_t*, bool);
 
         template <typename T>
         void launch_prep_pairs(const T* src, lazy::Tw<T>* dst, unsigned long long count, T q, hipStream_t stream);

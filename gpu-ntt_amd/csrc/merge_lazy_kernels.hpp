@@ -489,7 +489,12 @@ namespace gpuntt
                                 U = m.template csub<ku>(U);
                             if constexpr (kv != 0)
                                 V = m.template csub<kv>(V);
-                            v[j0] = U + V;
+                            // final stage of an inverse transform: its twiddle was prepared as
+                            // w * n^-1, so scaling the sum as well finishes the n^-1 product
+                            if constexpr (LAST && r == G::NR - 1 && s == STAGES - 1)
+                                v[j0] = m.mul(U + V, ninv);
+                            else
+                                v[j0] = U + V;
                             v[j1] = m.mul(U + m.kq(c) - V, tw);
                         }
                     });
@@ -509,7 +514,7 @@ namespace gpuntt
                                 if constexpr (EXACT)
                                     x = em.mul(v[j], ninv.w);
                                 else
-                                    x = lazy::normalize<M::TB>(m, m.mul(v[j], ninv)); // * n^-1
+                                    x = lazy::normalize<M::TB>(m, v[j]); // n^-1 went in with the last stage
                                 if (a.flags & F_CENTERED)
                                     x = (x > (m.q >> 1)) ? (x - m.q) : x;
                                 v[j] = x;

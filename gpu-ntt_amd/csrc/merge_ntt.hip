@@ -110,7 +110,8 @@ namespace gpuntt
         inline kern::LazyArgsT<TU> lazy_args(const void* in, TU* out, const TU* roots, const Modulus<TU>& m,
                                             const Modulus<TU>* mods, int mod_count, const TU* ninv_dev,
                                             int n_power, ReductionPolynomial poly, int batch_size,
-                                            hipStream_t stream, const int* mod_order = nullptr)
+                                            hipStream_t stream, const int* mod_order = nullptr,
+                                            const TU* ninv_single = nullptr)
         {
             using TW = lazy::Tw<TU>;
             const bool neg = (poly == ReductionPolynomial::X_N_plus);
@@ -125,7 +126,8 @@ namespace gpuntt
             unsigned* go_flag = mods ? reinterpret_cast<unsigned*>(tail_p) : nullptr;
             auto* norm_arr = mods ? reinterpret_cast<lazy::NormConst*>(tail_p + 16) : nullptr;
             host::launch_prep<TU>(roots, ws, mods, m.value, mod_count, n_power, neg, perm_tile_log, ninv_dev,
-                                  ninv_dev ? ws_ninv : nullptr, go_flag, norm_arr, stream, mod_order);
+                                  ninv_dev ? ws_ninv : nullptr, go_flag, norm_arr, stream, mod_order, ninv_single,
+                                  ninv_dev != nullptr);
             kern::LazyArgsT<TU> a{};
             a.in = in;
             a.out = out;
@@ -277,7 +279,8 @@ namespace gpuntt
         {
             kern::LazyArgsT<TU> la =
                 lazy_args<TU>(device_in, reinterpret_cast<TU*>(device_out), root_of_unity_table, modulus,
-                              nullptr, 1, nullptr, cfg.n_power, cfg.reduction_poly, batch_size, cfg.stream);
+                              nullptr, 1, nullptr, cfg.n_power, cfg.reduction_poly, batch_size, cfg.stream,
+                              nullptr, &cfg.mod_inverse);
             la.ninv = lazy::Tw<TU>{cfg.mod_inverse, host::shoup_host(cfg.mod_inverse, modulus.value)};
             host::run_transform_lazy<TU, true>(la, 0u, out_flags, cfg.stream);
             return;

@@ -70,6 +70,18 @@ namespace gpuntt
             return quo;
         }
 
+        // a * b mod q for a, b < q < 2^(W-1), through the Shoup pair of b
+        template <typename T> __device__ __forceinline__ T mulmod_r(T a, T b, T q, T rinv)
+        {
+            const T bp = shoup_quotient_r<T>(b, q, rinv);
+            const T r = a * b - dev::mulhi(a, bp) * q; // [0, 2q)
+            return (r >= q) ? (r - q) : r;
+        }
+
+        // fold_ninv (inverse transforms): the single twiddle of the final Gentleman-Sande stage
+        // (slot 1) is stored pre-multiplied by n^-1, so that stage scales both outputs itself --
+        // U' = (U + V) * n^-1, V' = (U - V) * (w * n^-1) -- instead of a separate n^-1 product on
+        // every coefficient afterwards.
         template <typename T>
         __global__ __launch_bounds__(256) void prep_twiddles(const T* __restrict__ roots,
                                                              lazy::Tw<T>* __restrict__ ws,
@@ -80,7 +92,8 @@ namespace gpuntt
                                                              lazy::Tw<T>* __restrict__ ws_ninv,
                                                              unsigned* __restrict__ go_flag,
                                                              lazy::NormConst* __restrict__ norm_arr,
-                                                             const int* __restrict__ mod_order)
+                                                             const int* __restrict__ mod_order,
+                                                             T ninv_single, int fold_ninv)
         {
             const unsigned long long gid = blockIdx.x * 256ull + threadIdx.x;
             if (gid == 0 && go_flag != nullptr)
@@ -143,7 +156,9 @@ namespace gpuntt
                 i = tile * (rp * nt) + t * rp + kk;
             }
             const unsigned src = negacyclic ? ((1u << S) + i) : i;
-            const T w = roots[(static_cast<unsigned long long>(prime) << n) + src];
+            T w = roots[(static_cast<unsigned long long>(prime) << n) + src];
+            if (fold_ninv && slot == 1)
+                w = mulmod_r<T>(w, (ninv_arr != nullptr) ? ninv_arr[prime] : ninv_single, q, rinv);
             ws[gid] = lazy::Tw<T>{w, shoup_quotient_r<T>(w, q, rinv)};
         }
 
@@ -236,12 +251,15 @@ namespace gpuntt
         template <typename T>
         void launch_prep(const T* roots, lazy::Tw<T>* ws, const Modulus<T>* mods, T q, int mod_count, int n,
                          bool negacyclic, int perm_tile_log, const T* ninv_arr, lazy::Tw<T>* ws_ninv,
-                         unsigned* go_flag, lazy::NormConst* norm_arr, hipStream_t stream, const int* mod_order)
+                         unsigned* go_flag, lazy::NormConst* norm_arr, hipStream_t stream, const int* mod_order,
+                         const T* fold_ninv_single, bool fold_ninv_rns)
         {
             const unsigned long long entries = static_cast<unsigned long long>(mod_count) << n;
             const unsigned grid = static_cast<unsigned>((entries + 255) / 256);
             hipLaunchKernelGGL((kern::prep_twiddles<T>), dim3(grid), dim3(256), 0, stream, roots, ws, mods, q,
-                               (mods == nullptr) ? recip_norm_host<T>(q) : static_cast<T>(0), mod_count, n, negacyclic ? 1 : 0, perm_tile_log, ninv_arr, ws_ninv, go_flag, norm_arr, mod_order);
+                               (mods == nullptr) ? recip_norm_host<T>(q) : static_cast<T>(0), mod_count, n, negacyclic ? 1 : 0, perm_tile_log, ninv_arr, ws_ninv, go_flag, norm_arr, mod_order,
+                               fold_ninv_single ? *fold_ninv_single : static_cast<T>(0),
+                               (fold_ninv_single != nullptr || (fold_ninv_rns && ninv_arr != nullptr)) ? 1 : 0);
             GPUNTT_HIP_CHECK(hipGetLastError());
         }
         template <typename T>
@@ -258,8 +276,10 @@ namespace gpuntt
                                                   hipStream_t);
 
         template void launch_prep<uint64_t>(const uint64_t*, lazy::Tw64*, const Modulus<uint64_t>*, uint64_t, int,
-                                            int, bool, int, const uint64_t*, lazy::Tw64*, unsigned*, lazy::NormConst*, hipStream_t, const int*);
+                                            int, bool, int, const uint64_t*, lazy::Tw64*, unsigned*, lazy::NormConst*, hipStream_t, const int*,
+                                            const uint64_t*, bool);
         template void launch_prep<uint32_t>(const uint32_t*, lazy::Tw32*, const Modulus<uint32_t>*, uint32_t, int,
-                                            int, bool, int, const uint32_t*, lazy::Tw32*, unsigned*, lazy::NormConst*, hipStream_t, const int*);
+                                            int, bool, int, const uint32_t*, lazy::Tw32*, unsigned*, lazy::NormConst*, hipStream_t, const int*,
+                                            const uint32_t*, bool);
     } // namespace host
 } // namespace gpuntt

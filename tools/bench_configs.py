@@ -23,10 +23,21 @@ PEAK = 8000.0
 
 
 def time_ms(fn, iters, warm=3):
+    """Average ms per call.  Warm-up runs for at least `warm` calls AND ~60 ms so the clocks have
+    settled (a 10 ms measurement straight after an idle period reads 15 % slow); the timed loop
+    runs at least `iters` calls and ~120 ms."""
+    import time
     import torch
-    for _ in range(warm):
+    t0 = time.perf_counter()
+    k = 0
+    while k < warm or time.perf_counter() - t0 < 0.06:
         fn()
+        k += 1
+        if k % 8 == 0:
+            torch.cuda.synchronize()
     torch.cuda.synchronize()
+    per = max((time.perf_counter() - t0) / max(k, 1), 1e-6)
+    iters = max(iters, min(2000, int(0.12 / per)))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
