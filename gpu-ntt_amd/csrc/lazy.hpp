@@ -98,7 +98,11 @@ namespace gpuntt
             {
                 const uint32_t x0 = lo32(x), x1 = hi32(x);
                 const uint32_t h1 = __umulhi(x1, lo32(t.wp)), h2 = __umulhi(x0, hi32(t.wp));
-                const uint64_t qh = static_cast<uint64_t>(x1) * hi32(t.wp) + h1 + h2;
+                uint64_t qh = static_cast<uint64_t>(x1) * hi32(t.wp) + h1;
+                // + h2 as a multiply-add by 1: adding a 32-bit value to a 64-bit one otherwise
+                // costs a zero-extending move plus a 64-bit add
+                uint64_t carry;
+                asm("v_mad_u64_u32 %0, %1, %2, 1, %3" : "=v"(qh), "=s"(carry) : "v"(h2), "v"(qh));
                 return x * t.w + qh * qneg;
             }
 
