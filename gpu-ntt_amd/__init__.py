@@ -85,7 +85,8 @@ def load_library():
 EXPORTED_SYMBOLS = ["gpuntt_last_error", "gpuntt_version"] + [
     "gpuntt_%s_%s" % (f, s)
     for f in ("modulus", "ntt", "intt", "ntt_rns", "intt_rns", "ntt_modulus_ordered",
-              "ntt_poly_ordered", "4step", "4step_rns", "transpose", "merge_params", "4step_params")
+              "ntt_poly_ordered", "4step", "4step_rns", "4step_natural", "transpose", "merge_params",
+              "4step_params")
     for s in ("u32", "u64")]
 
 
@@ -377,6 +378,21 @@ def GPU_4STEP_NTT(device_in, device_out, n1_root_of_unity_table, n2_root_of_unit
                   _ptr(n2_root_of_unity_table), _ptr(W_root_of_unity_table), _ptr(modulus),
                   cfg.n_power, cfg.ntt_type, _ptr(cfg.mod_inverse), _stream(cfg.stream),
                   batch_size, int(mod_count)))
+
+
+def GPU_4STEP_NTT_NaturalOrder(device_in, device_out, n1_root_of_unity_table, n2_root_of_unity_table,
+                               W_root_of_unity_table, modulus, cfg, batch_size):
+    """Extension: natural-order input -> NTT_4STEP_CPU::ntt / ::intt order in one call (what the
+    reference's examples do with GPU_Transpose -> GPU_4STEP_NTT -> GPU_Transpose).  device_in is
+    overwritten; device_in is not device_out."""
+    lib = load_library()
+    _require_gpu(device_in, device_out, n1_root_of_unity_table, n2_root_of_unity_table,
+                 W_root_of_unity_table)
+    bits = device_in.element_size() * 8
+    fn = getattr(lib, "gpuntt_4step_natural_u%d" % bits)
+    _check(fn(_ptr(device_in), _ptr(device_out), _ptr(n1_root_of_unity_table),
+              _ptr(n2_root_of_unity_table), _ptr(W_root_of_unity_table), modulus.c(), cfg.n_power,
+              cfg.ntt_type, _ct(bits)(cfg.mod_inverse), _stream(cfg.stream), batch_size))
 
 
 # ------------------------------------------------------------------ multi-GPU batch shard

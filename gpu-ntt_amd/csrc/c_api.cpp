@@ -152,6 +152,18 @@ namespace
     }
 
     template <typename T, typename CM>
+    int fourstep_natural(T* in, T* out, const T* t1, const T* t2, const T* w, CM modulus, int n_power,
+                         int ntt_type, T mod_inverse, void* stream, int batch)
+    {
+        return guarded([&] {
+            ntt4step_configuration<T> cfg = {n_power, static_cast<type>(ntt_type), mod_inverse,
+                                             static_cast<hipStream_t>(stream)};
+            GPU_4STEP_NTT_NaturalOrder<T>(in, out, const_cast<T*>(t1), const_cast<T*>(t2), const_cast<T*>(w),
+                                          to_mod<T>(modulus), cfg, batch);
+        });
+    }
+
+    template <typename T, typename CM>
     int fourstep_rns(const T* in, T* out, const T* t1, const T* t2, const T* w, const CM* modulus,
                      int n_power, int ntt_type, const T* mod_inverse, void* stream, int batch,
                      int mod_count)
@@ -344,6 +356,13 @@ extern "C"
     {                                                                                             \
         return fourstep_single<T>(in, out, n1_table, n2_table, w_table, modulus, n_power,         \
                                   ntt_type, mod_inverse, stream, batch_size);                     \
+    }                                                                                             \
+    int gpuntt_4step_natural_##S(T* in_scratch, T* out, const T* n1_table, const T* n2_table,      \
+                                 const T* w_table, CM modulus, int n_power, int ntt_type,          \
+                                 T mod_inverse, void* stream, int batch_size)                      \
+    {                                                                                             \
+        return fourstep_natural<T>(in_scratch, out, n1_table, n2_table, w_table, modulus, n_power, \
+                                   ntt_type, mod_inverse, stream, batch_size);                    \
     }                                                                                             \
     int gpuntt_4step_rns_##S(const T* in, T* out, const T* n1_table, const T* n2_table,           \
                              const T* w_table, const CM* modulus, int n_power, int ntt_type,      \

@@ -51,16 +51,25 @@ namespace gpuntt
         }
     } // namespace kern
 
+    namespace
+    {
+        template <typename T>
+        void transpose_on(T* in, T* out, int row, int col, int n_power, int batch_size, hipStream_t stream)
+        {
+            if (batch_size <= 0 || row <= 0 || col <= 0)
+                return;
+            const dim3 grid((col + 31) / 32, (row + 31) / 32, batch_size);
+            hipLaunchKernelGGL((kern::transpose_batch<T>), grid, dim3(256), 0, stream, in, out, row, col,
+                               1ull << n_power);
+            GPUNTT_HIP_CHECK(hipGetLastError());
+        }
+    } // namespace
+
     template <typename T>
     __host__ void GPU_Transpose(T* polynomial_in, T* polynomial_out, const int row, const int col,
                                 const int n_power, const int batch_size)
     {
-        if (batch_size <= 0 || row <= 0 || col <= 0)
-            return;
-        const dim3 grid((col + 31) / 32, (row + 31) / 32, batch_size);
-        hipLaunchKernelGGL((kern::transpose_batch<T>), grid, dim3(256), 0, 0, polynomial_in,
-                           polynomial_out, row, col, 1ull << n_power);
-        GPUNTT_HIP_CHECK(hipGetLastError());
+        transpose_on<T>(polynomial_in, polynomial_out, row, col, n_power, batch_size, 0);
     }
 
     namespace
@@ -187,6 +196,84 @@ namespace gpuntt
             return true;
         }
 
+        // Natural-order forward transform in three sweeps (no transposes):
+        //   1. STRIDED pass over the top log2(n1) bits of the row-major n1 x n2 input = the n1-point
+        //      column transforms, in place, W product on the way out (canonical);
+        //   2. n2 > 512: STRIDED pass over row bits [8, log2 n2) in place (lazy);
+        //   3. CONTIG stages on 2^K-column runs of 2^(12-K) consecutive rows, stored transposed into
+        //      `out` (canonical) -- out[(c)*n1 + r] = row r, column c, the order of NTT_4STEP_CPU::ntt.
+        // `in` is overwritten (the reference's own three-call sequence ping-pongs through it too).
+        template <typename T>
+        bool fourstep_natural_forward_lazy(T* in, T* out, const T* n1_table, const T* n2_table,
+                                           const T* w_table, const Modulus<T>& mod, int n_power, int log_n1,
+                                           int log_n2, int batch_size, hipStream_t stream)
+        {
+            using TW = lazy::Tw<T>;
+            if (mod.bit > T(lazy::Mod<T>::MAX_BIT) || mod.value < 3)
+                return false;
+            if (const char* e = std::getenv("GPUNTT_PATH"))
+                if (std::strcmp(e, "generic") == 0)
+                    return false;
+            const size_t n1 = size_t(1) << log_n1, n2 = size_t(1) << log_n2, n = size_t(1) << n_power;
+            auto* ws = static_cast<TW*>(host::lazy_workspace(stream, sizeof(TW) * (n1 + n + n2 + 2)));
+            TW* ws_n1 = ws;
+            TW* ws_w = ws + n1;
+            TW* ws_n2 = ws + n1 + n;
+            host::launch_prep<T>(n1_table, ws_n1, nullptr, mod.value, 1, log_n1, false, 0, nullptr, nullptr,
+                                 nullptr, nullptr, stream);
+            host::launch_prep_pairs<T>(w_table, ws_w, n, mod.value, stream);
+            host::launch_prep<T>(n2_table, ws_n2, nullptr, mod.value, 1, log_n2, false, 0, nullptr, nullptr,
+                                 nullptr, nullptr, stream); // plain stage layout (no per-tile permutation)
+
+            kern::LazyArgsT<T> a{};
+            a.in = in;
+            a.out = in;
+            a.tw = ws_n1;
+            a.mods = nullptr;
+            a.q = mod.value;
+            a.q_bit = mod.bit;
+            a.q_mu = mod.mu;
+            a.ninv_arr = nullptr;
+            a.ninv = TW{0, 0};
+            a.go_flag = nullptr;
+            a.norm = lazy::make_norm_const(static_cast<uint64_t>(mod.value), static_cast<uint64_t>(mod.bit));
+            a.norm_arr = nullptr;
+            a.w_pairs = ws_w;
+            a.n2_log = log_n2;
+            a.batch = batch_size;
+            a.total = static_cast<unsigned long long>(batch_size) << n_power;
+            a.n = n_power;
+            a.poly_shift = n_power;
+            a.mod_count = 1;
+            a.p_lo = log_n2;
+            a.flags = 0u;
+            host::launch_fourstep_nat_p1_lazy<T>(log_n1, a, stream);
+
+            // rows of length n2
+            kern::LazyArgsT<T> b = a;
+            b.tw = ws_n2;
+            b.w_pairs = nullptr;
+            b.n = log_n2;
+            int k_last = log_n2;
+            bool lazy_in = false;
+            if (log_n2 > 9)
+            {
+                k_last = 8;
+                lazy_in = true;
+                b.poly_shift = log_n2;
+                b.p_lo = k_last;
+                const host::Pass sp{false, log_n2 - k_last, k_last};
+                host::launch_pass_lazy<T, false>(sp, 12, true, false, b, stream);
+            }
+            b.in = in;
+            b.out = out;
+            b.poly_shift = n_power; // the transposing pass addresses whole polynomials
+            b.n2_log = log_n1;      // output row stride
+            b.p_lo = 0;
+            host::launch_fourstep_nat_last_lazy<T>(k_last, lazy_in, b, stream);
+            return true;
+        }
+
         template <typename T>
         void fourstep_dispatch(T* in, T* out, const T* n1_table, const T* n2_table, const T* w_table,
                                const Modulus<T>* mods, Modulus<T> mod, int mod_count,
@@ -248,6 +335,55 @@ namespace gpuntt
                              batch_size, cfg.stream);
     }
 
+    // Extension: the whole natural-order pipeline of the reference's examples in
+    // one call.  FORWARD == GPU_Transpose(in,t,n1,n2) ; GPU_4STEP_NTT(t,u,FORWARD) ;
+    // GPU_Transpose(u,out,n1,n2) == NTT_4STEP_CPU::ntt, computed in three sweeps instead of five
+    // (no transpose sweeps).  INVERSE == intt_first_transpose ; GPU_4STEP_NTT(INVERSE) ;
+    // GPU_Transpose == NTT_4STEP_CPU::intt (composed from the existing passes).  device_in is
+    // used as scratch and holds no meaningful data afterwards; device_in != device_out.
+    template <typename T>
+    __host__ void GPU_4STEP_NTT_NaturalOrder(T* device_in, T* device_out, Root<T>* n1_root_of_unity_table,
+                                             Root<T>* n2_root_of_unity_table, Root<T>* W_root_of_unity_table,
+                                             Modulus<T> modulus, ntt4step_configuration<T> cfg, int batch_size)
+    {
+        int l1 = 0, l2 = 0;
+        if ((cfg.ntt_type != FORWARD && cfg.ntt_type != INVERSE) || !fourstep_shape(cfg.n_power, l1, l2))
+        {
+            std::printf("This ring size is not supported!\n");
+            return;
+        }
+        if (device_in == device_out)
+            throw std::invalid_argument("GPU_4STEP_NTT_NaturalOrder needs distinct buffers");
+        if (batch_size <= 0)
+            return;
+        if ((static_cast<unsigned long long>(batch_size) << cfg.n_power) >> kern::TL > 0x7fffffffull)
+            throw std::invalid_argument("batch_size * N too large for one launch");
+        const int n1 = 1 << l1, n2 = 1 << l2;
+        if (cfg.ntt_type == FORWARD)
+        {
+            if (fourstep_natural_forward_lazy<T>(device_in, device_out, n1_root_of_unity_table,
+                                                 n2_root_of_unity_table, W_root_of_unity_table, modulus,
+                                                 cfg.n_power, l1, l2, batch_size, cfg.stream))
+                return;
+            transpose_on<T>(device_in, device_out, n1, n2, cfg.n_power, batch_size, cfg.stream);
+        }
+        else
+        {
+            // NTT_4STEP_CPU::intt_first_transpose: flat[i*n2+j] = x[i + j*n1]
+            transpose_on<T>(device_in, device_out, n2, n1, cfg.n_power, batch_size, cfg.stream);
+        }
+        fourstep_dispatch<T>(device_out, device_in, n1_root_of_unity_table, n2_root_of_unity_table,
+                             W_root_of_unity_table, nullptr, modulus, 1, nullptr, cfg.mod_inverse, cfg.n_power,
+                             cfg.ntt_type, batch_size, cfg.stream);
+        transpose_on<T>(device_in, device_out, n1, n2, cfg.n_power, batch_size, cfg.stream);
+    }
+
+    template __host__ void GPU_4STEP_NTT_NaturalOrder<Data32>(Data32*, Data32*, Root<Data32>*, Root<Data32>*,
+                                                              Root<Data32>*, Modulus<Data32>,
+                                                              ntt4step_configuration<Data32>, int);
+    template __host__ void GPU_4STEP_NTT_NaturalOrder<Data64>(Data64*, Data64*, Root<Data64>*, Root<Data64>*,
+                                                              Root<Data64>*, Modulus<Data64>,
+                                                              ntt4step_configuration<Data64>, int);
     template __host__ void GPU_Transpose<Data32>(Data32*, Data32*, const int, const int, const int,
                                                  const int);
     template __host__ void GPU_Transpose<Data64>(Data64*, Data64*, const int, const int, const int,

@@ -71,6 +71,16 @@ namespace gpuntt
         extern template void launch_fourstep_phase1_lazy<uint32_t, false>(int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
         extern template void launch_fourstep_phase1_lazy<uint32_t, true>(int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
 
+        // natural-order forward 4-step passes (instantiated with the forward kernels)
+        template <typename T>
+        void launch_fourstep_nat_p1_lazy(int log_n1, const kern::LazyArgsT<T>& a, hipStream_t stream);
+        template <typename T>
+        void launch_fourstep_nat_last_lazy(int k, bool lazy_in, const kern::LazyArgsT<T>& a, hipStream_t stream);
+        extern template void launch_fourstep_nat_p1_lazy<uint64_t>(int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
+        extern template void launch_fourstep_nat_p1_lazy<uint32_t>(int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
+        extern template void launch_fourstep_nat_last_lazy<uint64_t>(int, bool, const kern::LazyArgsT<uint64_t>&, hipStream_t);
+        extern template void launch_fourstep_nat_last_lazy<uint32_t>(int, bool, const kern::LazyArgsT<uint32_t>&, hipStream_t);
+
         // host Shoup companion floor(w * 2^W / q)
         inline uint64_t shoup_host(uint64_t w, uint64_t q)
         {

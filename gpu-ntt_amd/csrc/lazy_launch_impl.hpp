@@ -174,6 +174,53 @@ namespace gpuntt
             GPUNTT_HIP_CHECK(hipGetLastError());
         }
 
+        // natural-order forward 4-step (fourstep_ntt.hip): column pass with W, and the transposing
+        // last row pass (k = stages, lazy_in = its input comes from a strided row pass)
+        template <typename T>
+        void launch_fourstep_nat_p1_lazy(int log_n1, const kern::LazyArgsT<T>& a, hipStream_t stream)
+        {
+            constexpr int TLOG = 12;
+            const unsigned grid = static_cast<unsigned>(a.total >> TLOG);
+            switch (log_n1)
+            {
+#define GPUNTT_CASE(KK)                                                                          \
+    case KK:                                                                                      \
+        hipLaunchKernelGGL((kern::fourstep_nat_p1_lazy<T, TLOG, KK>), dim3(grid),                 \
+                           dim3(kern::LTile<TLOG>::NT), 0, stream, a);                            \
+        break;
+                GPUNTT_CASE(5)
+                GPUNTT_CASE(6)
+                GPUNTT_CASE(7)
+                GPUNTT_CASE(8)
+#undef GPUNTT_CASE
+                default:
+                    throw std::invalid_argument("internal: bad 4-step n1");
+            }
+            GPUNTT_HIP_CHECK(hipGetLastError());
+        }
+        template <typename T>
+        void launch_fourstep_nat_last_lazy(int k, bool lazy_in, const kern::LazyArgsT<T>& a, hipStream_t stream)
+        {
+            constexpr int TLOG = 12;
+            constexpr int LIM = lazy::Mod<T>::LIMIT;
+            const unsigned grid = static_cast<unsigned>(a.total >> TLOG);
+#define GPUNTT_ONE(KK, IN_)                                                                       \
+    hipLaunchKernelGGL((kern::fourstep_nat_last_lazy<T, TLOG, KK, IN_>), dim3(grid),               \
+                       dim3(kern::LTile<TLOG>::NT), 0, stream, a)
+            if (k == 7 && !lazy_in)
+                GPUNTT_ONE(7, 1);
+            else if (k == 8 && !lazy_in)
+                GPUNTT_ONE(8, 1);
+            else if (k == 9 && !lazy_in)
+                GPUNTT_ONE(9, 1);
+            else if (k == 8 && lazy_in)
+                GPUNTT_ONE(8, LIM);
+            else
+                throw std::invalid_argument("internal: bad natural-order 4-step row pass");
+#undef GPUNTT_ONE
+            GPUNTT_HIP_CHECK(hipGetLastError());
+        }
+
         template <typename T, bool INV>
         void launch_pass_lazy(const Pass& p, int tile_log, bool in_first, bool last,
                               const kern::LazyArgsT<T>& a, hipStream_t stream)

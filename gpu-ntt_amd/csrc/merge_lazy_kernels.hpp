@@ -68,24 +68,28 @@ namespace gpuntt
             static constexpr int L = CONTIG ? 0 : (TLOG - K);
             static constexpr int NR = (K + R - 1) / R;
         };
-        template <int TLOG, bool CONTIG, int K> struct LTileMap
+        // SEG (CONTIG only): the tile is 2^(TLOG-K) runs of 2^K contiguous coefficients, run r at
+        // base + (r << row_shift) -- the same column range of consecutive rows of a row-major matrix
+        template <int TLOG, bool CONTIG, int K, bool SEG = false> struct LTileMap
         {
             unsigned long long base;
-            int p_lo;
+            int p_lo; // STRIDED: first stage bit of the pass; SEG: log2 of the row stride
             // CONTIG tile at an explicit flat base (4-step phase 1 orders its blocks poly-minor)
-            __device__ __forceinline__ explicit LTileMap(unsigned long long flat_base) : base(flat_base), p_lo(0) {}
-            __device__ __forceinline__ LTileMap(int n, int pass_p_lo)
+            __device__ __forceinline__ explicit LTileMap(unsigned long long flat_base, int row_shift = 0)
+                : base(flat_base), p_lo(row_shift)
+            {
+            }
+            __device__ __forceinline__ LTileMap(int n, int pass_p_lo, unsigned long long blk)
             {
                 constexpr int L = LGeo<TLOG, CONTIG, K>::L;
                 if constexpr (CONTIG)
                 {
-                    base = static_cast<unsigned long long>(blockIdx.x) << TLOG;
+                    base = blk << TLOG;
                     p_lo = 0;
                 }
                 else
                 {
                     p_lo = pass_p_lo;
-                    const unsigned long long blk = blockIdx.x;
                     const unsigned long long poly = blk >> (n - TLOG);
                     const unsigned long long b = blk & ((1ull << (n - TLOG)) - 1);
                     const unsigned long long xb = b & ((1ull << (p_lo - L)) - 1);
@@ -93,14 +97,10 @@ namespace gpuntt
                     base = (poly << n) | (hi << (p_lo + K)) | (xb << L);
                 }
             }
+            __device__ __forceinline__ LTileMap(int n, int pass_p_lo) : LTileMap(n, pass_p_lo, blockIdx.x) {}
             __device__ __forceinline__ unsigned long long flat(int e) const
             {
-                constexpr int L = LGeo<TLOG, CONTIG, K>::L;
-                if constexpr (CONTIG)
-                    return base + static_cast<unsigned>(e);
-                else
-                    return base | (static_cast<unsigned long long>(e >> L) << p_lo) |
-                           static_cast<unsigned>(e & ((1 << L) - 1));
+                return base + part(static_cast<unsigned>(e));
             }
             __device__ __forceinline__ int gpos(int p) const
             {
@@ -124,7 +124,9 @@ namespace gpuntt
             __device__ __forceinline__ unsigned part(unsigned e) const
             {
                 constexpr int L = LGeo<TLOG, CONTIG, K>::L;
-                if constexpr (CONTIG)
+                if constexpr (CONTIG && SEG)
+                    return ((e >> K) << p_lo) | (e & ((1u << K) - 1u));
+                else if constexpr (CONTIG)
                     return e;
                 else
                     return ((e >> L) << p_lo) | (e & ((1u << L) - 1u));
@@ -242,11 +244,18 @@ namespace gpuntt
         // over the rows (length n1 = 2^K) of the n2 x n1 input, stored transposed into the n1 x n2
         // output with the W multiply fused; output canonical.  Blocks are ordered poly-minor so the
         // polynomials of a batch that share a slice of W run back to back (W stays in L2).
+        // FST = 2, natural-order 4-step, last forward pass: CONTIG stages on the same 2^K-column range
+        // of 2^(TL-K) consecutive rows (lazy input from the strided row passes, or canonical input
+        // when the rows fit one pass), canonical output stored transposed (no W product).
+        // WMUL (STRIDED passes): natural-order 4-step, first forward pass: the column transforms run
+        // in place on the row-major input, the W product is applied on the way out; blocks are
+        // ordered poly-minor (blk_override) so a batch shares each W slice in L2.
         template <typename T, int TLOG, bool EXACT, bool INV, bool CONTIG, int K, int IN_BOUND, bool LAST,
-                  bool FST = false>
+                  int FST = 0, bool WMUL = false>
         __device__ __forceinline__ void pass_body(const LazyArgsT<T>& a, T* lds, T q_value, T q_bit, T q_mu,
                                                   int mi, unsigned long long fst_poly = 0,
-                                                  unsigned fst_tile = 0)
+                                                  unsigned fst_tile = 0, long long blk_override = -1,
+                                                  unsigned fst_seg = 0)
         {
             using G = LGeo<TLOG, CONTIG, K>;
             using M = lazy::Mod<T>;
@@ -259,10 +268,16 @@ namespace gpuntt
             constexpr bool MULTI_POLY = CONTIG && (K < TL) && (IN_BOUND == 1) && (LAST || FST);
 
             const int t = threadIdx.x;
-            LTileMap<TLOG, CONTIG, K> map =
-                FST ? LTileMap<TLOG, CONTIG, K>((fst_poly << a.poly_shift) +
-                                                (static_cast<unsigned long long>(fst_tile) << TL))
-                    : LTileMap<TLOG, CONTIG, K>(a.n, a.p_lo);
+            constexpr bool SEG = (FST == 2);
+            using Map = LTileMap<TLOG, CONTIG, K, SEG>;
+            Map map = SEG   ? Map((fst_poly << a.poly_shift) +
+                                      ((static_cast<unsigned long long>(fst_tile) << (TL - K)) << a.n) +
+                                      (static_cast<unsigned long long>(fst_seg) << K),
+                                  a.n)
+                      : FST ? Map((fst_poly << a.poly_shift) + (static_cast<unsigned long long>(fst_tile) << TL))
+                            : Map(a.n, a.p_lo,
+                                  blk_override >= 0 ? static_cast<unsigned long long>(blk_override)
+                                                    : static_cast<unsigned long long>(blockIdx.x));
             if (a.poly_order != nullptr)
                 map.remap_poly(a.poly_order, a.n); // twiddle indices use flat & (N-1): unaffected
             M m;
@@ -295,7 +310,7 @@ namespace gpuntt
                     constexpr int jb = p - WL;
                     constexpr int CNT = 1 << (R - 1 - jb);
                     // prepared layout of the distance-1/2/4 stages of full tiles: [tile][k][thread]
-                    constexpr bool PERM = CONTIG && !MULTI_POLY && (WL == 0) && (p <= 2);
+                    constexpr bool PERM = CONTIG && !MULTI_POLY && !SEG && (WL == 0) && (p <= 2);
                     const int P = map.gpos(p);
                     const unsigned stage_base = 1u << (a.n - 1 - P); // slots [2^S, 2^(S+1)), S = n-1-P
                     const TW* ps;
@@ -313,7 +328,7 @@ namespace gpuntt
                     }
                     static_for<CNT>([&](auto k_) {
                         constexpr int kk = decltype(k_)::value;
-                        if constexpr (CONTIG && !MULTI_POLY && (WL != 0) && (p <= 2))
+                        if constexpr (CONTIG && !MULTI_POLY && !SEG && (WL != 0) && (p <= 2))
                         {
                             // distance-1/2/4 stage that is not in the 16-contiguous-coefficient round
                             // (contiguous passes of 9 or 10 stages): address the permuted layout
@@ -402,9 +417,10 @@ namespace gpuntt
                         if (plain_io)
                         {
                             T tmp[EPT];
+                            const unsigned lane = map.part(static_cast<unsigned>(t));
 #pragma unroll
                             for (int j = 0; j < EPT; j++)
-                                tmp[j] = (src + (map.base + static_cast<unsigned>(NT * j)))[t];
+                                tmp[j] = (src + (map.base + map.part(static_cast<unsigned>(NT * j))))[lane];
                             T* lc = lds + lds_pad(t);
 #pragma unroll
                             for (int j = 0; j < EPT; j++)
@@ -527,7 +543,7 @@ namespace gpuntt
                     }
                     if constexpr (FST)
                     {
-                        static_assert(!FST || (CONTIG && K >= 4 && K <= 8), "phase-1 rows are 32..256 long");
+                        static_assert(!FST || (CONTIG && K >= 4 && K <= 9), "4-step row runs are 16..512 long");
                         constexpr int RB = TL - K; // log2 rows per tile
                         __syncthreads();           // all gathers from the e + (e >> 4) layout are done
 #pragma unroll
@@ -535,6 +551,9 @@ namespace gpuntt
                             lds[lds_pad_t<K>(elem_of<WL>(t, j))] = v[j];
                         __syncthreads();
                         const unsigned row0 = fst_tile << RB;
+                        // SEG: output row of tile column i is (seg << K) + i
+                        const unsigned long long seg_base =
+                            SEG ? ((static_cast<unsigned long long>(fst_seg) << K) << a.n2_log) : 0ull;
                         // two halves of 8 keep {coefficient, W pair} in 48 VGPRs instead of 96
 #pragma unroll
                         for (int half = 0; half < 2; half++)
@@ -552,7 +571,8 @@ namespace gpuntt
                                 const unsigned lane = (static_cast<unsigned>(t >> RB) << a.n2_log) + (t & ((1 << RB) - 1));
                                 const unsigned long long ubase =
                                     (static_cast<unsigned long long>((NT >> RB) * jr) << a.n2_log) + row0;
-                                wv[jj] = (a.w_pairs + ubase)[lane];
+                                if constexpr (!SEG)
+                                    wv[jj] = (a.w_pairs + ubase)[lane];
                                 x[jj] = lds[lds_pad_t<K>((jl << K) | i)];
                             }
 #pragma unroll
@@ -562,14 +582,38 @@ namespace gpuntt
                                 const unsigned lane = (static_cast<unsigned>(t >> RB) << a.n2_log) + (t & ((1 << RB) - 1));
                                 const unsigned long long ubase =
                                     (static_cast<unsigned long long>((NT >> RB) * jr) << a.n2_log) + row0;
-                                (a.out + ((fst_poly << a.poly_shift) + ubase))[lane] =
-                                    lazy::normalize<M::TB>(m, m.mul(x[jj], wv[jj]));
+                                if constexpr (SEG)
+                                    (a.out + ((fst_poly << a.poly_shift) + seg_base + ubase))[lane] = x[jj];
+                                else
+                                    (a.out + ((fst_poly << a.poly_shift) + ubase))[lane] =
+                                        lazy::normalize<M::TB>(m, m.mul(x[jj], wv[jj]));
                             }
                         }
                     }
                     else if constexpr (DIRECT_IO)
                     {
-                        if (full_tile)
+                        if constexpr (WMUL)
+                        {
+                            // W[f mod N] rides on the store; halves of 8 bound the live W pairs
+                            const unsigned lane = map.part(elem_of<WL>(t, 0));
+                            const unsigned long long wb = map.base & nmask;
+#pragma unroll
+                            for (int half = 0; half < 2; half++)
+                            {
+                                TW wv[EPT / 2];
+#pragma unroll
+                                for (int jj = 0; jj < EPT / 2; jj++)
+                                    wv[jj] = (a.w_pairs + (wb + map.part(static_cast<unsigned>(half * (EPT / 2) + jj) << WL)))[lane];
+#pragma unroll
+                                for (int jj = 0; jj < EPT / 2; jj++)
+                                {
+                                    const int j = half * (EPT / 2) + jj;
+                                    (a.out + (map.base + map.part(static_cast<unsigned>(j) << WL)))[lane] =
+                                        lazy::normalize<M::TB>(m, m.mul(v[j], wv[jj]));
+                                }
+                            }
+                        }
+                        else if (full_tile)
                         {
                             const unsigned lane = map.part(elem_of<WL>(t, 0));
 #pragma unroll
@@ -657,6 +701,38 @@ namespace gpuntt
                 qm = md.mu;
             }
             pass_body<T, TLOG, false, INV, CONTIG, K, IN_BOUND, LAST>(a, lds, qv, qb, qm, mi);
+        }
+
+        // natural-order 4-step, forward pass 1: STRIDED column transforms (K = log2 n1 top bits of the
+        // N-ring, in place) + W product; block b -> (tile b / batch, poly b % batch)
+        template <typename T, int TLOG, int K>
+        __global__ __launch_bounds__(LTile<TLOG>::NT, LOcc<TLOG>::WAVES) void fourstep_nat_p1_lazy(LazyArgsT<T> a)
+        {
+            using G = LGeo<TLOG, false, K>;
+            using M = lazy::Mod<T>;
+            using SCH = PassSched<TLOG, false, false, K, 1, M::LIMIT, M::TB>;
+            constexpr bool NEEDS_LDS = (G::NR > 1) || (SCH::wl_of(0) < 4);
+            __shared__ T lds[NEEDS_LDS ? LTile<TLOG>::LDS_ELEMS : 1];
+            const unsigned long long poly = blockIdx.x % static_cast<unsigned>(a.batch);
+            const unsigned long long tile = blockIdx.x / static_cast<unsigned>(a.batch);
+            const long long blk = static_cast<long long>((poly << (a.n - TLOG)) | tile);
+            pass_body<T, TLOG, false, false, false, K, 1, false, 0, true>(a, lds, a.q, a.q_bit, a.q_mu, 0, 0, 0, blk);
+        }
+
+        // natural-order 4-step, last forward pass: block b -> (row block fastest, column run, poly);
+        // a.n = log2 n2 (row length and input row stride), a.n2_log = log2 n1 (output row stride)
+        template <typename T, int TLOG, int K, int IN_BOUND>
+        __global__ __launch_bounds__(LTile<TLOG>::NT, LOcc<TLOG>::WAVES) void fourstep_nat_last_lazy(LazyArgsT<T> a)
+        {
+            __shared__ T lds[LTile<TLOG>::LDS_ELEMS_FST];
+            constexpr int RB = TLOG - K;
+            const unsigned row_blocks = 1u << (a.n2_log - RB);
+            const unsigned runs = 1u << (a.n - K);
+            const unsigned rb = blockIdx.x % row_blocks;
+            const unsigned rest = blockIdx.x / row_blocks;
+            const unsigned seg = rest % runs;
+            const unsigned long long poly = rest / runs;
+            pass_body<T, TLOG, false, false, true, K, IN_BOUND, true, 2>(a, lds, a.q, a.q_bit, a.q_mu, 0, poly, rb, -1, seg);
         }
 
         // 4-step phase 1 kernel; grid = batch * N / TILE blocks, block b -> (tile b / batch, poly b % batch)

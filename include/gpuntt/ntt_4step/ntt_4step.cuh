@@ -54,4 +54,20 @@ namespace gpuntt
                                 Modulus<T>* modulus, ntt4step_rns_configuration<T> cfg,
                                 int batch_size, int mod_count);
 
+    // ---- extension (not in the reference) ------------------------------------------------
+    // The natural-order pipeline of the reference's 4-step examples as ONE call:
+    //   FORWARD  == GPU_Transpose(in, t, n1, n2) -> GPU_4STEP_NTT(t, u, FORWARD) -> GPU_Transpose(u, out, n1, n2)
+    //            == NTT_4STEP_CPU<T>::ntt(in)      (example/ntt_4step/test_4step_ntt.cu:147-178)
+    //   INVERSE  == intt_first_transpose(in) -> GPU_4STEP_NTT(INVERSE) -> GPU_Transpose
+    //            == NTT_4STEP_CPU<T>::intt(in)     (example/ntt_4step/test_4step_intt.cu:81-179)
+    // The forward direction runs in three HBM sweeps instead of five (the column transforms work
+    // on the row-major input directly, the last row pass stores transposed).  device_in is used
+    // as scratch (as the three-call sequence does) and must differ from device_out; every launch
+    // is on cfg.stream.
+    template <typename T>
+    __host__ void GPU_4STEP_NTT_NaturalOrder(T* device_in, T* device_out, Root<T>* n1_root_of_unity_table,
+                                             Root<T>* n2_root_of_unity_table, Root<T>* W_root_of_unity_table,
+                                             Modulus<T> modulus, ntt4step_configuration<T> cfg,
+                                             int batch_size);
+
 } // namespace gpuntt

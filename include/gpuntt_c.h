@@ -127,6 +127,17 @@ extern "C"
                          const uint64_t* n2_table, const uint64_t* w_table,
                          gpuntt_modulus64 modulus, int n_power, int ntt_type, uint64_t mod_inverse,
                          void* stream, int batch_size);
+    /* extension: the reference examples' natural-order pipeline (GPU_Transpose -> GPU_4STEP_NTT ->
+     * GPU_Transpose, test_4step_ntt.cu:147-178 / test_4step_intt.cu:81-179) as one call =
+     * NTT_4STEP_CPU::ntt / ::intt; `in_scratch` is overwritten, in_scratch != out */
+    int gpuntt_4step_natural_u32(uint32_t* in_scratch, uint32_t* out, const uint32_t* n1_table,
+                                 const uint32_t* n2_table, const uint32_t* w_table,
+                                 gpuntt_modulus32 modulus, int n_power, int ntt_type,
+                                 uint32_t mod_inverse, void* stream, int batch_size);
+    int gpuntt_4step_natural_u64(uint64_t* in_scratch, uint64_t* out, const uint64_t* n1_table,
+                                 const uint64_t* n2_table, const uint64_t* w_table,
+                                 gpuntt_modulus64 modulus, int n_power, int ntt_type,
+                                 uint64_t mod_inverse, void* stream, int batch_size);
     int gpuntt_4step_rns_u32(const uint32_t* in, uint32_t* out, const uint32_t* n1_table,
                              const uint32_t* n2_table, const uint32_t* w_table,
                              const gpuntt_modulus32* modulus, int n_power, int ntt_type,

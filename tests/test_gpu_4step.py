@@ -91,6 +91,63 @@ def test_fourstep_vs_oracle(g, bits):
 
 
 @pytest.mark.parametrize("bits", [32, 64])
+def test_fourstep_natural_order_vs_oracle(g, bits):
+    """extension GPU_4STEP_NTT_NaturalOrder == the three-call pipeline == NTT_4STEP_CPU::ntt / intt,
+    every shape class (single transposing row pass n2 <= 512, strided + transposing pass above)"""
+    import torch
+    P = O.Port(bits)
+    for logn in (12, 13, 14, 15, 16, 17, 18, 19, 20):
+        p4 = g.NTTParameters4Step(logn, bits)
+        oprm = P.fourstep_params(logn)
+        batch = 3 if logn <= 16 else 1
+        x = P.splitmix(700 + logn, 0, batch * p4.n, p4.modulus.value)
+        want = np.concatenate([P.fourstep_ntt(x[i * p4.n:(i + 1) * p4.n], oprm) for i in range(batch)])
+        tf = [g.to_device(t) for t in p4.tables["fwd"]]
+        ti = [g.to_device(t) for t in p4.tables["inv"]]
+        d_in = g.to_device(x)
+        d_out = torch.zeros_like(d_in)
+        cf = g.ntt4step_configuration(n_power=logn, ntt_type=g.FORWARD)
+        g.GPU_4STEP_NTT_NaturalOrder(d_in, d_out, *tf, p4.modulus, cf, batch)
+        torch.cuda.synchronize()
+        got = g.to_host(d_out)
+        assert np.array_equal(got, want), ("forward", bits, logn)
+        ci = g.ntt4step_configuration(n_power=logn, ntt_type=g.INVERSE, mod_inverse=p4.n_inv)
+        d_back = torch.zeros_like(d_out)
+        g.GPU_4STEP_NTT_NaturalOrder(d_out, d_back, *ti, p4.modulus, ci, batch)
+        torch.cuda.synchronize()
+        assert np.array_equal(g.to_host(d_back), x), ("inverse", bits, logn)
+    # same buffer twice is rejected (the input doubles as scratch)
+    with pytest.raises(ValueError):
+        g.GPU_4STEP_NTT_NaturalOrder(d_in, d_in, *tf, p4.modulus, cf, batch)
+
+
+def test_fourstep_natural_order_generic_fallback(g):
+    """no fast path (forced here; also what a 61/62-bit modulus gets): generic 4-step kernels
+    between two transposes, same result"""
+    import torch
+    P = O.Port(64)
+    logn = 13
+    p4 = g.NTTParameters4Step(logn, 64)
+    oprm = P.fourstep_params(logn)
+    x = P.splitmix(801, 0, p4.n, p4.modulus.value)
+    tf = [g.to_device(t) for t in p4.tables["fwd"]]
+    d_in = g.to_device(x)
+    d_out = torch.zeros_like(d_in)
+    cf = g.ntt4step_configuration(n_power=logn, ntt_type=g.FORWARD)
+    old = os.environ.get("GPUNTT_PATH")
+    os.environ["GPUNTT_PATH"] = "generic"  # the 4-step hosts read it per call
+    try:
+        g.GPU_4STEP_NTT_NaturalOrder(d_in, d_out, *tf, p4.modulus, cf, 1)
+        torch.cuda.synchronize()
+    finally:
+        if old is None:
+            del os.environ["GPUNTT_PATH"]
+        else:
+            os.environ["GPUNTT_PATH"] = old
+    assert np.array_equal(g.to_host(d_out), P.fourstep_ntt(x, oprm))
+
+
+@pytest.mark.parametrize("bits", [32, 64])
 def test_fourstep_golden(g, bits, golden_dir):
     P = O.Port(bits)
     gold = np.load(os.path.join(golden_dir, "fourstep_u%d.npz" % bits))

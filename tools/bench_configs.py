@@ -144,6 +144,14 @@ def fourstep_case(g, bits, logn, batch, iters, name, check=True):
         g.GPU_Transpose(a, b, p4.n1, p4.n2, logn, batch)
     emit(name + "-fwd+2transposes", bits, "4step-fwd-natural", logn, batch, time_ms(full, iters), ok)
 
+    # the same natural-order result from the fused extension entry point (3 sweeps)
+    a.copy_(g.to_device(x))
+    g.GPU_4STEP_NTT_NaturalOrder(a, b, *tf, p4.modulus, cf, batch)
+    torch.cuda.synchronize()
+    ok2 = (not check) or np.array_equal(g.to_host(b)[:n], P.fourstep_ntt(x[:n], oprm))
+    nat = lambda: g.GPU_4STEP_NTT_NaturalOrder(a, b, *tf, p4.modulus, cf, batch)  # noqa: E731
+    emit(name + "-fwd-natural-fused", bits, "4step-fwd-natural-fused", logn, batch, time_ms(nat, iters), ok2)
+
 
 def main():
     ap = argparse.ArgumentParser()
