@@ -179,7 +179,7 @@ def main():
                                  "call); the contiguous pass dominates and is VALU-issue bound; per-kernel "
                                  "averages in profiles/"},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only
             line["cpu_baseline"] = cpu_baseline(prm.modulus.value, x[:args.cpu_polys * n], y_first, LOGN)
         print(json.dumps(line), flush=True)
     if dist is not None:
