@@ -106,19 +106,19 @@ namespace gpuntt
         {
             unsigned long long base; // CONTIG: flat base; STRIDED: flat index bits supplied by the block
             int p_lo;
-            __device__ __forceinline__ TileMap(const PassArgs<T>& a) : TileMap(a.n, a.p_lo) {}
-            __device__ __forceinline__ TileMap(int n, int pass_p_lo)
+            __device__ __forceinline__ TileMap(const PassArgs<T>& a, unsigned tile) : TileMap(a.n, a.p_lo, tile) {}
+            __device__ __forceinline__ TileMap(int n, int pass_p_lo, unsigned tile)
             {
                 constexpr int L = Geo<CONTIG, K>::L;
                 if constexpr (CONTIG)
                 {
-                    base = static_cast<unsigned long long>(blockIdx.x) << TL;
+                    base = static_cast<unsigned long long>(tile) << TL;
                     p_lo = 0;
                 }
                 else
                 {
                     p_lo = pass_p_lo;
-                    const unsigned long long blk = blockIdx.x;
+                    const unsigned long long blk = tile;
                     const unsigned long long poly = blk >> (n - TL);
                     const unsigned long long b = blk & ((1ull << (n - TL)) - 1);
                     const unsigned long long xb = b & ((1ull << (p_lo - L)) - 1);
@@ -265,7 +265,14 @@ namespace gpuntt
             if (a.skip_flag != nullptr && *a.skip_flag != 0u)
                 return;
             const int t = threadIdx.x;
-            const TileMap<T, CONTIG, K> map(a);
+            // one tile per block, except for the shadow launches of RNS calls (skip_flag set), which
+            // use a capped grid that walks the tiles so that a skipped launch costs ~1 us, not ~7
+            const unsigned ntiles = static_cast<unsigned>((a.total + TILE - 1) >> TL);
+            for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x)
+            {
+            if (tile != blockIdx.x)
+                __syncthreads(); // LDS of the previous tile is free
+            const TileMap<T, CONTIG, K> map(a, tile);
             // block-uniform context (exact when the tile lies inside one polynomial; with
             // F_MULTI it is refreshed per butterfly)
             const Ctx<T> ctx = make_ctx(a, map.flat(0) >> a.poly_shift);
@@ -349,8 +356,8 @@ namespace gpuntt
                             lds[lds_pad_t<K>(elem_of<WL>(t, j))] = v[j];
                         __syncthreads();
                         const unsigned tiles_log = a.poly_shift - TL;
-                        const unsigned long long poly = blockIdx.x >> tiles_log;
-                        const unsigned row0 = (blockIdx.x & ((1u << tiles_log) - 1u)) << RB;
+                        const unsigned long long poly = tile >> tiles_log;
+                        const unsigned row0 = (tile & ((1u << tiles_log) - 1u)) << RB;
 #pragma unroll
                         for (int j = 0; j < EPT; j++)
                         {
@@ -399,6 +406,7 @@ namespace gpuntt
                     __syncthreads();
                 }
             });
+            } // tile loop
         }
 
         // Column-wise (PerCoefficient) transform for matrices too small for a 4096-coefficient

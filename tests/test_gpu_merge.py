@@ -339,6 +339,32 @@ def test_moduli_without_lazy_headroom(g):
     assert np.array_equal(g.to_host(d), x)
 
 
+def test_rns_generic_kernels_walk_tiles_with_capped_grid(g):
+    """An RNS call whose moduli lack the lazy headroom is served by the generic kernels, which
+    for RNS calls are launched with at most 1024 blocks that walk the tiles (so that their usual
+    role -- a skipped shadow launch -- is cheap): more tiles than blocks, both directions."""
+    import torch
+    from gpu_utils import find_ntt_factors
+    logn, batch = 13, 1200  # 2400 tiles
+    fl = [find_ntt_factors(62, logn), find_ntt_factors(60, logn), find_ntt_factors(61, logn)]
+    cases, fwd, inv, mods, ninv = _rns_setup(g, 64, logn, O.X_N_plus, fl)
+    n = 1 << logn
+    x = np.concatenate([cases[p % 3].P.splitmix(170 + p, 0, n, cases[p % 3].q) for p in range(batch)])
+    d = g.to_device(x)
+    g.GPU_NTT_Inplace(d, fwd, mods, g.ntt_rns_configuration(n_power=logn, reduction_poly=O.X_N_plus),
+                      batch, 3)
+    torch.cuda.synchronize()
+    y = g.to_host(d)
+    for p in list(range(0, batch, 97)) + [batch - 1]:
+        c = cases[p % 3]
+        assert np.array_equal(y[p * n:(p + 1) * n], c.P.merge_ntt(x[p * n:(p + 1) * n], c.oprm)), p
+    g.GPU_INTT_Inplace(d, inv, mods,
+                       g.ntt_rns_configuration(n_power=logn, ntt_type=g.INVERSE,
+                                               reduction_poly=O.X_N_plus, mod_inverse=ninv), batch, 3)
+    torch.cuda.synchronize()
+    assert np.array_equal(g.to_host(d), x)
+
+
 def test_small_and_odd_sized_moduli_u64(g):
     """64-bit words holding small primes (14..50 bit): exercises the shift-free branch of the
     one-multiply final normalisation and the lazy bounds far from the 60-bit case."""
