@@ -358,7 +358,7 @@ namespace gpuntt
 
             // whole tile inside the batch (always true for N >= 4096) and no signed conversion
             const bool full_tile =
-                (CONTIG && !FST) ? (((static_cast<unsigned long long>(blockIdx.x) + 1) << TL) <= a.total) : true;
+                (CONTIG && !FST) ? ((map.base + LTile<TLOG>::TILE) <= a.total) : true;
             const bool plain_io = full_tile && !(a.flags & F_SIGNED_IN);
 
             // 64-bit: request a round's twiddles one round ahead (in front of the exchange barrier);
