@@ -85,7 +85,8 @@ def load_library():
 EXPORTED_SYMBOLS = ["gpuntt_last_error", "gpuntt_version"] + [
     "gpuntt_%s_%s" % (f, s)
     for f in ("modulus", "ntt", "intt", "ntt_rns", "intt_rns", "ntt_modulus_ordered",
-              "ntt_poly_ordered", "4step", "4step_rns", "4step_natural", "transpose", "merge_params",
+              "ntt_poly_ordered", "polymul", "polymul_rns", "4step", "4step_rns", "4step_natural", "transpose",
+              "merge_params",
               "4step_params")
     for s in ("u32", "u64")]
 
@@ -377,6 +378,26 @@ def GPU_4STEP_NTT(device_in, device_out, n1_root_of_unity_table, n2_root_of_unit
         _check(fn(_ptr(device_in), _ptr(device_out), _ptr(n1_root_of_unity_table),
                   _ptr(n2_root_of_unity_table), _ptr(W_root_of_unity_table), _ptr(modulus),
                   cfg.n_power, cfg.ntt_type, _ptr(cfg.mod_inverse), _stream(cfg.stream),
+                  batch_size, int(mod_count)))
+
+
+def GPU_PolyMul(device_a, device_b, device_out, forward_table, inverse_table, modulus, cfg, batch_size,
+                mod_count=None):
+    """Extension: device_out = INTT(NTT(a) (.) NTT(b)) -- the product in Z_q[X]/(X^N -+ 1) that the
+    reference's CPU example builds from NTTCPU::ntt / mult / intt.  a and b are overwritten with their
+    transforms; cfg carries n_power, reduction_poly, mod_inverse (N^-1; device array for RNS), stream."""
+    lib = load_library()
+    _require_gpu(device_a, device_b, device_out, forward_table, inverse_table)
+    bits = device_a.element_size() * 8
+    if isinstance(modulus, Modulus):
+        fn = getattr(lib, "gpuntt_polymul_u%d" % bits)
+        _check(fn(_ptr(device_a), _ptr(device_b), _ptr(device_out), _ptr(forward_table), _ptr(inverse_table),
+                  modulus.c(), cfg.n_power, cfg.reduction_poly, _ct(bits)(cfg.mod_inverse),
+                  _stream(cfg.stream), batch_size))
+    else:
+        fn = getattr(lib, "gpuntt_polymul_rns_u%d" % bits)
+        _check(fn(_ptr(device_a), _ptr(device_b), _ptr(device_out), _ptr(forward_table), _ptr(inverse_table),
+                  _ptr(modulus), cfg.n_power, cfg.reduction_poly, _ptr(cfg.mod_inverse), _stream(cfg.stream),
                   batch_size, int(mod_count)))
 
 

@@ -140,6 +140,30 @@ namespace
     }
 
     template <typename T, typename CM>
+    int polymul_single(T* a, T* b, T* out, const T* fwd, const T* inv, CM modulus, int n_power,
+                       int reduction_poly, T mod_inverse, void* stream, int batch)
+    {
+        return guarded([&] {
+            ntt_configuration<T> cfg = {n_power, FORWARD, PerPolynomial,
+                                        static_cast<ReductionPolynomial>(reduction_poly), false, mod_inverse,
+                                        static_cast<hipStream_t>(stream)};
+            GPU_PolyMul<T>(a, b, out, const_cast<T*>(fwd), const_cast<T*>(inv), to_mod<T>(modulus), cfg, batch);
+        });
+    }
+    template <typename T, typename CM>
+    int polymul_rns(T* a, T* b, T* out, const T* fwd, const T* inv, const CM* modulus, int n_power,
+                    int reduction_poly, const T* mod_inverse, void* stream, int batch, int mod_count)
+    {
+        return guarded([&] {
+            ntt_rns_configuration<T> cfg = {n_power, FORWARD, PerPolynomial,
+                                            static_cast<ReductionPolynomial>(reduction_poly), false,
+                                            const_cast<T*>(mod_inverse), static_cast<hipStream_t>(stream)};
+            GPU_PolyMul<T>(a, b, out, const_cast<T*>(fwd), const_cast<T*>(inv),
+                           reinterpret_cast<Modulus<T>*>(const_cast<CM*>(modulus)), cfg, batch, mod_count);
+        });
+    }
+
+    template <typename T, typename CM>
     int fourstep_single(const T* in, T* out, const T* t1, const T* t2, const T* w, CM modulus,
                         int n_power, int ntt_type, T mod_inverse, void* stream, int batch)
     {
@@ -356,6 +380,20 @@ extern "C"
     {                                                                                             \
         return fourstep_single<T>(in, out, n1_table, n2_table, w_table, modulus, n_power,         \
                                   ntt_type, mod_inverse, stream, batch_size);                     \
+    }                                                                                             \
+    int gpuntt_polymul_##S(T* a, T* b, T* out, const T* forward_table, const T* inverse_table,     \
+                           CM modulus, int n_power, int reduction_poly, T mod_inverse, void* stream, \
+                           int batch_size)                                                          \
+    {                                                                                             \
+        return polymul_single<T>(a, b, out, forward_table, inverse_table, modulus, n_power,        \
+                                 reduction_poly, mod_inverse, stream, batch_size);                \
+    }                                                                                             \
+    int gpuntt_polymul_rns_##S(T* a, T* b, T* out, const T* forward_table, const T* inverse_table, \
+                               const CM* modulus, int n_power, int reduction_poly,                 \
+                               const T* mod_inverse, void* stream, int batch_size, int mod_count)  \
+    {                                                                                             \
+        return polymul_rns<T>(a, b, out, forward_table, inverse_table, modulus, n_power,           \
+                              reduction_poly, mod_inverse, stream, batch_size, mod_count);        \
     }                                                                                             \
     int gpuntt_4step_natural_##S(T* in_scratch, T* out, const T* n1_table, const T* n2_table,      \
                                  const T* w_table, CM modulus, int n_power, int ntt_type,          \

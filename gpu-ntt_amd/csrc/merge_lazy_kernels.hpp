@@ -278,6 +278,9 @@ namespace gpuntt
                             : Map(a.n, a.p_lo,
                                   blk_override >= 0 ? static_cast<unsigned long long>(blk_override)
                                                     : static_cast<unsigned long long>(blockIdx.x));
+            // whole tile inside the batch (always true for N >= 4096); taken before *_Poly_Ordered moves
+            // the tile to its memory slot, which may lie beyond batch * N
+            const bool tile_in_range = (CONTIG && !FST) ? ((map.base + LTile<TLOG>::TILE) <= a.total) : true;
             if (a.poly_order != nullptr)
                 map.remap_poly(a.poly_order, a.n); // twiddle indices use flat & (N-1): unaffected
             M m;
@@ -356,9 +359,8 @@ namespace gpuntt
                 });
             };
 
-            // whole tile inside the batch (always true for N >= 4096) and no signed conversion
-            const bool full_tile =
-                (CONTIG && !FST) ? ((map.base + LTile<TLOG>::TILE) <= a.total) : true;
+            // ... and no signed conversion
+            const bool full_tile = tile_in_range;
             const bool plain_io = full_tile && !(a.flags & F_SIGNED_IN);
 
             // 64-bit: request a round's twiddles one round ahead (in front of the exchange barrier);

@@ -411,6 +411,126 @@ namespace gpuntt
                     mod_count);
     }
 
+    // ------------------------------------------------- pointwise product / PolyMul ----
+    namespace kern
+    {
+        // out[i] = a[i] * b[i] mod q_p, p = (i >> n) % mod_count; Barrett with the caller's
+        // {value, bit, mu} (reference OPERATOR_GPU::mult, modular_arith.cuh:312-339); HBM-bound:
+        // 16-byte accesses, grid-stride
+        template <typename T, int V>
+        __global__ __launch_bounds__(256) void pointwise_mul(const T* a, const T* b, T* out,
+                                                             const Modulus<T>* __restrict__ mods, Modulus<T> mod,
+                                                             int mod_count, int n, unsigned long long total)
+        {
+            // V elements per access: 16 bytes when the buffers are 16-byte aligned, else 1 element
+            struct alignas(V * sizeof(T)) Vec
+            {
+                T x[V];
+            };
+            const unsigned long long stride = static_cast<unsigned long long>(gridDim.x) * 256ull * V;
+            for (unsigned long long i = (blockIdx.x * 256ull + threadIdx.x) * V; i < total; i += stride)
+            {
+                Modulus<T> md = mod;
+                if (mods != nullptr)
+                    md = mods[(i >> n) % static_cast<unsigned>(mod_count)];
+                const dev::ModCtx<T> m{md.value, md.bit, md.mu};
+                const Vec va = *reinterpret_cast<const Vec*>(a + i);
+                const Vec vb = *reinterpret_cast<const Vec*>(b + i);
+                Vec vo;
+#pragma unroll
+                for (int k = 0; k < V; k++)
+                    vo.x[k] = m.mul(va.x[k], vb.x[k]);
+                *reinterpret_cast<Vec*>(out + i) = vo;
+            }
+        }
+    } // namespace kern
+
+    namespace
+    {
+        template <typename T>
+        void pointwise_launch(T* a, T* b, T* out, const Modulus<T>* mods, Modulus<T> mod, int mod_count,
+                              int n_power, int batch_size, hipStream_t stream)
+        {
+            if (n_power <= 0 || n_power >= 29)
+                throw std::invalid_argument("Invalid n_power range!");
+            if (batch_size <= 0)
+                return;
+            const unsigned long long total = static_cast<unsigned long long>(batch_size) << n_power;
+            constexpr int VW = 16 / sizeof(T);
+            // a 16-byte group must stay inside one polynomial (one modulus) and be aligned
+            const bool wide = (n_power >= (sizeof(T) == 8 ? 1 : 2)) &&
+                              ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) |
+                                reinterpret_cast<uintptr_t>(out)) & 15u) == 0;
+            const unsigned long long per_block = 256ull * (wide ? VW : 1);
+            unsigned long long blocks = (total + per_block - 1) / per_block;
+            if (blocks > 16384)
+                blocks = 16384; // 64 blocks per CU, grid-stride beyond
+            if (wide)
+                hipLaunchKernelGGL((kern::pointwise_mul<T, VW>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0,
+                                   stream, a, b, out, mods, mod, mod_count, n_power, total);
+            else
+                hipLaunchKernelGGL((kern::pointwise_mul<T, 1>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0,
+                                   stream, a, b, out, mods, mod, mod_count, n_power, total);
+            GPUNTT_HIP_CHECK(hipGetLastError());
+        }
+    } // namespace
+
+    template <typename T>
+    __host__ void GPU_PointwiseMul(T* device_a, T* device_b, T* device_out, Modulus<T> modulus, int n_power,
+                                   int batch_size, stream_t stream)
+    {
+        pointwise_launch<T>(device_a, device_b, device_out, nullptr, modulus, 1, n_power, batch_size, stream);
+    }
+    template <typename T>
+    __host__ void GPU_PointwiseMul(T* device_a, T* device_b, T* device_out, Modulus<T>* modulus, int n_power,
+                                   int batch_size, int mod_count, stream_t stream)
+    {
+        if (mod_count <= 0 || modulus == nullptr)
+            throw std::invalid_argument("Invalid mod_count!");
+        pointwise_launch<T>(device_a, device_b, device_out, modulus, Modulus<T>(), mod_count, n_power, batch_size,
+                            stream);
+    }
+
+    template <typename T>
+    __host__ void GPU_PolyMul(T* device_a, T* device_b, T* device_out, Root<T>* forward_table,
+                              Root<T>* inverse_table, Modulus<T> modulus, ntt_configuration<T> cfg,
+                              int batch_size)
+    {
+        ntt_configuration<T> f = cfg;
+        f.ntt_type = FORWARD;
+        f.ntt_layout = PerPolynomial;
+        GPU_NTT<T>(device_a, device_a, forward_table, modulus, f, batch_size);
+        GPU_NTT<T>(device_b, device_b, forward_table, modulus, f, batch_size);
+        pointwise_launch<T>(device_a, device_b, device_out, nullptr, modulus, 1, cfg.n_power, batch_size, cfg.stream);
+        f.ntt_type = INVERSE;
+        GPU_INTT<T>(device_out, device_out, inverse_table, modulus, f, batch_size);
+    }
+    template <typename T>
+    __host__ void GPU_PolyMul(T* device_a, T* device_b, T* device_out, Root<T>* forward_table,
+                              Root<T>* inverse_table, Modulus<T>* modulus, ntt_rns_configuration<T> cfg,
+                              int batch_size, int mod_count)
+    {
+        ntt_rns_configuration<T> f = cfg;
+        f.ntt_type = FORWARD;
+        f.ntt_layout = PerPolynomial;
+        GPU_NTT<T>(device_a, device_a, forward_table, modulus, f, batch_size, mod_count);
+        GPU_NTT<T>(device_b, device_b, forward_table, modulus, f, batch_size, mod_count);
+        pointwise_launch<T>(device_a, device_b, device_out, modulus, Modulus<T>(), mod_count, cfg.n_power, batch_size,
+                            cfg.stream);
+        f.ntt_type = INVERSE;
+        GPU_INTT<T>(device_out, device_out, inverse_table, modulus, f, batch_size, mod_count);
+    }
+
+#define GPUNTT_INST_POLYMUL(T)                                                                                    \
+    template __host__ void GPU_PolyMul<T>(T*, T*, T*, Root<T>*, Root<T>*, Modulus<T>, ntt_configuration<T>, int);  \
+    template __host__ void GPU_PolyMul<T>(T*, T*, T*, Root<T>*, Root<T>*, Modulus<T>*, ntt_rns_configuration<T>,   \
+                                          int, int);                                                              \
+    template __host__ void GPU_PointwiseMul<T>(T*, T*, T*, Modulus<T>, int, int, stream_t);                        \
+    template __host__ void GPU_PointwiseMul<T>(T*, T*, T*, Modulus<T>*, int, int, int, stream_t);
+    GPUNTT_INST_POLYMUL(Data32)
+    GPUNTT_INST_POLYMUL(Data64)
+#undef GPUNTT_INST_POLYMUL
+
     // ---------------------------------------------------------------- ordered RNS ----
     namespace
     {

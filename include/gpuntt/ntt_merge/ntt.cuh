@@ -124,4 +124,30 @@ namespace gpuntt
                                                Modulus<T>* modulus, ntt_rns_configuration<T> cfg,
                                                int batch_size, int mod_count, int* order);
 
+    // ---- extension (not in the reference GPU API) ------------------------------------------
+    // Polynomial product in the ring Z_q[X]/(X^N -+ 1), the composition the reference's CPU
+    // example checks against schoolbook multiplication (NTTCPU<T>::mult between ntt() and
+    // intt(), example/ntt_merge/test_cpu_merge_ntt.cu:69-101):
+    //     device_out = INTT( NTT(device_a) (.) NTT(device_b) )
+    // forward_table / inverse_table as for GPU_NTT / GPU_INTT (omega tables for X_N_minus = cyclic
+    // product, psi tables for X_N_plus = negacyclic product); cfg.mod_inverse = N^-1 mod q.
+    // device_a and device_b are overwritten with their transforms; device_out may alias either.
+    template <typename T>
+    __host__ void GPU_PolyMul(T* device_a, T* device_b, T* device_out, Root<T>* forward_table,
+                              Root<T>* inverse_table, Modulus<T> modulus, ntt_configuration<T> cfg,
+                              int batch_size);
+    // RNS: polynomial p uses modulus p % mod_count, tables at (p % mod_count) << n_power
+    template <typename T>
+    __host__ void GPU_PolyMul(T* device_a, T* device_b, T* device_out, Root<T>* forward_table,
+                              Root<T>* inverse_table, Modulus<T>* modulus, ntt_rns_configuration<T> cfg,
+                              int batch_size, int mod_count);
+    // device_out[i] = device_a[i] * device_b[i] mod q (per-polynomial modulus in the RNS form); the
+    // pointwise step on its own, all three pointers may alias
+    template <typename T>
+    __host__ void GPU_PointwiseMul(T* device_a, T* device_b, T* device_out, Modulus<T> modulus, int n_power,
+                                   int batch_size, stream_t stream);
+    template <typename T>
+    __host__ void GPU_PointwiseMul(T* device_a, T* device_b, T* device_out, Modulus<T>* modulus, int n_power,
+                                   int batch_size, int mod_count, stream_t stream);
+
 } // namespace gpuntt

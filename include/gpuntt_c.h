@@ -118,6 +118,24 @@ extern "C"
                                     int reduction_poly, const uint64_t* mod_inverse, void* stream,
                                     int batch_size, int mod_count, const int* order);
 
+    /* ---- extension: polynomial product out = INTT(NTT(a) (.) NTT(b)) in Z_q[X]/(X^N -+ 1), the
+     * composition of the reference's CPU example (test_cpu_merge_ntt.cu:69-101); a and b are
+     * overwritten with their transforms, out may alias either; mod_inverse = N^-1 (RNS: device array) */
+    int gpuntt_polymul_u32(uint32_t* a, uint32_t* b, uint32_t* out, const uint32_t* forward_table,
+                           const uint32_t* inverse_table, gpuntt_modulus32 modulus, int n_power,
+                           int reduction_poly, uint32_t mod_inverse, void* stream, int batch_size);
+    int gpuntt_polymul_u64(uint64_t* a, uint64_t* b, uint64_t* out, const uint64_t* forward_table,
+                           const uint64_t* inverse_table, gpuntt_modulus64 modulus, int n_power,
+                           int reduction_poly, uint64_t mod_inverse, void* stream, int batch_size);
+    int gpuntt_polymul_rns_u32(uint32_t* a, uint32_t* b, uint32_t* out, const uint32_t* forward_table,
+                               const uint32_t* inverse_table, const gpuntt_modulus32* modulus,
+                               int n_power, int reduction_poly, const uint32_t* mod_inverse,
+                               void* stream, int batch_size, int mod_count);
+    int gpuntt_polymul_rns_u64(uint64_t* a, uint64_t* b, uint64_t* out, const uint64_t* forward_table,
+                               const uint64_t* inverse_table, const gpuntt_modulus64* modulus,
+                               int n_power, int reduction_poly, const uint64_t* mod_inverse,
+                               void* stream, int batch_size, int mod_count);
+
     /* ---- 4-Step NTT (cyclic, 12 <= n_power <= 24, in != out) ------------------------ */
     int gpuntt_4step_u32(const uint32_t* in, uint32_t* out, const uint32_t* n1_table,
                          const uint32_t* n2_table, const uint32_t* w_table,

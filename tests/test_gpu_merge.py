@@ -365,6 +365,58 @@ def test_rns_generic_kernels_walk_tiles_with_capped_grid(g):
     assert np.array_equal(g.to_host(d), x)
 
 
+@pytest.mark.parametrize("bits", [32, 64])
+def test_polymul_vs_schoolbook_and_oracle(g, bits):
+    """extension GPU_PolyMul = INTT(NTT(a) (.) NTT(b)): against schoolbook multiplication in the
+    ring (what example/ntt_merge/test_cpu_merge_ntt.cu:69-101 checks on the CPU) for small rings,
+    against the oracle's ntt / pointwise / intt composition for larger ones; cyclic and negacyclic"""
+    import torch
+    for logn, batch in ((4, 5), (9, 3), (12, 2), (14, 3)):
+        for poly in (O.X_N_plus, O.X_N_minus):
+            c = MergeCase(g, bits, logn, poly)
+            a = c.random(batch, 900 + logn)
+            b = c.random(batch, 950 + logn)
+            n = c.n
+            if logn <= 9:
+                want = np.concatenate([c.P.schoolbook(a[i * n:(i + 1) * n], b[i * n:(i + 1) * n], poly, c.oprm["mod"])
+                                       for i in range(batch)])
+            else:
+                want = c.P.merge_ntt(c.P.pointwise(c.P.merge_ntt(a, c.oprm), c.P.merge_ntt(b, c.oprm),
+                                                   c.oprm["mod"]), c.oprm, inverse=True)
+            da, db = g.to_device(a), g.to_device(b)
+            out = torch.zeros_like(da)
+            g.GPU_PolyMul(da, db, out, c.fwd_dev, c.inv_dev, c.prm.modulus, c.cfg(inverse=True), batch)
+            torch.cuda.synchronize()
+            assert np.array_equal(g.to_host(out), want), (bits, logn, poly)
+            # in place on a
+            da, db = g.to_device(a), g.to_device(b)
+            g.GPU_PolyMul(da, db, da, c.fwd_dev, c.inv_dev, c.prm.modulus, c.cfg(inverse=True), batch)
+            torch.cuda.synchronize()
+            assert np.array_equal(g.to_host(da), want)
+
+
+def test_polymul_rns(g):
+    import torch
+    logn, batch = 13, 7
+    from gpu_utils import find_ntt_factors
+    fl = [find_ntt_factors(58, logn), find_ntt_factors(60, logn), find_ntt_factors(62, logn)]
+    cases, fwd, inv, mods, ninv = _rns_setup(g, 64, logn, O.X_N_plus, fl)
+    n = 1 << logn
+    a = np.concatenate([cases[p % 3].P.splitmix(270 + p, 0, n, cases[p % 3].q) for p in range(batch)])
+    b = np.concatenate([cases[p % 3].P.splitmix(370 + p, 0, n, cases[p % 3].q) for p in range(batch)])
+    want = []
+    for p in range(batch):
+        c = cases[p % 3]
+        fa, fb = c.P.merge_ntt(a[p * n:(p + 1) * n], c.oprm), c.P.merge_ntt(b[p * n:(p + 1) * n], c.oprm)
+        want.append(c.P.merge_ntt(c.P.pointwise(fa, fb, c.oprm["mod"]), c.oprm, inverse=True))
+    da, db = g.to_device(a), g.to_device(b)
+    out = torch.zeros_like(da)
+    cfg = g.ntt_rns_configuration(n_power=logn, ntt_type=g.INVERSE, reduction_poly=O.X_N_plus, mod_inverse=ninv)
+    g.GPU_PolyMul(da, db, out, fwd, inv, mods, cfg, batch, 3)
+    torch.cuda.synchronize()
+    assert np.array_equal(g.to_host(out), np.concatenate(want))
+
+
 def test_small_and_odd_sized_moduli_u64(g):
     """64-bit words holding small primes (14..50 bit): exercises the shift-free branch of the
     one-multiply final normalisation and the lazy bounds far from the 60-bit case."""

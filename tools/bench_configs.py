@@ -81,6 +81,37 @@ def merge_case(g, bits, logn, batch, poly, iters, name, inverse=False):
     emit(name, bits, "merge-inv" if inverse else "merge-fwd", logn, batch, time_ms(fn, iters), ok)
 
 
+def polymul_case(g, bits, logn, batch, iters, name):
+    """extension GPU_PolyMul: out = INTT(NTT(a) (.) NTT(b)), negacyclic; reported per product with the
+    algorithmic bytes of its three transforms + the pointwise step (3 x 2N + 3N words)."""
+    import torch
+    P = O.Port(bits)
+    prm = g.NTTParameters(logn, g.X_N_plus, bits)
+    oprm = P.merge_params(logn, O.X_N_plus)
+    n = 1 << logn
+    a = P.splitmix(0x5EED0010, 0, batch * n, prm.modulus.value)
+    b = P.splitmix(0x5EED0011, 0, batch * n, prm.modulus.value)
+    da, db = g.to_device(a), g.to_device(b)
+    out = torch.empty_like(da)
+    tf, ti = g.to_device(prm.forward_table_device_order), g.to_device(prm.inverse_table_device_order)
+    cfg = g.ntt_configuration(n_power=logn, ntt_type=g.INVERSE, reduction_poly=g.X_N_plus,
+                              mod_inverse=prm.n_inv)
+    g.GPU_PolyMul(da, db, out, tf, ti, prm.modulus, cfg, batch)
+    torch.cuda.synchronize()
+    p = batch - 1
+    sl = slice(p * n, (p + 1) * n)
+    want = P.merge_ntt(P.pointwise(P.merge_ntt(a[sl], oprm), P.merge_ntt(b[sl], oprm), oprm["mod"]), oprm,
+                       inverse=True)
+    ok = np.array_equal(g.to_host(out)[sl], want)
+    fn = lambda: g.GPU_PolyMul(da, db, out, tf, ti, prm.modulus, cfg, batch)  # noqa: E731
+    ms = time_ms(fn, iters)
+    d = {"name": name, "dtype": "u%d" % bits, "algo": "polymul-negacyclic", "log2N": logn, "batch": batch,
+         "ms": round(ms, 5), "products_per_s": round(batch / (ms * 1e-3), 1),
+         "alg_GBps": round(9 * n * (bits // 8) * batch / (ms * 1e-3) / 1e9, 1), "checked": bool(ok)}
+    d["frac_of_8TBps"] = round(d["alg_GBps"] / PEAK, 4)
+    print(json.dumps(d), flush=True)
+
+
 def rns_case(g, logn, batch, iters, name, golden_dir):
     import torch
     rns = json.load(open(os.path.join(golden_dir, "rns_c5.json")))
@@ -168,6 +199,7 @@ def main():
         merge_case(g, 32, 14, 1024, g.X_N_minus, args.iters, "C4 Merge u32 2^14 x1024 (per-GPU shard of 8192)")
         merge_case(g, 32, 14, 8192, g.X_N_minus, args.iters, "C4full Merge u32 2^14 x8192 (whole batch on one GPU)")
         rns_case(g, 16, 512, args.iters, "C5 RNS Merge u64 2^16 x512, 8 primes, X^N+1", golden)
+        polymul_case(g, 64, 16, 1024, args.iters, "PolyMul u64 2^16 x1024 (extension)")
     if args.what in ("sweep32", "sweep64"):
         bits = int(args.what[-2:])
         for logn in range(12, 25):
