@@ -274,6 +274,85 @@ namespace gpuntt
             return true;
         }
 
+        // Natural-order inverse transform: the three forward sweeps run backwards.
+        //   1. transposed load of the column-major input (the forward result) + the low row stages
+        //      (Gentleman-Sande) on 2^K-column runs of 2^(12-K) rows, row-major `out`, lazy;
+        //   2. n2 > 512: STRIDED inverse pass over row bits [8, log2 n2), in place;
+        //   3. W^-1 product on the way in + STRIDED inverse pass over the top log2(n1) bits of the
+        //      N-ring with N^-1 folded into its last stage: canonical, natural order, in `out`.
+        // The caller's inverse W table is indexed W[i*n2 + j] = root^-(bitrev(j)*i) (reference
+        // nttparameters.cu:430-444); sweep 3 needs root^-(bitrev(k)*j) at [k*n2 + j], i.e. the same
+        // matrix with both indices bit-reversed -- the pair preparation re-indexes it.  `in` is
+        // left intact.
+        template <typename T>
+        bool fourstep_natural_inverse_lazy(T* in, T* out, const T* n1_table, const T* n2_table,
+                                           const T* w_table, const Modulus<T>& mod, T ninv, int n_power,
+                                           int log_n1, int log_n2, int batch_size, hipStream_t stream)
+        {
+            using TW = lazy::Tw<T>;
+            if (mod.bit > T(lazy::Mod<T>::MAX_BIT) || mod.value < 3 || ninv >= mod.value)
+                return false;
+            if (const char* e = std::getenv("GPUNTT_PATH"))
+                if (std::strcmp(e, "generic") == 0)
+                    return false;
+            const size_t n1 = size_t(1) << log_n1, n2 = size_t(1) << log_n2, n = size_t(1) << n_power;
+            auto* ws = static_cast<TW*>(host::lazy_workspace(stream, sizeof(TW) * (n1 + n + n2 + 2)));
+            TW* ws_n1 = ws;
+            TW* ws_w = ws + n1;
+            TW* ws_n2 = ws + n1 + n;
+            host::launch_prep<T>(n1_table, ws_n1, nullptr, mod.value, 1, log_n1, false, 0, nullptr, nullptr,
+                                 nullptr, nullptr, stream, nullptr, &ninv); // N^-1 rides on the very last stage
+            host::launch_prep_pairs_brev<T>(w_table, ws_w, log_n1, log_n2, mod.value, stream);
+            host::launch_prep<T>(n2_table, ws_n2, nullptr, mod.value, 1, log_n2, false, 0, nullptr, nullptr,
+                                 nullptr, nullptr, stream);
+
+            kern::LazyArgsT<T> a{};
+            a.in = in;
+            a.out = out;
+            a.tw = ws_n2;
+            a.mods = nullptr;
+            a.q = mod.value;
+            a.q_bit = mod.bit;
+            a.q_mu = mod.mu;
+            a.ninv_arr = nullptr;
+            a.ninv = TW{0, 0};
+            a.go_flag = nullptr;
+            a.norm = lazy::make_norm_const(static_cast<uint64_t>(mod.value), static_cast<uint64_t>(mod.bit));
+            a.norm_arr = nullptr;
+            a.w_pairs = nullptr;
+            a.n2_log = log_n1; // input column stride
+            a.batch = batch_size;
+            a.total = static_cast<unsigned long long>(batch_size) << n_power;
+            a.n = log_n2;
+            a.poly_shift = n_power;
+            a.mod_count = 1;
+            a.p_lo = 0;
+            a.flags = 0u;
+            const int k_first = (log_n2 > 9) ? 8 : log_n2;
+            host::launch_fourstep_nat_first_inv_lazy<T>(k_first, a, stream);
+
+            if (log_n2 > 9)
+            {
+                kern::LazyArgsT<T> b = a;
+                b.in = out;
+                b.poly_shift = log_n2;
+                b.p_lo = k_first;
+                const host::Pass sp{false, log_n2 - k_first, k_first};
+                host::launch_pass_lazy<T, true>(sp, 12, false, false, b, stream);
+            }
+
+            kern::LazyArgsT<T> c = a;
+            c.in = out;
+            c.tw = ws_n1;
+            c.w_pairs = ws_w;
+            c.n = n_power;
+            c.poly_shift = n_power;
+            c.p_lo = log_n2;
+            c.ninv = TW{ninv, host::shoup_host(ninv, mod.value)};
+            host::launch_fourstep_nat_last_inv_lazy<T>(log_n1, c, stream);
+            return true;
+        }
+
         template <typename T>
         void fourstep_dispatch(T* in, T* out, const T* n1_table, const T* n2_table, const T* w_table,
                                const Modulus<T>* mods, Modulus<T> mod, int mod_count,
@@ -369,6 +448,10 @@ namespace gpuntt
         }
         else
         {
+            if (fourstep_natural_inverse_lazy<T>(device_in, device_out, n1_root_of_unity_table,
+                                                 n2_root_of_unity_table, W_root_of_unity_table, modulus,
+                                                 cfg.mod_inverse, cfg.n_power, l1, l2, batch_size, cfg.stream))
+                return;
             // NTT_4STEP_CPU::intt_first_transpose: flat[i*n2+j] = x[i + j*n1]
             transpose_on<T>(device_in, device_out, n2, n1, cfg.n_power, batch_size, cfg.stream);
         }

@@ -81,6 +81,21 @@ namespace gpuntt
         extern template void launch_fourstep_nat_last_lazy<uint64_t>(int, bool, const kern::LazyArgsT<uint64_t>&, hipStream_t);
         extern template void launch_fourstep_nat_last_lazy<uint32_t>(int, bool, const kern::LazyArgsT<uint32_t>&, hipStream_t);
 
+        // natural-order inverse 4-step passes (instantiated with the inverse kernels)
+        template <typename T>
+        void launch_fourstep_nat_first_inv_lazy(int k, const kern::LazyArgsT<T>& a, hipStream_t stream);
+        template <typename T>
+        void launch_fourstep_nat_last_inv_lazy(int log_n1, const kern::LazyArgsT<T>& a, hipStream_t stream);
+        extern template void launch_fourstep_nat_first_inv_lazy<uint64_t>(int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
+        extern template void launch_fourstep_nat_first_inv_lazy<uint32_t>(int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
+        extern template void launch_fourstep_nat_last_inv_lazy<uint64_t>(int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
+        extern template void launch_fourstep_nat_last_inv_lazy<uint32_t>(int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
+        // W table of the inverse direction re-indexed for it: dst[k*n2 + j] = pair(src[brev(k)*n2 + brev(j)])
+        template <typename T>
+        void launch_prep_pairs_brev(const T* src, lazy::Tw<T>* dst, int log_n1, int log_n2, T q, hipStream_t stream);
+        extern template void launch_prep_pairs_brev<uint64_t>(const uint64_t*, lazy::Tw64*, int, int, uint64_t, hipStream_t);
+        extern template void launch_prep_pairs_brev<uint32_t>(const uint32_t*, lazy::Tw32*, int, int, uint32_t, hipStream_t);
+
         // host Shoup companion floor(w * 2^W / q)
         inline uint64_t shoup_host(uint64_t w, uint64_t q)
         {

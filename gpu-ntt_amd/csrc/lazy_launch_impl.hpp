@@ -221,6 +221,51 @@ namespace gpuntt
             GPUNTT_HIP_CHECK(hipGetLastError());
         }
 
+        // natural-order inverse 4-step: transposing first row pass (k stages) and the column pass with W^-1
+        template <typename T>
+        void launch_fourstep_nat_first_inv_lazy(int k, const kern::LazyArgsT<T>& a, hipStream_t stream)
+        {
+            constexpr int TLOG = 12;
+            const unsigned grid = static_cast<unsigned>(a.total >> TLOG);
+            switch (k)
+            {
+#define GPUNTT_CASE(KK)                                                                          \
+    case KK:                                                                                      \
+        hipLaunchKernelGGL((kern::fourstep_nat_first_inv_lazy<T, TLOG, KK>), dim3(grid),          \
+                           dim3(kern::LTile<TLOG>::NT), 0, stream, a);                            \
+        break;
+                GPUNTT_CASE(7)
+                GPUNTT_CASE(8)
+                GPUNTT_CASE(9)
+#undef GPUNTT_CASE
+                default:
+                    throw std::invalid_argument("internal: bad natural-order 4-step row pass");
+            }
+            GPUNTT_HIP_CHECK(hipGetLastError());
+        }
+        template <typename T>
+        void launch_fourstep_nat_last_inv_lazy(int log_n1, const kern::LazyArgsT<T>& a, hipStream_t stream)
+        {
+            constexpr int TLOG = 12;
+            const unsigned grid = static_cast<unsigned>(a.total >> TLOG);
+            switch (log_n1)
+            {
+#define GPUNTT_CASE(KK)                                                                          \
+    case KK:                                                                                      \
+        hipLaunchKernelGGL((kern::fourstep_nat_last_inv_lazy<T, TLOG, KK>), dim3(grid),           \
+                           dim3(kern::LTile<TLOG>::NT), 0, stream, a);                            \
+        break;
+                GPUNTT_CASE(5)
+                GPUNTT_CASE(6)
+                GPUNTT_CASE(7)
+                GPUNTT_CASE(8)
+#undef GPUNTT_CASE
+                default:
+                    throw std::invalid_argument("internal: bad 4-step n1");
+            }
+            GPUNTT_HIP_CHECK(hipGetLastError());
+        }
+
         template <typename T, bool INV>
         void launch_pass_lazy(const Pass& p, int tile_log, bool in_first, bool last,
                               const kern::LazyArgsT<T>& a, hipStream_t stream)

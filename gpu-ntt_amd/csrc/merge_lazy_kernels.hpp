@@ -398,9 +398,56 @@ namespace gpuntt
                         return static_cast<const T*>(a.in)[f];
                     };
                     const T* src = static_cast<const T*>(a.in); // may alias a.out (in-place calls)
-                    if constexpr (DIRECT_IO)
+                    if constexpr (SEG && INV)
                     {
-                        if (plain_io)
+                        // natural-order inverse 4-step, first pass: the tile's 2^RB rows x 2^K columns
+                        // come from the column-major side -- in[((seg << K) + c) * n1 + row0 + r] -- as
+                        // runs of 2^RB rows, and are transposed through LDS into the row-major tile
+                        constexpr int RB = TL - K;
+                        const unsigned lane = (static_cast<unsigned>(t >> RB) << a.n2_log) + (t & ((1 << RB) - 1));
+                        const unsigned long long in_base =
+                            (fst_poly << a.poly_shift) + ((static_cast<unsigned long long>(fst_seg) << K) << a.n2_log) +
+                            (fst_tile << RB);
+                        T tmp[EPT];
+#pragma unroll
+                        for (int j = 0; j < EPT; j++)
+                            tmp[j] = (src + (in_base + (static_cast<unsigned long long>((NT >> RB) * j) << a.n2_log)))[lane];
+#pragma unroll
+                        for (int j = 0; j < EPT; j++)
+                        {
+                            const int o = t + NT * j;
+                            lds[lds_pad_t<K>(((o & ((1 << RB) - 1)) << K) | (o >> RB))] = tmp[j];
+                        }
+                        __syncthreads();
+#pragma unroll
+                        for (int j = 0; j < EPT; j++)
+                            v[j] = lds[lds_pad_t<K>(elem_of<WL>(t, j))];
+                        __syncthreads(); // the exchanges below reuse the buffer in the e + (e >> 4) layout
+                    }
+                    else if constexpr (DIRECT_IO)
+                    {
+                        if constexpr (WMUL && INV)
+                        {
+                            // natural-order inverse 4-step, last pass: W^-1[f mod N] on the way in
+                            const unsigned lane = map.part(elem_of<WL>(t, 0));
+                            const unsigned long long wb = map.base & nmask;
+#pragma unroll
+                            for (int half = 0; half < 2; half++)
+                            {
+                                TW wv[EPT / 2];
+#pragma unroll
+                                for (int jj = 0; jj < EPT / 2; jj++)
+                                {
+                                    const int j = half * (EPT / 2) + jj;
+                                    wv[jj] = (a.w_pairs + (wb + map.part(static_cast<unsigned>(j) << WL)))[lane];
+                                    v[j] = (src + (map.base + map.part(static_cast<unsigned>(j) << WL)))[lane];
+                                }
+#pragma unroll
+                                for (int jj = 0; jj < EPT / 2; jj++)
+                                    v[half * (EPT / 2) + jj] = m.mul(v[half * (EPT / 2) + jj], wv[jj]);
+                            }
+                        }
+                        else if (plain_io)
                         {
                             const unsigned lane = map.part(elem_of<WL>(t, 0));
 #pragma unroll
@@ -543,7 +590,7 @@ namespace gpuntt
                             }
                         });
                     }
-                    if constexpr (FST)
+                    if constexpr (FST && !(SEG && INV))
                     {
                         static_assert(!FST || (CONTIG && K >= 4 && K <= 9), "4-step row runs are 16..512 long");
                         constexpr int RB = TL - K; // log2 rows per tile
@@ -594,7 +641,7 @@ namespace gpuntt
                     }
                     else if constexpr (DIRECT_IO)
                     {
-                        if constexpr (WMUL)
+                        if constexpr (WMUL && !INV)
                         {
                             // W[f mod N] rides on the store; halves of 8 bound the live W pairs
                             const unsigned lane = map.part(elem_of<WL>(t, 0));
@@ -645,7 +692,8 @@ namespace gpuntt
                             const T* lc = lds + lds_pad(t);
 #pragma unroll
                             for (int j = 0; j < EPT; j++)
-                                (a.out + (map.base + static_cast<unsigned>(NT * j)))[t] = lc[NT * j + ((NT * j) >> 4)];
+                                (a.out + (map.base + map.part(static_cast<unsigned>(NT * j))))[map.part(static_cast<unsigned>(t))] =
+                                    lc[NT * j + ((NT * j) >> 4)];
                         }
                         else
                         {
@@ -735,6 +783,39 @@ namespace gpuntt
             const unsigned seg = rest % runs;
             const unsigned long long poly = rest / runs;
             pass_body<T, TLOG, false, false, true, K, IN_BOUND, true, 2>(a, lds, a.q, a.q_bit, a.q_mu, 0, poly, rb, -1, seg);
+        }
+
+        // natural-order 4-step, inverse direction (the forward passes run backwards):
+        //   first pass  transposed load of the column-major input + the 2^K low row stages
+        //               (Gentleman-Sande), stored row-major, lazy; block order as fourstep_nat_last_lazy
+        template <typename T, int TLOG, int K>
+        __global__ __launch_bounds__(LTile<TLOG>::NT, LOcc<TLOG>::WAVES) void fourstep_nat_first_inv_lazy(LazyArgsT<T> a)
+        {
+            __shared__ T lds[LTile<TLOG>::LDS_ELEMS_FST];
+            constexpr int RB = TLOG - K;
+            const unsigned row_blocks = 1u << (a.n2_log - RB);
+            const unsigned runs = 1u << (a.n - K);
+            const unsigned rb = blockIdx.x % row_blocks;
+            const unsigned rest = blockIdx.x / row_blocks;
+            const unsigned seg = rest % runs;
+            const unsigned long long poly = rest / runs;
+            pass_body<T, TLOG, false, true, true, K, 1, false, 2>(a, lds, a.q, a.q_bit, a.q_mu, 0, poly, rb, -1, seg);
+        }
+        //   last pass   W^-1 product on the way in, then the n1-point column transforms over the top
+        //               log2 n1 bits of the N-ring with n^-1 folded into the final stage; canonical,
+        //               natural order, in place; block b -> (tile b / batch, poly b % batch)
+        template <typename T, int TLOG, int K>
+        __global__ __launch_bounds__(LTile<TLOG>::NT, LOcc<TLOG>::WAVES) void fourstep_nat_last_inv_lazy(LazyArgsT<T> a)
+        {
+            using G = LGeo<TLOG, false, K>;
+            using M = lazy::Mod<T>;
+            using SCH = PassSched<TLOG, true, false, K, M::TB, M::LIMIT, M::TB>;
+            constexpr bool NEEDS_LDS = (G::NR > 1) || (SCH::wl_of(0) < 4);
+            __shared__ T lds[NEEDS_LDS ? LTile<TLOG>::LDS_ELEMS : 1];
+            const unsigned long long poly = blockIdx.x % static_cast<unsigned>(a.batch);
+            const unsigned long long tile = blockIdx.x / static_cast<unsigned>(a.batch);
+            const long long blk = static_cast<long long>((poly << (a.n - TLOG)) | tile);
+            pass_body<T, TLOG, false, true, false, K, M::TB, true, 0, true>(a, lds, a.q, a.q_bit, a.q_mu, 0, 0, 0, blk);
         }
 
         // 4-step phase 1 kernel; grid = batch * N / TILE blocks, block b -> (tile b / batch, poly b % batch)

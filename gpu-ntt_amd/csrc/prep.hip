@@ -173,6 +173,22 @@ namespace gpuntt
             const T w = src[gid];
             dst[gid] = lazy::Tw<T>{w, shoup_quotient_r<T>(w, q, rinv)};
         }
+        // plain residues -> Shoup pairs with both matrix indices bit-reversed:
+        // dst[k * n2 + j] = pair(src[brev(k, log n1) * n2 + brev(j, log n2)])
+        template <typename T>
+        __global__ __launch_bounds__(256) void prep_pairs_brev(const T* __restrict__ src, lazy::Tw<T>* __restrict__ dst,
+                                                               int log_n1, int log_n2, T q, T rinv)
+        {
+            const unsigned long long gid = blockIdx.x * 256ull + threadIdx.x;
+            if (gid >= (1ull << (log_n1 + log_n2)))
+                return;
+            const unsigned k = static_cast<unsigned>(gid >> log_n2);
+            const unsigned j = static_cast<unsigned>(gid & ((1ull << log_n2) - 1));
+            const unsigned kr = __brev(k) >> (32 - log_n1);
+            const unsigned jr = __brev(j) >> (32 - log_n2);
+            const T w = src[(static_cast<unsigned long long>(kr) << log_n2) + jr];
+            dst[gid] = lazy::Tw<T>{w, shoup_quotient_r<T>(w, q, rinv)};
+        }
     } // namespace kern
 
     namespace host
@@ -270,6 +286,17 @@ namespace gpuntt
                                recip_norm_host<T>(q));
             GPUNTT_HIP_CHECK(hipGetLastError());
         }
+        template <typename T>
+        void launch_prep_pairs_brev(const T* src, lazy::Tw<T>* dst, int log_n1, int log_n2, T q, hipStream_t stream)
+        {
+            const unsigned long long count = 1ull << (log_n1 + log_n2);
+            const unsigned grid = static_cast<unsigned>((count + 255) / 256);
+            hipLaunchKernelGGL((kern::prep_pairs_brev<T>), dim3(grid), dim3(256), 0, stream, src, dst, log_n1, log_n2, q,
+                               recip_norm_host<T>(q));
+            GPUNTT_HIP_CHECK(hipGetLastError());
+        }
+        template void launch_prep_pairs_brev<uint64_t>(const uint64_t*, lazy::Tw64*, int, int, uint64_t, hipStream_t);
+        template void launch_prep_pairs_brev<uint32_t>(const uint32_t*, lazy::Tw32*, int, int, uint32_t, hipStream_t);
         template void launch_prep_pairs<uint64_t>(const uint64_t*, lazy::Tw64*, unsigned long long, uint64_t,
                                                   hipStream_t);
         template void launch_prep_pairs<uint32_t>(const uint32_t*, lazy::Tw32*, unsigned long long, uint32_t,

@@ -183,6 +183,22 @@ def fourstep_case(g, bits, logn, batch, iters, name, check=True):
     nat = lambda: g.GPU_4STEP_NTT_NaturalOrder(a, b, *tf, p4.modulus, cf, batch)  # noqa: E731
     emit(name + "-fwd-natural-fused", bits, "4step-fwd-natural-fused", logn, batch, time_ms(nat, iters), ok2)
 
+    # inverse of the natural-order result: three-call form (first transpose on the device) vs the fused entry
+    a.copy_(g.to_device(x))
+    g.GPU_4STEP_NTT_NaturalOrder(a, b, *tf, p4.modulus, cf, batch)  # b = forward result
+    c = torch.empty_like(a)
+    g.GPU_4STEP_NTT_NaturalOrder(b, c, *ti, p4.modulus, ci, batch)
+    torch.cuda.synchronize()
+    ok3 = np.array_equal(g.to_host(c)[:n], x[:n])
+
+    def inv3():
+        g.GPU_Transpose(b, a, p4.n2, p4.n1, logn, batch)
+        g.GPU_4STEP_NTT(a, c, *ti, p4.modulus, ci, batch)
+        g.GPU_Transpose(c, a, p4.n1, p4.n2, logn, batch)
+    emit(name + "-inv+2transposes", bits, "4step-inv-natural", logn, batch, time_ms(inv3, iters), ok3)
+    invn = lambda: g.GPU_4STEP_NTT_NaturalOrder(b, c, *ti, p4.modulus, ci, batch)  # noqa: E731
+    emit(name + "-inv-natural-fused", bits, "4step-inv-natural-fused", logn, batch, time_ms(invn, iters), ok3)
+
 
 def main():
     ap = argparse.ArgumentParser()
