@@ -96,5 +96,21 @@ int main(int argc, char* argv[])
     bool check2 = check_result(Output_Host.data(), flat_in.data(), static_cast<int>(Output_Host.size()));
     if (check2)
         cout << "All Correct (inverse)." << endl;
-    return (check && check2) ? EXIT_SUCCESS : EXIT_FAILURE;
+
+    // extension: the same two pipelines as single calls (GPU_4STEP_NTT_NaturalOrder)
+    GPUNTT_CUDA_CHECK(hipMemcpy(Input_Datas, flat_in.data(), flat_in.size() * sizeof(TestDataType),
+                                hipMemcpyHostToDevice));
+    ntt4step_configuration<TestDataType> cfg_nat = {
+        .n_power = LOGN, .ntt_type = FORWARD, .mod_inverse = 0, .stream = 0};
+    GPU_4STEP_NTT_NaturalOrder(Input_Datas, Output_Datas, t1, t2, W, parameters.modulus, cfg_nat, BATCH);
+    GPUNTT_CUDA_CHECK(hipMemcpy(Output_Host.data(), Output_Datas,
+                                Output_Host.size() * sizeof(TestDataType), hipMemcpyDeviceToHost));
+    bool check3 = check_result(Output_Host.data(), flat_expected.data(), static_cast<int>(Output_Host.size()));
+    GPU_4STEP_NTT_NaturalOrder(Output_Datas, Input_Datas, it1, it2, iW, parameters.modulus, cfg_intt, BATCH);
+    GPUNTT_CUDA_CHECK(hipMemcpy(Output_Host.data(), Input_Datas,
+                                Output_Host.size() * sizeof(TestDataType), hipMemcpyDeviceToHost));
+    bool check4 = check_result(Output_Host.data(), flat_in.data(), static_cast<int>(Output_Host.size()));
+    if (check3 && check4)
+        cout << "All Correct (natural order, one call)." << endl;
+    return (check && check2 && check3 && check4) ? EXIT_SUCCESS : EXIT_FAILURE;
 }

@@ -99,6 +99,29 @@ template <typename TestDataType> int run(int LOGN, int BATCH)
     if (check2)
         cout << "All Correct for PerPolynomial INTT." << endl;
 
+    // extension: ring product INTT(NTT(a) . NTT(b)) on the GPU against the CPU composition the
+    // reference's example checks (NTTCPU ntt / mult / intt, test_cpu_merge_ntt.cu:69-101)
+    bool check3 = true;
+    {
+        vector<TestDataType> b_host(parameters.n);
+        for (auto& x : b_host)
+            x = dis(gen);
+        vector<TestDataType> fa = generator.ntt(input1[0]), fb = generator.ntt(b_host);
+        vector<TestDataType> fc = generator.mult(fa, fb);
+        vector<TestDataType> want = generator.intt(fc);
+        GPUNTT_CUDA_CHECK(hipMemcpy(InOut_Datas, input1[0].data(), parameters.n * sizeof(TestDataType),
+                                    hipMemcpyHostToDevice));
+        GPUNTT_CUDA_CHECK(hipMemcpy(Out_Datas, b_host.data(), parameters.n * sizeof(TestDataType),
+                                    hipMemcpyHostToDevice));
+        GPU_PolyMul(InOut_Datas, Out_Datas, Out_Datas, Forward_Omega_Table_Device, Inverse_Omega_Table_Device,
+                    parameters.modulus, cfg_intt, 1);
+        GPUNTT_CUDA_CHECK(hipMemcpy(Output_Host.data(), Out_Datas, parameters.n * sizeof(TestDataType),
+                                    hipMemcpyDeviceToHost));
+        check3 = check_result(Output_Host.data(), want.data(), static_cast<int>(parameters.n));
+        if (check3)
+            cout << "All Correct for GPU_PolyMul." << endl;
+    }
+
     // argument checking keeps the reference's exception type and text
     bool threw = false;
     try
@@ -116,7 +139,7 @@ template <typename TestDataType> int run(int LOGN, int BATCH)
     GPUNTT_CUDA_CHECK(hipFree(Forward_Omega_Table_Device));
     GPUNTT_CUDA_CHECK(hipFree(Inverse_Omega_Table_Device));
     GPUNTT_CUDA_CHECK(hipFree(test_modulus));
-    return (check && check2 && threw) ? EXIT_SUCCESS : EXIT_FAILURE;
+    return (check && check2 && check3 && threw) ? EXIT_SUCCESS : EXIT_FAILURE;
 }
 
 int main(int argc, char* argv[])

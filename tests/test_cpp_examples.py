@@ -36,6 +36,7 @@ def test_cpu_examples_build_and_pass(pkg):
 def test_gpu_merge_example(logn, batch, dt):
     out = _run("example_merge_ntt", logn, batch, dt)
     assert "All Correct for PerPolynomial NTT." in out and "All Correct for PerPolynomial INTT." in out
+    assert "All Correct for GPU_PolyMul." in out
 
 
 @pytest.mark.gpu
@@ -43,3 +44,4 @@ def test_gpu_merge_example(logn, batch, dt):
 def test_gpu_4step_example(logn, batch):
     out = _run("example_4step_ntt", logn, batch)
     assert "All Correct." in out and "All Correct (inverse)." in out
+    assert "All Correct (natural order, one call)." in out
