@@ -89,9 +89,10 @@ namespace gpuntt
         void fourstep_run(T* in, T* out, const T* n1_table, const T* n2_table, const T* w_table,
                           const Modulus<T>* mods, Modulus<T> mod, int mod_count, const T* ninv_arr,
                           T ninv, int n_power, int log_n1, int log_n2, int batch_size,
-                          hipStream_t stream)
+                          hipStream_t stream, const unsigned* skip_flag = nullptr)
         {
             kern::PassArgs<T> a{};
+            a.skip_flag = skip_flag;
             a.in = in;
             a.out = out;
             a.roots = n1_table;
@@ -135,43 +136,63 @@ namespace gpuntt
 
         // fast path: single modulus with lazy headroom.  Workspace layout (Shoup pairs):
         //   [0, n1)  n1 table by stage | [n1, n1 + N)  W matrix | [.., + n2)  n2 table by stage
+        // mods_dev != nullptr: the RNS overload with ONE modulus (how the reference's own example calls
+        // the 4-step, test_4step_ntt.cu:126-146): modulus and n^-1 live in device memory, so the first
+        // preparation kernel classifies the modulus and publishes the go-flag that the fast kernels and
+        // the generic kernels (enqueued behind them with the flag as skip_flag) both test -- the same
+        // dual launch as the RNS Merge calls.  `*go_flag_out` receives the flag (nullptr otherwise).
         template <typename T, bool INV>
         bool fourstep_run_lazy(T* in, T* out, const T* n1_table, const T* n2_table, const T* w_table,
                                const Modulus<T>& mod, T ninv, int n_power, int log_n1, int log_n2,
-                               int batch_size, hipStream_t stream)
+                               int batch_size, hipStream_t stream, const Modulus<T>* mods_dev = nullptr,
+                               const T* ninv_dev = nullptr, const unsigned** go_flag_out = nullptr)
         {
             using TW = lazy::Tw<T>;
-            if (mod.bit > T(lazy::Mod<T>::MAX_BIT) || mod.value < 3 || (INV && ninv >= mod.value))
+            if (mods_dev == nullptr &&
+                (mod.bit > T(lazy::Mod<T>::MAX_BIT) || mod.value < 3 || (INV && ninv >= mod.value)))
+                return false;
+            if (mods_dev != nullptr && INV && ninv_dev == nullptr)
                 return false;
             if (const char* e = std::getenv("GPUNTT_PATH"))
                 if (std::strcmp(e, "generic") == 0)
                     return false;
             const size_t n1 = size_t(1) << log_n1, n2 = size_t(1) << log_n2, n = size_t(1) << n_power;
-            auto* ws = static_cast<TW*>(host::lazy_workspace(stream, sizeof(TW) * (n1 + n + n2 + 2)));
+            // pairs: n1 table | W | n2 table | n^-1 ; then go-flag (16 B) and the normalisation constants
+            const size_t pairs = n1 + n + n2 + 2;
+            auto* ws = static_cast<TW*>(
+                host::lazy_workspace(stream, sizeof(TW) * pairs + 16 + sizeof(lazy::NormConst)));
             TW* ws_n1 = ws;
             TW* ws_w = ws + n1;
             TW* ws_n2 = ws + n1 + n;
-            host::launch_prep<T>(n1_table, ws_n1, nullptr, mod.value, 1, log_n1, false, 0, nullptr, nullptr,
-                                 nullptr, nullptr, stream);
-            host::launch_prep_pairs<T>(w_table, ws_w, n, mod.value, stream);
+            TW* ws_ninv = ws + n1 + n + n2;
+            unsigned char* tail = reinterpret_cast<unsigned char*>(ws + pairs);
+            unsigned* go_flag = mods_dev ? reinterpret_cast<unsigned*>(tail) : nullptr;
+            auto* norm_arr = mods_dev ? reinterpret_cast<lazy::NormConst*>(tail + 16) : nullptr;
+            host::launch_prep<T>(n1_table, ws_n1, mods_dev, mod.value, 1, log_n1, false, 0, nullptr, nullptr,
+                                 go_flag, norm_arr, stream);
+            host::launch_prep_pairs<T>(w_table, ws_w, n, mod.value, stream, mods_dev);
             const int tl2 = host::lazy_tile_log<T>(log_n2);
-            host::launch_prep<T>(n2_table, ws_n2, nullptr, mod.value, 1, log_n2, false,
-                                 (log_n2 >= tl2) ? tl2 : 0, nullptr, nullptr, nullptr, nullptr, stream, nullptr,
-                                 INV ? &ninv : nullptr); // inverse: n^-1 rides on the last row stage
+            host::launch_prep<T>(n2_table, ws_n2, mods_dev, mod.value, 1, log_n2, false,
+                                 (log_n2 >= tl2) ? tl2 : 0, (INV && mods_dev) ? ninv_dev : nullptr,
+                                 (INV && mods_dev) ? ws_ninv : nullptr, nullptr, nullptr, stream, nullptr,
+                                 (INV && !mods_dev) ? &ninv : nullptr,
+                                 INV && mods_dev != nullptr); // inverse: n^-1 rides on the last row stage
+            if (go_flag_out != nullptr)
+                *go_flag_out = go_flag;
 
             kern::LazyArgsT<T> a{};
             a.in = in;
             a.out = out;
             a.tw = ws_n1;
-            a.mods = nullptr;
+            a.mods = mods_dev;
             a.q = mod.value;
             a.q_bit = mod.bit;
             a.q_mu = mod.mu;
             a.ninv_arr = nullptr;
             a.ninv = TW{0, 0};
-            a.go_flag = nullptr;
+            a.go_flag = go_flag;
             a.norm = lazy::make_norm_const(static_cast<uint64_t>(mod.value), static_cast<uint64_t>(mod.bit));
-            a.norm_arr = nullptr;
+            a.norm_arr = norm_arr;
             a.w_pairs = ws_w;
             a.n2_log = log_n2;
             a.batch = batch_size;
@@ -190,8 +211,10 @@ namespace gpuntt
             b.w_pairs = nullptr;
             b.n = log_n2;
             b.poly_shift = log_n2;
-            if (INV)
+            if (INV && mods_dev == nullptr)
                 b.ninv = TW{ninv, host::shoup_host(ninv, mod.value)};
+            if (INV && mods_dev != nullptr)
+                b.ninv_arr = ws_ninv;
             host::run_transform_lazy<T, INV>(b, 0u, 0u, stream);
             return true;
         }
@@ -370,6 +393,17 @@ namespace gpuntt
                 return;
             if ((static_cast<unsigned long long>(batch_size) << n_power) >> kern::TL > 0x7fffffffull)
                 throw std::invalid_argument("batch_size * N too large for one launch");
+            const unsigned* skip_flag = nullptr;
+            if (mods != nullptr && mod_count == 1)
+            {
+                // one device-side modulus: fast kernels + generic kernels behind the go-flag
+                if (ntt_type == FORWARD)
+                    fourstep_run_lazy<T, false>(in, out, n1_table, n2_table, w_table, Modulus<T>(), T(0), n_power, l1,
+                                                l2, batch_size, stream, mods, ninv_arr, &skip_flag);
+                else
+                    fourstep_run_lazy<T, true>(in, out, n1_table, n2_table, w_table, Modulus<T>(), T(0), n_power, l1,
+                                               l2, batch_size, stream, mods, ninv_arr, &skip_flag);
+            }
             if (mods == nullptr)
             {
                 const bool done =
@@ -383,10 +417,10 @@ namespace gpuntt
             }
             if (ntt_type == FORWARD)
                 fourstep_run<T, false>(in, out, n1_table, n2_table, w_table, mods, mod, mod_count,
-                                       ninv_arr, ninv, n_power, l1, l2, batch_size, stream);
+                                       ninv_arr, ninv, n_power, l1, l2, batch_size, stream, skip_flag);
             else
                 fourstep_run<T, true>(in, out, n1_table, n2_table, w_table, mods, mod, mod_count,
-                                      ninv_arr, ninv, n_power, l1, l2, batch_size, stream);
+                                      ninv_arr, ninv, n_power, l1, l2, batch_size, stream, skip_flag);
         }
     } // namespace
 

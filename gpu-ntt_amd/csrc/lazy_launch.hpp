@@ -57,11 +57,12 @@ namespace gpuntt
                                                    const uint32_t*, bool);
 
         template <typename T>
-        void launch_prep_pairs(const T* src, lazy::Tw<T>* dst, unsigned long long count, T q, hipStream_t stream);
+        void launch_prep_pairs(const T* src, lazy::Tw<T>* dst, unsigned long long count, T q, hipStream_t stream,
+                               const Modulus<T>* mods = nullptr); // mods: one device-side modulus instead of q
         extern template void launch_prep_pairs<uint64_t>(const uint64_t*, lazy::Tw64*, unsigned long long,
-                                                         uint64_t, hipStream_t);
+                                                         uint64_t, hipStream_t, const Modulus<uint64_t>*);
         extern template void launch_prep_pairs<uint32_t>(const uint32_t*, lazy::Tw32*, unsigned long long,
-                                                         uint32_t, hipStream_t);
+                                                         uint32_t, hipStream_t, const Modulus<uint32_t>*);
 
         // 4-step phase 1 (fused n1-point transform + transpose + W multiply), log_n1 in 5..8
         template <typename T, bool INV>

@@ -823,9 +823,20 @@ namespace gpuntt
         __global__ __launch_bounds__(LTile<TLOG>::NT, LOcc<TLOG>::WAVES) void fourstep_phase1_lazy(LazyArgsT<T> a)
         {
             __shared__ T lds[LTile<TLOG>::LDS_ELEMS_FST];
+            // RNS overload with one device-side modulus: go-flag + modulus from memory (see merge_pass_lazy)
+            if (a.go_flag != nullptr && *a.go_flag == 0u)
+                return;
+            T qv = a.q, qb = a.q_bit, qm = a.q_mu;
+            if (a.mods != nullptr)
+            {
+                const Modulus<T> md = a.mods[0];
+                qv = md.value;
+                qb = md.bit;
+                qm = md.mu;
+            }
             const unsigned long long poly = blockIdx.x % static_cast<unsigned>(a.batch);
             const unsigned tile = blockIdx.x / static_cast<unsigned>(a.batch);
-            pass_body<T, TLOG, false, INV, true, K, 1, false, true>(a, lds, a.q, a.q_bit, a.q_mu, 0, poly, tile);
+            pass_body<T, TLOG, false, INV, true, K, 1, false, true>(a, lds, qv, qb, qm, 0, poly, tile);
         }
 
     } // namespace kern

@@ -167,6 +167,12 @@ def fourstep_case(g, bits, logn, batch, iters, name, check=True):
     fwd = lambda: g.GPU_4STEP_NTT(a, b, *tf, p4.modulus, cf, batch)  # noqa: E731
     inv = lambda: g.GPU_4STEP_NTT(a, b, *ti, p4.modulus, ci, batch)  # noqa: E731
     emit(name + "-fwd", bits, "4step-fwd", logn, batch, time_ms(fwd, iters), ok)
+    # the RNS overload with one device-side modulus, as the reference's own example calls it
+    mods = g.modulus_array_to_device([p4.modulus], bits)
+    crf = g.ntt4step_rns_configuration(n_power=logn, ntt_type=g.FORWARD,
+                                       mod_inverse=g.to_device(np.array([p4.n_inv], dtype=g.np_dtype(bits))))
+    fwd_rns = lambda: g.GPU_4STEP_NTT(a, b, *tf, mods, crf, batch, 1)  # noqa: E731
+    emit(name + "-fwd-rns-overload", bits, "4step-fwd-rns1", logn, batch, time_ms(fwd_rns, iters), ok)
     emit(name + "-inv", bits, "4step-inv", logn, batch, time_ms(inv, iters), ok)
 
     def full():
