@@ -11,6 +11,10 @@
 //            batch*n1 rows with the n2 table -> the shared tile-pass planner (launch.hpp);
 //            the inverse applies cfg.mod_inverse (= N^-1) in its last pass.
 // => 2 sweeps for n2 <= 4096, 3 sweeps up to N = 2^24 (the reference also needs 2-3).
+//
+// Extension GPU_4STEP_NTT_NaturalOrder: the reference examples' GPU_Transpose -> GPU_4STEP_NTT ->
+// GPU_Transpose pipeline as one call in three sweeps (fourstep_natural_forward_lazy /
+// fourstep_natural_inverse_lazy below) instead of five.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>

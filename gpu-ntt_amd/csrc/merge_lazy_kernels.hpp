@@ -1,4 +1,4 @@
-// merge_lazy_kernels.hpp -- the fast 64-bit Merge-NTT tile-pass kernel (gfx950).
+// merge_lazy_kernels.hpp -- the fast (lazy-residue) Merge-NTT tile-pass kernels, 32- and 64-bit (gfx950).
 //
 // Same tile/round geometry as merge_kernels.hpp (4096-coefficient tiles, 16 coefficients per
 // thread, <= 4 radix-2 stages per register round, padded-LDS exchanges), but
@@ -6,7 +6,7 @@
 //     (prep.hip): block-uniform rounds fetch them through the scalar cache (s_load), the
 //     last contiguous round reads them fully coalesced from a per-thread permuted layout;
 //   * butterflies work on lazy residues in [0, B*q) with B tracked at compile time
-//     (lazy64.hpp); passes hand over lazy values, only the final pass normalises.
+//     (lazy.hpp); passes hand over lazy values, only the final pass normalises.
 // Replaces the hot loops of reference ForwardCore/InverseCore
 // (src/lib/ntt_merge/ntt.cu:596-761, 1086-1318).
 #pragma once

@@ -57,14 +57,14 @@ namespace gpuntt
             }
         }
 
-        // ---- fast 64-bit path (lazy residues + prepared Shoup twiddles) -----------------
-        // Used for Data64 calls whose moduli leave >= 4 bits of headroom (bit <= 60).
+        // ---- fast path (lazy residues + prepared Shoup twiddles) ------------------------
+        // Used for calls whose moduli leave the lazy headroom: bit <= 60 (Data64) / bit <= 30 (Data32).
         //   single modulus: the host sees Modulus<T>::bit and picks the path;
         //   RNS: the moduli live in device memory, so the twiddle-prep kernel classifies them and
         //        publishes a go-flag; the fast kernels AND the generic kernels are both enqueued,
         //        each returning at once when the flag says the call belongs to the other family.
-        // Small jobs, rings above 2^24 and RNS stacks of rings below one tile use the generic
-        // kernels only.
+        // Tiny single-modulus rings (below 2^5 / 2^11), small RNS jobs, rings above 2^24 and RNS
+        // stacks of rings below one tile use the generic kernels only.
         // GPUNTT_PATH=generic | fast overrides the size heuristic (testing / A-B timing);
         // moduli without the headroom always take the generic kernels.
         inline int forced_path()

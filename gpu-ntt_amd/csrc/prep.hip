@@ -1,8 +1,8 @@
-// prep.hip -- twiddle preparation for the fast 64-bit path + its workspace.
+// prep.hip -- twiddle preparation for the fast (lazy-residue) kernels, 32- and 64-bit, + its workspace.
 //
 // The caller's tables hold plain residues in the reference's bit-reversed order
 // (reference test_merge_ntt.cu:115-122).  Each call re-derives from them, on the call's
-// stream, the table the fast kernels read: Shoup pairs {w, floor(w * 2^64 / q)} laid out by
+// stream, the table the fast kernels read: Shoup pairs {w, floor(w * 2^W / q)} laid out by
 // stage (stage with m = 2^S groups occupies slots [2^S, 2^(S+1)) for both reduction
 // polynomials), with the distance-1/2/4 stages permuted to [tile][k][thread] so the last
 // contiguous round loads them fully coalesced.  The quotients come from one multiplication by
