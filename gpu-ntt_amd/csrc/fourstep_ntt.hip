@@ -172,15 +172,11 @@ namespace gpuntt
             unsigned char* tail = reinterpret_cast<unsigned char*>(ws + pairs);
             unsigned* go_flag = mods_dev ? reinterpret_cast<unsigned*>(tail) : nullptr;
             auto* norm_arr = mods_dev ? reinterpret_cast<lazy::NormConst*>(tail + 16) : nullptr;
-            host::launch_prep<T>(n1_table, ws_n1, mods_dev, mod.value, 1, log_n1, false, 0, nullptr, nullptr,
-                                 go_flag, norm_arr, stream);
-            host::launch_prep_pairs<T>(w_table, ws_w, n, mod.value, stream, mods_dev);
             const int tl2 = host::lazy_tile_log<T>(log_n2);
-            host::launch_prep<T>(n2_table, ws_n2, mods_dev, mod.value, 1, log_n2, false,
-                                 (log_n2 >= tl2) ? tl2 : 0, (INV && mods_dev) ? ninv_dev : nullptr,
-                                 (INV && mods_dev) ? ws_ninv : nullptr, nullptr, nullptr, stream, nullptr,
-                                 (INV && !mods_dev) ? &ninv : nullptr,
-                                 INV && mods_dev != nullptr); // inverse: n^-1 rides on the last row stage
+            // one preparation launch; inverse: n^-1 rides on the last row stage (fold = 2)
+            host::launch_prep_fourstep<T>(n1_table, n2_table, w_table, ws_n1, ws_w, ws_n2, log_n1, log_n2,
+                                          (log_n2 >= tl2) ? tl2 : 0, false, INV ? 2 : 0, mod.value, ninv, mods_dev,
+                                          (INV && mods_dev) ? ninv_dev : nullptr, ws_ninv, go_flag, norm_arr, stream);
             if (go_flag_out != nullptr)
                 *go_flag_out = go_flag;
 
@@ -246,11 +242,9 @@ namespace gpuntt
             TW* ws_n1 = ws;
             TW* ws_w = ws + n1;
             TW* ws_n2 = ws + n1 + n;
-            host::launch_prep<T>(n1_table, ws_n1, nullptr, mod.value, 1, log_n1, false, 0, nullptr, nullptr,
-                                 nullptr, nullptr, stream);
-            host::launch_prep_pairs<T>(w_table, ws_w, n, mod.value, stream);
-            host::launch_prep<T>(n2_table, ws_n2, nullptr, mod.value, 1, log_n2, false, 0, nullptr, nullptr,
-                                 nullptr, nullptr, stream); // plain stage layout (no per-tile permutation)
+            // plain stage layout of the n2 table (no per-tile permutation: the last pass works on row runs)
+            host::launch_prep_fourstep<T>(n1_table, n2_table, w_table, ws_n1, ws_w, ws_n2, log_n1, log_n2, 0, false, 0,
+                                          mod.value, T(0), nullptr, nullptr, nullptr, nullptr, nullptr, stream);
 
             kern::LazyArgsT<T> a{};
             a.in = in;
@@ -327,11 +321,9 @@ namespace gpuntt
             TW* ws_n1 = ws;
             TW* ws_w = ws + n1;
             TW* ws_n2 = ws + n1 + n;
-            host::launch_prep<T>(n1_table, ws_n1, nullptr, mod.value, 1, log_n1, false, 0, nullptr, nullptr,
-                                 nullptr, nullptr, stream, nullptr, &ninv); // N^-1 rides on the very last stage
-            host::launch_prep_pairs_brev<T>(w_table, ws_w, log_n1, log_n2, mod.value, stream);
-            host::launch_prep<T>(n2_table, ws_n2, nullptr, mod.value, 1, log_n2, false, 0, nullptr, nullptr,
-                                 nullptr, nullptr, stream);
+            // N^-1 rides on the very last stage (fold = 1: the n1 table); W re-indexed (w_brev)
+            host::launch_prep_fourstep<T>(n1_table, n2_table, w_table, ws_n1, ws_w, ws_n2, log_n1, log_n2, 0, true, 1,
+                                          mod.value, ninv, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
 
             kern::LazyArgsT<T> a{};
             a.in = in;

@@ -184,6 +184,99 @@ namespace gpuntt
             const T w = src[gid];
             dst[gid] = lazy::Tw<T>{w, shoup_quotient_r<T>(w, q, rinv)};
         }
+        // One launch for everything a 4-step call prepares (single modulus; cyclic tables):
+        //   ws_n1[0, n1)  stage layout of the n1 table | ws_w[0, N)  W pairs (optionally with both
+        //   matrix indices bit-reversed, see prep_pairs_brev) | ws_n2[0, n2)  stage layout of the n2
+        //   table (perm2 = tile size of the contiguous row pass or 0).
+        // fold: 0 none, 1 = n^-1 into the last-stage twiddle of the n1 table, 2 = of the n2 table.
+        // mods != nullptr: the modulus (and ninv_dev[0]) live in device memory; thread 0 classifies it
+        // (go_flag, norm_arr) and publishes the n^-1 pair in ws_ninv.
+        template <typename T>
+        __device__ __forceinline__ void prep_table_entry(const T* __restrict__ roots, lazy::Tw<T>* __restrict__ ws,
+                                                         unsigned slot, int n, int perm_tile_log, T q, T rinv,
+                                                         bool fold, T ninv)
+        {
+            if (slot == 0)
+            {
+                ws[0] = lazy::Tw<T>{0, 0};
+                return;
+            }
+            const int S = 31 - __clz(slot);
+            unsigned i = slot - (1u << S);
+            const int P = n - 1 - S;
+            if (perm_tile_log > 0 && P <= 2)
+            {
+                const unsigned nt = 1u << (perm_tile_log - 4);
+                const unsigned rp = 16u >> (P + 1);
+                const unsigned tile = i / (rp * nt), rem = i % (rp * nt);
+                const unsigned kk = rem / nt, t = rem % nt;
+                i = tile * (rp * nt) + t * rp + kk;
+            }
+            T w = roots[i];
+            if (fold && slot == 1)
+                w = mulmod_r<T>(w, ninv, q, rinv);
+            ws[slot] = lazy::Tw<T>{w, shoup_quotient_r<T>(w, q, rinv)};
+        }
+
+        template <typename T>
+        __global__ __launch_bounds__(256) void prep_fourstep(const T* __restrict__ n1_table, const T* __restrict__ n2_table,
+                                                             const T* __restrict__ w_table, lazy::Tw<T>* __restrict__ ws_n1,
+                                                             lazy::Tw<T>* __restrict__ ws_w, lazy::Tw<T>* __restrict__ ws_n2,
+                                                             int log_n1, int log_n2, int perm2, int w_brev, int fold,
+                                                             T q_single, T rinv_single, T ninv_single,
+                                                             const Modulus<T>* __restrict__ mods,
+                                                             const T* __restrict__ ninv_dev, lazy::Tw<T>* __restrict__ ws_ninv,
+                                                             unsigned* __restrict__ go_flag,
+                                                             lazy::NormConst* __restrict__ norm_arr)
+        {
+            const unsigned long long gid = blockIdx.x * 256ull + threadIdx.x;
+            __shared__ T s_rinv;
+            T q = q_single, rinv = rinv_single;
+            if (mods != nullptr)
+            {
+                const Modulus<T> md = mods[0];
+                q = md.value;
+                if (threadIdx.x == 0)
+                    s_rinv = recip_norm<T>(q);
+                __syncthreads();
+                rinv = s_rinv;
+                if (gid == 0)
+                {
+                    if (go_flag != nullptr)
+                        *go_flag = (md.bit > static_cast<T>(lazy::Mod<T>::MAX_BIT) || md.value < 3) ? 0u : 1u;
+                    if (norm_arr != nullptr)
+                        norm_arr[0] = lazy::make_norm_const(md.value, md.bit);
+                }
+            }
+            const T ninv = (ninv_dev != nullptr) ? ninv_dev[0] : ninv_single;
+            if (gid == 0 && ninv_dev != nullptr && ws_ninv != nullptr)
+                ws_ninv[0] = lazy::Tw<T>{ninv, shoup_quotient_r<T>(ninv, q, rinv)};
+            const unsigned long long n1 = 1ull << log_n1, n2 = 1ull << log_n2, n = 1ull << (log_n1 + log_n2);
+            if (gid < n1)
+            {
+                prep_table_entry<T>(n1_table, ws_n1, static_cast<unsigned>(gid), log_n1, 0, q, rinv, fold == 1, ninv);
+            }
+            else if (gid < n1 + n)
+            {
+                const unsigned long long e = gid - n1;
+                unsigned long long src = e;
+                if (w_brev)
+                {
+                    const unsigned k = static_cast<unsigned>(e >> log_n2);
+                    const unsigned j = static_cast<unsigned>(e & (n2 - 1));
+                    src = (static_cast<unsigned long long>(__brev(k) >> (32 - log_n1)) << log_n2) +
+                          (__brev(j) >> (32 - log_n2));
+                }
+                const T w = w_table[src];
+                ws_w[e] = lazy::Tw<T>{w, shoup_quotient_r<T>(w, q, rinv)};
+            }
+            else if (gid < n1 + n + n2)
+            {
+                prep_table_entry<T>(n2_table, ws_n2, static_cast<unsigned>(gid - n1 - n), log_n2, perm2, q, rinv,
+                                    fold == 2, ninv);
+            }
+        }
+
         // plain residues -> Shoup pairs with both matrix indices bit-reversed:
         // dst[k * n2 + j] = pair(src[brev(k, log n1) * n2 + brev(j, log n2)])
         template <typename T>
@@ -298,6 +391,29 @@ namespace gpuntt
                                mods ? static_cast<T>(0) : recip_norm_host<T>(q), mods);
             GPUNTT_HIP_CHECK(hipGetLastError());
         }
+        template <typename T>
+        void launch_prep_fourstep(const T* n1_table, const T* n2_table, const T* w_table, lazy::Tw<T>* ws_n1,
+                                  lazy::Tw<T>* ws_w, lazy::Tw<T>* ws_n2, int log_n1, int log_n2, int perm2, bool w_brev,
+                                  int fold, T q, T ninv, const Modulus<T>* mods, const T* ninv_dev, lazy::Tw<T>* ws_ninv,
+                                  unsigned* go_flag, lazy::NormConst* norm_arr, hipStream_t stream)
+        {
+            const unsigned long long count = (1ull << log_n1) + (1ull << (log_n1 + log_n2)) + (1ull << log_n2);
+            const unsigned grid = static_cast<unsigned>((count + 255) / 256);
+            hipLaunchKernelGGL((kern::prep_fourstep<T>), dim3(grid), dim3(256), 0, stream, n1_table, n2_table, w_table,
+                               ws_n1, ws_w, ws_n2, log_n1, log_n2, perm2, w_brev ? 1 : 0, fold, q,
+                               mods ? static_cast<T>(0) : recip_norm_host<T>(q), ninv, mods, ninv_dev, ws_ninv, go_flag,
+                               norm_arr);
+            GPUNTT_HIP_CHECK(hipGetLastError());
+        }
+        template void launch_prep_fourstep<uint64_t>(const uint64_t*, const uint64_t*, const uint64_t*, lazy::Tw64*,
+                                                     lazy::Tw64*, lazy::Tw64*, int, int, int, bool, int, uint64_t, uint64_t,
+                                                     const Modulus<uint64_t>*, const uint64_t*, lazy::Tw64*, unsigned*,
+                                                     lazy::NormConst*, hipStream_t);
+        template void launch_prep_fourstep<uint32_t>(const uint32_t*, const uint32_t*, const uint32_t*, lazy::Tw32*,
+                                                     lazy::Tw32*, lazy::Tw32*, int, int, int, bool, int, uint32_t, uint32_t,
+                                                     const Modulus<uint32_t>*, const uint32_t*, lazy::Tw32*, unsigned*,
+                                                     lazy::NormConst*, hipStream_t);
+
         template <typename T>
         void launch_prep_pairs_brev(const T* src, lazy::Tw<T>* dst, int log_n1, int log_n2, T q, hipStream_t stream)
         {

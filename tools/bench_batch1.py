@@ -17,7 +17,7 @@ g = _load_pkg()
 g.load_library()
 import torch  # noqa: E402
 
-for bits in (64, 32):
+for bits in (() if os.environ.get('SKIP_MERGE') else (64, 32)):
     for logn in range(int(os.environ.get('LOGN_MIN', '12')), 25):
         prm = g.NTTParameters(logn, g.X_N_minus, bits)
         n = 1 << logn
@@ -29,3 +29,19 @@ for bits in (64, 32):
         ms = time_ms(fn, 200 if logn < 20 else 50, warm=10)
         print(json.dumps({"path": os.environ.get("GPUNTT_PATH", "auto"), "dtype": "u%d" % bits, "log2N": logn,
                           "batch": 1, "us": round(ms * 1e3, 2)}), flush=True)
+
+# 4-step, single polynomial (benchmark/bench_4step_ntt.cu:96-100 sweeps the same axis), pre-transposed input
+for logn in range(12, 25):
+    p4 = g.NTTParameters4Step(logn, 64)
+    x = (np.arange(p4.n, dtype=np.uint64) * 2654435761 % p4.modulus.value).astype(np.uint64)
+    a = g.to_device(x)
+    b = torch.empty_like(a)
+    tf = [g.to_device(t) for t in p4.tables["fwd"]]
+    cf = g.ntt4step_configuration(n_power=logn, ntt_type=g.FORWARD)
+    fn = lambda: g.GPU_4STEP_NTT(a, b, *tf, p4.modulus, cf, 1)  # noqa: E731
+    ms = time_ms(fn, 200 if logn < 20 else 50, warm=10)
+    fn2 = lambda: g.GPU_4STEP_NTT_NaturalOrder(a, b, *tf, p4.modulus, cf, 1)  # noqa: E731
+    ms2 = time_ms(fn2, 200 if logn < 20 else 50, warm=10)
+    print(json.dumps({"path": os.environ.get("GPUNTT_PATH", "auto"), "dtype": "u64", "log2N": logn, "batch": 1,
+                      "algo": "4step-fwd", "us": round(ms * 1e3, 2), "natural_order_us": round(ms2 * 1e3, 2)}),
+          flush=True)
