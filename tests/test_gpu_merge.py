@@ -40,6 +40,33 @@ def test_forward_inverse_all_sizes(g, bits, poly):
         assert np.array_equal(c.gpu_inverse(x), c.P.merge_ntt(x, c.oprm, inverse=True))
 
 
+def test_random_configurations(g):
+    """seeded sweep over (word size, ring size, polynomial, batch, direction, in place, custom prime):
+    the pass planner, tile choice and path heuristics see combinations the structured tests do not"""
+    from gpu_utils import find_ntt_factors
+    rng = np.random.default_rng(20260929)
+    cache = {}
+    for it in range(48):
+        bits = int(rng.choice([32, 64]))
+        logn = int(rng.integers(1, 19))
+        poly = O.X_N_plus if rng.integers(0, 2) else O.X_N_minus
+        batch = int(rng.integers(1, 12)) if logn <= 15 else int(rng.integers(1, 4))
+        custom = bool(rng.integers(0, 3) == 0)
+        key = (bits, logn, poly, custom)
+        if key not in cache:
+            factors = None
+            if custom:
+                qbits = int(rng.integers(max(logn + 3, 20), 31 if bits == 32 else 61))
+                factors = find_ntt_factors(qbits, logn)
+            cache[key] = MergeCase(g, bits, logn, poly, factors)
+        c = cache[key]
+        x = c.random(batch, 5000 + it)
+        inverse, inplace = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        want = c.P.merge_ntt(x, c.oprm, inverse=inverse)
+        got = c.gpu_inverse(x, inplace=inplace) if inverse else c.gpu_forward(x, inplace=inplace)
+        assert np.array_equal(got, want), (it, bits, logn, poly, batch, inverse, inplace, custom, c.q)
+
+
 @pytest.mark.parametrize("bits", [32, 64])
 def test_ragged_batches_small_rings(g, bits):
     # tiles that hold several polynomials and a ragged tail (reference LowRing tail guard,
