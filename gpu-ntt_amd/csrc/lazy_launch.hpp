@@ -21,9 +21,21 @@ namespace gpuntt
         // stages): measured in profiles/u32_tile_ab_r01.txt.  GPUNTT_U32_TILE=12|14 overrides the
         // choice above 2^14 (A/B timing).
         int lazy_u32_tile_override();
+        // largest ring (log2) that 64-bit calls transform inside one big tile: 13 by default,
+        // GPUNTT_U64_BIG_TILES=14 adds the 16384-coefficient tile, =0 turns both off
+        int lazy_u64_big_tiles();
         template <typename T> inline int lazy_tile_log(int n)
         {
-            if (sizeof(T) != 4 || n <= 12)
+            if (sizeof(T) == 8)
+            {
+                // a 64-bit ring of 2^13 fits one 8192-coefficient tile (68 KiB of LDS, two blocks per CU):
+                // one HBM sweep instead of two, 0.45 -> 0.33 ms per 2^26 coefficients.  2^14 in one
+                // 16384-coefficient tile (136 KiB, one block per CU) gains 7 % forward and loses 9 % inverse.
+                if ((n == 13 || n == 14) && lazy_u64_big_tiles() >= n)
+                    return n;
+                return 12;
+            }
+            if (n <= 12)
                 return 12;
             if (n <= 14)
                 return 14;

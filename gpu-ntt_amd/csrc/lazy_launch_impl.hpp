@@ -34,6 +34,15 @@ namespace gpuntt
             const unsigned grid = static_cast<unsigned>(tiles);
 #define GPUNTT_ONE(CONTIG_, K_, IN_, LAST_)                                                      \
     return launch_lazy_one<T, TLOG, INV, CONTIG_, K_, IN_, LAST_>(a, grid, stream)
+            if constexpr (sizeof(T) == 8 && TLOG >= 13)
+            {
+                // 64-bit big tiles exist for exactly one shape: the whole ring in one pass
+                if (p.contig && in_first && last && p.k == TLOG)
+                    GPUNTT_ONE(true, TLOG, 1, true);
+                throw std::invalid_argument("internal: unsupported 64-bit big-tile pass");
+            }
+            else
+            {
             if (p.contig)
             {
                 if (in_first && last)
@@ -55,6 +64,11 @@ namespace gpuntt
                             case 12: GPUNTT_ONE(true, 12, 1, true);
                             default: break;
                         }
+                    else if constexpr (TLOG == 13)
+                    {
+                        if (p.k == 13)
+                            GPUNTT_ONE(true, 13, 1, true);
+                    }
                     else
                         switch (p.k)
                         {
@@ -147,8 +161,9 @@ namespace gpuntt
                         }
                 }
             }
-#undef GPUNTT_ONE
             throw std::invalid_argument("internal: unsupported strided pass in the fast path");
+            }
+#undef GPUNTT_ONE
         }
 
         template <typename T, bool INV>
@@ -272,9 +287,11 @@ namespace gpuntt
         {
             if (tile_log == 12)
                 return dispatch_tl<T, 12, INV>(p, in_first, last, a, stream);
-            if constexpr (sizeof(T) == 4)
-                if (tile_log == 14)
-                    return dispatch_tl<T, 14, INV>(p, in_first, last, a, stream);
+            if (tile_log == 14 && (sizeof(T) == 4 || (p.contig && in_first && last)))
+                return dispatch_tl<T, 14, INV>(p, in_first, last, a, stream);
+            if constexpr (sizeof(T) == 8)
+                if (tile_log == 13 && p.contig && in_first && last)
+                    return dispatch_tl<T, 13, INV>(p, in_first, last, a, stream);
             throw std::invalid_argument("internal: unsupported tile size in the fast path");
         }
     } // namespace host

@@ -224,9 +224,10 @@ namespace gpuntt
         // waves per SIMD requested from the register allocator: four 256-thread tiles per CU
         // (128 VGPRs) or two 1024-thread tiles per CU (64 VGPRs; the 32-bit kernels fit once the
         // twiddles of a round are loaded at the start of that round instead of a round ahead)
-        template <int TLOG> struct LOcc
+        template <int TLOG, typename T = uint32_t> struct LOcc
         {
-            static constexpr int WAVES = (TLOG >= 14) ? 8 : 4;
+            // 64-bit kernels need the 128-VGPR budget at every tile size
+            static constexpr int WAVES = (TLOG >= 14 && sizeof(T) == 4) ? 8 : 4;
         };
 
         // twiddles of one register round, in stage order: stage s (register bit jb) contributes
@@ -366,7 +367,7 @@ namespace gpuntt
             // 64-bit: request a round's twiddles one round ahead (in front of the exchange barrier);
             // 32-bit big tiles: at the start of the round (halves the live twiddle registers; the
             // 8 waves per SIMD cover the latency)
-            constexpr bool TW_AHEAD = (LOcc<TLOG>::WAVES <= 4);
+            constexpr bool TW_AHEAD = (LOcc<TLOG, T>::WAVES <= 4);
 
             T v[EPT];
             TW tw_next[TW_PER_ROUND];
@@ -722,7 +723,7 @@ namespace gpuntt
         }
 
         template <typename T, int TLOG, bool INV, bool CONTIG, int K, int IN_BOUND, bool LAST>
-        __global__ __launch_bounds__(LTile<TLOG>::NT, LOcc<TLOG>::WAVES) void merge_pass_lazy(LazyArgsT<T> a)
+        __global__ __launch_bounds__(LTile<TLOG>::NT, (LOcc<TLOG, T>::WAVES)) void merge_pass_lazy(LazyArgsT<T> a)
         {
             using G = LGeo<TLOG, CONTIG, K>;
             using M = lazy::Mod<T>;
@@ -756,7 +757,7 @@ namespace gpuntt
         // natural-order 4-step, forward pass 1: STRIDED column transforms (K = log2 n1 top bits of the
         // N-ring, in place) + W product; block b -> (tile b / batch, poly b % batch)
         template <typename T, int TLOG, int K>
-        __global__ __launch_bounds__(LTile<TLOG>::NT, LOcc<TLOG>::WAVES) void fourstep_nat_p1_lazy(LazyArgsT<T> a)
+        __global__ __launch_bounds__(LTile<TLOG>::NT, (LOcc<TLOG, T>::WAVES)) void fourstep_nat_p1_lazy(LazyArgsT<T> a)
         {
             using G = LGeo<TLOG, false, K>;
             using M = lazy::Mod<T>;
@@ -772,7 +773,7 @@ namespace gpuntt
         // natural-order 4-step, last forward pass: block b -> (row block fastest, column run, poly);
         // a.n = log2 n2 (row length and input row stride), a.n2_log = log2 n1 (output row stride)
         template <typename T, int TLOG, int K, int IN_BOUND>
-        __global__ __launch_bounds__(LTile<TLOG>::NT, LOcc<TLOG>::WAVES) void fourstep_nat_last_lazy(LazyArgsT<T> a)
+        __global__ __launch_bounds__(LTile<TLOG>::NT, (LOcc<TLOG, T>::WAVES)) void fourstep_nat_last_lazy(LazyArgsT<T> a)
         {
             __shared__ T lds[LTile<TLOG>::LDS_ELEMS_FST];
             constexpr int RB = TLOG - K;
@@ -789,7 +790,7 @@ namespace gpuntt
         //   first pass  transposed load of the column-major input + the 2^K low row stages
         //               (Gentleman-Sande), stored row-major, lazy; block order as fourstep_nat_last_lazy
         template <typename T, int TLOG, int K>
-        __global__ __launch_bounds__(LTile<TLOG>::NT, LOcc<TLOG>::WAVES) void fourstep_nat_first_inv_lazy(LazyArgsT<T> a)
+        __global__ __launch_bounds__(LTile<TLOG>::NT, (LOcc<TLOG, T>::WAVES)) void fourstep_nat_first_inv_lazy(LazyArgsT<T> a)
         {
             __shared__ T lds[LTile<TLOG>::LDS_ELEMS_FST];
             constexpr int RB = TLOG - K;
@@ -805,7 +806,7 @@ namespace gpuntt
         //               log2 n1 bits of the N-ring with n^-1 folded into the final stage; canonical,
         //               natural order, in place; block b -> (tile b / batch, poly b % batch)
         template <typename T, int TLOG, int K>
-        __global__ __launch_bounds__(LTile<TLOG>::NT, LOcc<TLOG>::WAVES) void fourstep_nat_last_inv_lazy(LazyArgsT<T> a)
+        __global__ __launch_bounds__(LTile<TLOG>::NT, (LOcc<TLOG, T>::WAVES)) void fourstep_nat_last_inv_lazy(LazyArgsT<T> a)
         {
             using G = LGeo<TLOG, false, K>;
             using M = lazy::Mod<T>;
@@ -820,7 +821,7 @@ namespace gpuntt
 
         // 4-step phase 1 kernel; grid = batch * N / TILE blocks, block b -> (tile b / batch, poly b % batch)
         template <typename T, int TLOG, bool INV, int K>
-        __global__ __launch_bounds__(LTile<TLOG>::NT, LOcc<TLOG>::WAVES) void fourstep_phase1_lazy(LazyArgsT<T> a)
+        __global__ __launch_bounds__(LTile<TLOG>::NT, (LOcc<TLOG, T>::WAVES)) void fourstep_phase1_lazy(LazyArgsT<T> a)
         {
             __shared__ T lds[LTile<TLOG>::LDS_ELEMS_FST];
             // RNS overload with one device-side modulus: go-flag + modulus from memory (see merge_pass_lazy)

@@ -336,6 +336,15 @@ namespace gpuntt
             return 12;
         }
 
+        int lazy_u64_big_tiles()
+        {
+            static const int v = [] {
+                const char* e = std::getenv("GPUNTT_U64_BIG_TILES");
+                return e ? std::atoi(e) : 13; // 2^14 in one 16384-tile: forward -7 %, inverse +9 % -> off by default
+            }();
+            return v;
+        }
+
         int lazy_u32_tile_override()
         {
             static const int forced = [] {
