@@ -96,7 +96,7 @@ def test_signed_input_and_centered_output(g, bits):
     # GPU_NTT<Data64s>: signed input in (-q/2, q/2] gives the same result as its residue
     # (test_merge_ntt.cu:185-341); GPU_INTT<Data64s>: centred output (test_merge_intt.cu:206-379)
     import torch
-    for logn in (5, 12, 14):
+    for logn in (5, 12, 13, 14):  # 13: the 64-bit 8192-coefficient tile
         c = MergeCase(g, bits, logn, O.X_N_minus)
         q, n = c.q, c.n
         x = c.random(2, 31 + logn)
