@@ -1,6 +1,7 @@
 // c_api.cpp -- extern "C" boundary (include/gpuntt_c.h) over the C++ template API.
 #include <cstring>
 #include <exception>
+#include <initializer_list>
 #include <stdexcept>
 #include <string>
 
@@ -37,6 +38,22 @@ namespace
             return GPUNTT_ERR_UNKNOWN;
         }
     }
+
+    // device / host pointer arguments of the C entry points must not be NULL (the C++ templates,
+    // like the reference's, do not check)
+    inline int need(std::initializer_list<const void*> ptrs)
+    {
+        for (const void* p : ptrs)
+            if (p == nullptr)
+            {
+                g_last_error = "null pointer argument";
+                return GPUNTT_ERR_INVALID_ARGUMENT;
+            }
+        return GPUNTT_OK;
+    }
+#define GPUNTT_NEED(...)                                                                          \
+    if (int rc_ = need({__VA_ARGS__}))                                                            \
+        return rc_;
 
     template <typename T, typename CM> Modulus<T> to_mod(const CM& m)
     {
@@ -333,6 +350,7 @@ extern "C"
                        int ntt_layout, int reduction_poly, int input_signed, void* stream,        \
                        int batch_size)                                                            \
     {                                                                                             \
+        GPUNTT_NEED(in, out, roots)                                                                      \
         return ntt_single<T>(in, out, roots, modulus, n_power, ntt_layout, reduction_poly,        \
                              input_signed, stream, batch_size);                                   \
     }                                                                                             \
@@ -340,6 +358,7 @@ extern "C"
                         int ntt_layout, int reduction_poly, T mod_inverse, int output_signed,     \
                         void* stream, int batch_size)                                             \
     {                                                                                             \
+        GPUNTT_NEED(in, out, inverse_roots)                                                              \
         return intt_single<T>(in, out, inverse_roots, modulus, n_power, ntt_layout,               \
                               reduction_poly, mod_inverse, output_signed, stream, batch_size);    \
     }                                                                                             \
@@ -347,6 +366,7 @@ extern "C"
                            int n_power, int ntt_layout, int reduction_poly, int input_signed,     \
                            void* stream, int batch_size, int mod_count)                           \
     {                                                                                             \
+        GPUNTT_NEED(in, out, roots, modulus)                                                             \
         return ntt_rns<T>(in, out, roots, modulus, n_power, ntt_layout, reduction_poly,           \
                           input_signed, stream, batch_size, mod_count);                           \
     }                                                                                             \
@@ -355,6 +375,7 @@ extern "C"
                             const T* mod_inverse, int output_signed, void* stream,                \
                             int batch_size, int mod_count)                                        \
     {                                                                                             \
+        GPUNTT_NEED(in, out, inverse_roots, modulus, mod_inverse)                                        \
         return intt_rns<T>(in, out, inverse_roots, modulus, n_power, ntt_layout, reduction_poly,  \
                            mod_inverse, output_signed, stream, batch_size, mod_count);            \
     }                                                                                             \
@@ -363,6 +384,7 @@ extern "C"
                                        const T* mod_inverse, void* stream, int batch_size,        \
                                        int mod_count, const int* order)                           \
     {                                                                                             \
+        GPUNTT_NEED(in, out, roots, modulus, order)                                                      \
         return ordered<T>(false, in, out, roots, modulus, n_power, ntt_type, reduction_poly,      \
                           mod_inverse, stream, batch_size, mod_count, order);                     \
     }                                                                                             \
@@ -371,6 +393,7 @@ extern "C"
                                     const T* mod_inverse, void* stream, int batch_size,           \
                                     int mod_count, const int* order)                              \
     {                                                                                             \
+        GPUNTT_NEED(in, out, roots, modulus, order)                                                      \
         return ordered<T>(true, in, out, roots, modulus, n_power, ntt_type, reduction_poly,       \
                           mod_inverse, stream, batch_size, mod_count, order);                     \
     }                                                                                             \
@@ -378,6 +401,7 @@ extern "C"
                          const T* w_table, CM modulus, int n_power, int ntt_type, T mod_inverse,  \
                          void* stream, int batch_size)                                            \
     {                                                                                             \
+        GPUNTT_NEED(in, out, n1_table, n2_table, w_table)                                                \
         return fourstep_single<T>(in, out, n1_table, n2_table, w_table, modulus, n_power,         \
                                   ntt_type, mod_inverse, stream, batch_size);                     \
     }                                                                                             \
@@ -385,6 +409,7 @@ extern "C"
                            CM modulus, int n_power, int reduction_poly, T mod_inverse, void* stream, \
                            int batch_size)                                                          \
     {                                                                                             \
+        GPUNTT_NEED(a, b, out, forward_table, inverse_table)                                             \
         return polymul_single<T>(a, b, out, forward_table, inverse_table, modulus, n_power,        \
                                  reduction_poly, mod_inverse, stream, batch_size);                \
     }                                                                                             \
@@ -392,6 +417,7 @@ extern "C"
                                const CM* modulus, int n_power, int reduction_poly,                 \
                                const T* mod_inverse, void* stream, int batch_size, int mod_count)  \
     {                                                                                             \
+        GPUNTT_NEED(a, b, out, forward_table, inverse_table, modulus, mod_inverse)                       \
         return polymul_rns<T>(a, b, out, forward_table, inverse_table, modulus, n_power,           \
                               reduction_poly, mod_inverse, stream, batch_size, mod_count);        \
     }                                                                                             \
@@ -399,6 +425,7 @@ extern "C"
                                  const T* w_table, CM modulus, int n_power, int ntt_type,          \
                                  T mod_inverse, void* stream, int batch_size)                      \
     {                                                                                             \
+        GPUNTT_NEED(in_scratch, out, n1_table, n2_table, w_table)                                        \
         return fourstep_natural<T>(in_scratch, out, n1_table, n2_table, w_table, modulus, n_power, \
                                    ntt_type, mod_inverse, stream, batch_size);                    \
     }                                                                                             \
@@ -406,11 +433,13 @@ extern "C"
                              const T* w_table, const CM* modulus, int n_power, int ntt_type,      \
                              const T* mod_inverse, void* stream, int batch_size, int mod_count)   \
     {                                                                                             \
+        GPUNTT_NEED(in, out, n1_table, n2_table, w_table, modulus)                                       \
         return fourstep_rns<T>(in, out, n1_table, n2_table, w_table, modulus, n_power, ntt_type,  \
                                mod_inverse, stream, batch_size, mod_count);                       \
     }                                                                                             \
     int gpuntt_transpose_##S(const T* in, T* out, int row, int col, int n_power, int batch_size)  \
     {                                                                                             \
+        GPUNTT_NEED(in, out)                                                                             \
         return guarded(                                                                           \
             [&] { GPU_Transpose<T>(const_cast<T*>(in), out, row, col, n_power, batch_size); });   \
     }                                                                                             \

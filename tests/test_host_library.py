@@ -84,23 +84,34 @@ def test_fourstep_parameter_generator(g, bits, golden_dir):
 def test_argument_errors_without_gpu(g):
     lib = g.load_library()
     m = g.Modulus(576460756061519873).c()
+    d = ctypes.c_void_p(8)  # never dereferenced: the checks below fail before any launch
     for bad in (0, 29):
-        assert lib.gpuntt_ntt_u64(None, None, None, m, bad, 0, 1, 0, None, 1) == -1
+        assert lib.gpuntt_ntt_u64(d, d, d, m, bad, 0, 1, 0, None, 1) == -1
         assert lib.gpuntt_last_error() == b"Invalid n_power range!"
-        assert lib.gpuntt_intt_u64(None, None, None, m, bad, 0, 1, ctypes.c_uint64(1), 0, None, 1) == -1
-    assert lib.gpuntt_ntt_u64(None, None, None, m, 12, 9, 1, 0, None, 1) == -1
+        assert lib.gpuntt_intt_u64(d, d, d, m, bad, 0, 1, ctypes.c_uint64(1), 0, None, 1) == -1
+    assert lib.gpuntt_ntt_u64(d, d, d, m, 12, 9, 1, 0, None, 1) == -1
     assert lib.gpuntt_last_error() == b"Invalid ntt_layout!"
-    assert lib.gpuntt_ntt_rns_u64(None, None, None, None, 12, 0, 1, 0, None, 1, 0) == -1
+    assert lib.gpuntt_ntt_rns_u64(d, d, d, d, 12, 0, 1, 0, None, 1, 0) == -1
+    assert lib.gpuntt_last_error() == b"Invalid mod_count!"
     # ordered entry points: n_power in [10, 28] (reference ntt.cu:3607-3610, 4288-4291)
-    dummy = ctypes.c_void_p(8)
     for fn in (lib.gpuntt_ntt_modulus_ordered_u64, lib.gpuntt_ntt_poly_ordered_u64,
                lib.gpuntt_ntt_modulus_ordered_u32, lib.gpuntt_ntt_poly_ordered_u32):
         for bad in (9, 29):
-            assert fn(None, None, None, dummy, bad, 0, 1, None, None, 1, 1, dummy) == -1
+            assert fn(d, d, d, d, bad, 0, 1, None, None, 1, 1, d) == -1
             assert lib.gpuntt_last_error() == b"Invalid n_power range!"
     # PerCoefficient range check (reference ntt.cu:2230-2233)
-    assert lib.gpuntt_ntt_u64(None, None, None, m, 10, 1, 1, 0, None, 1) == -1
+    assert lib.gpuntt_ntt_u64(d, d, d, m, 10, 1, 1, 0, None, 1) == -1
     assert lib.gpuntt_last_error() == b"Invalid n_power range!"
+    # NULL data / table / modulus pointers are rejected at the C boundary
+    assert lib.gpuntt_ntt_u64(None, d, d, m, 12, 0, 1, 0, None, 1) == -1
+    assert lib.gpuntt_last_error() == b"null pointer argument"
+    assert lib.gpuntt_intt_u64(d, d, None, m, 12, 0, 1, ctypes.c_uint64(1), 0, None, 1) == -1
+    assert lib.gpuntt_ntt_rns_u64(d, d, d, None, 12, 0, 1, 0, None, 1, 1) == -1
+    assert lib.gpuntt_4step_u64(d, d, d, None, d, m, 12, 0, ctypes.c_uint64(0), None, 1) == -1
+    assert lib.gpuntt_4step_natural_u32(d, None, d, d, d, g.Modulus(469762049, bits=32).c(), 12, 0,
+                                        ctypes.c_uint32(0), None, 1) == -1
+    assert lib.gpuntt_polymul_u64(d, d, d, d, None, m, 12, 1, ctypes.c_uint64(1), None, 1) == -1
+    assert lib.gpuntt_last_error() == b"null pointer argument"
 
 
 def test_no_cpu_fallback(g):
