@@ -34,6 +34,7 @@ namespace gpuntt
             const unsigned* go_flag;         // RNS: device word, 1 = every modulus has lazy headroom
             const int* mod_order;            // *_Modulus_Ordered: prime of slot mi is mod_order[mi]
             const int* poly_order;           // *_Poly_Ordered: polynomial p lives in slot poly_order[p]
+            const T* mul_in;                 // GPU_PolyMul: canonical operand multiplied into the final forward store, or nullptr
             const lazy::Tw<T>* w_pairs;      // 4-step phase 1: prepared W matrix (N pairs)
             int n2_log;                      // 4-step phase 1: log2 n2
             int batch;                       // 4-step phase 1: polynomials (block order is poly-minor)
@@ -570,6 +571,9 @@ namespace gpuntt
                 // ---- scatter ----------------------------------------------------------
                 if constexpr (r == G::NR - 1)
                 {
+                    constexpr bool PMUL_OK = LAST && !INV && !FST && !WMUL && !EXACT;
+                    const T* mul_in = PMUL_OK ? a.mul_in : nullptr;
+                    (void) mul_in;
                     if constexpr (LAST)
                     {
                         static_for<EPT>([&](auto j_) {
@@ -666,6 +670,12 @@ namespace gpuntt
                         else if (full_tile)
                         {
                             const unsigned lane = map.part(elem_of<WL>(t, 0));
+                            if (PMUL_OK && mul_in != nullptr)
+                            {
+#pragma unroll
+                                for (int j = 0; j < EPT; j++)
+                                    v[j] = em.mul(v[j], (mul_in + (map.base + map.part(static_cast<unsigned>(j) << WL)))[lane]);
+                            }
 #pragma unroll
                             for (int j = 0; j < EPT; j++)
                                 (a.out + (map.base + map.part(static_cast<unsigned>(j) << WL)))[lane] = v[j];
@@ -677,7 +687,7 @@ namespace gpuntt
                             {
                                 const unsigned long long f = map.flat(elem_of<WL>(t, j));
                                 if (f < a.total)
-                                    a.out[f] = v[j];
+                                    a.out[f] = (PMUL_OK && mul_in != nullptr) ? em.mul(v[j], mul_in[f]) : v[j];
                             }
                         }
                     }
@@ -691,10 +701,34 @@ namespace gpuntt
                         if (full_tile)
                         {
                             const T* lc = lds + lds_pad(t);
+                            const unsigned lane = map.part(static_cast<unsigned>(t));
+                            if (PMUL_OK && mul_in != nullptr)
+                            {
+                                // GPU_PolyMul: the pointwise product with the other operand's transform rides
+                                // on the final store (halves of 8 bound the live operands)
 #pragma unroll
-                            for (int j = 0; j < EPT; j++)
-                                (a.out + (map.base + map.part(static_cast<unsigned>(NT * j))))[map.part(static_cast<unsigned>(t))] =
-                                    lc[NT * j + ((NT * j) >> 4)];
+                                for (int half = 0; half < 2; half++)
+                                {
+                                    T o[EPT / 2];
+#pragma unroll
+                                    for (int jj = 0; jj < EPT / 2; jj++)
+                                        o[jj] = (mul_in + (map.base + map.part(static_cast<unsigned>(NT * (half * (EPT / 2) + jj)))))[lane];
+#pragma unroll
+                                    for (int jj = 0; jj < EPT / 2; jj++)
+                                    {
+                                        const int j = half * (EPT / 2) + jj;
+                                        (a.out + (map.base + map.part(static_cast<unsigned>(NT * j))))[lane] =
+                                            em.mul(lc[NT * j + ((NT * j) >> 4)], o[jj]);
+                                    }
+                                }
+                            }
+                            else
+                            {
+#pragma unroll
+                                for (int j = 0; j < EPT; j++)
+                                    (a.out + (map.base + map.part(static_cast<unsigned>(NT * j))))[lane] =
+                                        lc[NT * j + ((NT * j) >> 4)];
+                            }
                         }
                         else
                         {
@@ -703,7 +737,10 @@ namespace gpuntt
                             {
                                 const unsigned long long f = map.flat(t + NT * j);
                                 if (f < a.total)
-                                    a.out[f] = lds[lds_pad(t + NT * j)];
+                                {
+                                    const T x = lds[lds_pad(t + NT * j)];
+                                    a.out[f] = (PMUL_OK && mul_in != nullptr) ? em.mul(x, mul_in[f]) : x;
+                                }
                             }
                         }
                     }

@@ -420,8 +420,12 @@ namespace gpuntt
         template <typename T, int V>
         __global__ __launch_bounds__(256) void pointwise_mul(const T* a, const T* b, T* out,
                                                              const Modulus<T>* __restrict__ mods, Modulus<T> mod,
-                                                             int mod_count, int n, unsigned long long total)
+                                                             int mod_count, int n, unsigned long long total,
+                                                             const unsigned* __restrict__ skip_flag)
         {
+            // GPU_PolyMul, RNS form: the fast forward kernels already multiplied on their final store
+            if (skip_flag != nullptr && *skip_flag != 0u)
+                return;
             // V elements per access: 16 bytes when the buffers are 16-byte aligned, else 1 element
             struct alignas(V * sizeof(T)) Vec
             {
@@ -449,7 +453,7 @@ namespace gpuntt
     {
         template <typename T>
         void pointwise_launch(T* a, T* b, T* out, const Modulus<T>* mods, Modulus<T> mod, int mod_count,
-                              int n_power, int batch_size, hipStream_t stream)
+                              int n_power, int batch_size, hipStream_t stream, const unsigned* skip_flag = nullptr)
         {
             if (n_power <= 0 || n_power >= 29)
                 throw std::invalid_argument("Invalid n_power range!");
@@ -467,10 +471,10 @@ namespace gpuntt
                 blocks = 16384; // 64 blocks per CU, grid-stride beyond
             if (wide)
                 hipLaunchKernelGGL((kern::pointwise_mul<T, VW>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0,
-                                   stream, a, b, out, mods, mod, mod_count, n_power, total);
+                                   stream, a, b, out, mods, mod, mod_count, n_power, total, skip_flag);
             else
                 hipLaunchKernelGGL((kern::pointwise_mul<T, 1>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0,
-                                   stream, a, b, out, mods, mod, mod_count, n_power, total);
+                                   stream, a, b, out, mods, mod, mod_count, n_power, total, skip_flag);
             GPUNTT_HIP_CHECK(hipGetLastError());
         }
     } // namespace
@@ -491,17 +495,39 @@ namespace gpuntt
                             stream);
     }
 
+    // out = INTT(NTT(a) . NTT(b)).  The first operand is transformed in place; the second one's forward
+    // transform multiplies by it on its final store (fast kernels, LazyArgsT::mul_in), so the
+    // pointwise step costs one extra read instead of a kernel of its own; the generic kernels (wide
+    // moduli, tiny rings) are followed by pointwise_mul instead.  `out` may alias either operand:
+    // the operand that shares its buffer with `out` is the one transformed last.
     template <typename T>
     __host__ void GPU_PolyMul(T* device_a, T* device_b, T* device_out, Root<T>* forward_table,
                               Root<T>* inverse_table, Modulus<T> modulus, ntt_configuration<T> cfg,
                               int batch_size)
     {
+        check_layout_and_range(PerPolynomial, cfg.n_power);
+        if (batch_size <= 0)
+            return;
         ntt_configuration<T> f = cfg;
         f.ntt_type = FORWARD;
         f.ntt_layout = PerPolynomial;
-        GPU_NTT<T>(device_a, device_a, forward_table, modulus, f, batch_size);
-        GPU_NTT<T>(device_b, device_b, forward_table, modulus, f, batch_size);
-        pointwise_launch<T>(device_a, device_b, device_out, nullptr, modulus, 1, cfg.n_power, batch_size, cfg.stream);
+        T* first = (device_out == device_a) ? device_b : device_a;  // transformed in place
+        T* second = (device_out == device_a) ? device_a : device_b; // transformed into device_out
+        GPU_NTT<T>(first, first, forward_table, modulus, f, batch_size);
+        if (modulus.value >= 3 && modulus.bit <= T(lazy::Mod<T>::MAX_BIT) &&
+            lazy_eligible<T>(cfg.n_power, batch_size, 1))
+        {
+            kern::LazyArgsT<T> la = lazy_args<T>(second, device_out, forward_table, modulus, nullptr, 1, nullptr,
+                                                 cfg.n_power, cfg.reduction_poly, batch_size, cfg.stream);
+            la.mul_in = first;
+            host::run_transform_lazy<T, false>(la, 0u, 0u, cfg.stream);
+        }
+        else
+        {
+            GPU_NTT<T>(second, device_out, forward_table, modulus, f, batch_size);
+            pointwise_launch<T>(first, device_out, device_out, nullptr, modulus, 1, cfg.n_power, batch_size,
+                                cfg.stream);
+        }
         f.ntt_type = INVERSE;
         GPU_INTT<T>(device_out, device_out, inverse_table, modulus, f, batch_size);
     }
@@ -510,13 +536,39 @@ namespace gpuntt
                               Root<T>* inverse_table, Modulus<T>* modulus, ntt_rns_configuration<T> cfg,
                               int batch_size, int mod_count)
     {
+        check_layout_and_range(PerPolynomial, cfg.n_power);
+        if (mod_count <= 0 || modulus == nullptr)
+            throw std::invalid_argument("Invalid mod_count!");
+        if (batch_size <= 0)
+            return;
         ntt_rns_configuration<T> f = cfg;
         f.ntt_type = FORWARD;
         f.ntt_layout = PerPolynomial;
-        GPU_NTT<T>(device_a, device_a, forward_table, modulus, f, batch_size, mod_count);
-        GPU_NTT<T>(device_b, device_b, forward_table, modulus, f, batch_size, mod_count);
-        pointwise_launch<T>(device_a, device_b, device_out, modulus, Modulus<T>(), mod_count, cfg.n_power, batch_size,
-                            cfg.stream);
+        T* first = (device_out == device_a) ? device_b : device_a;
+        T* second = (device_out == device_a) ? device_a : device_b;
+        GPU_NTT<T>(first, first, forward_table, modulus, f, batch_size, mod_count);
+        // moduli live on the device: fast kernels (multiplying on their final store) and generic
+        // kernels + pointwise_mul are both enqueued, the go-flag decides which family runs
+        const unsigned* skip_flag = nullptr;
+        if (lazy_eligible<T>(cfg.n_power, batch_size, mod_count))
+        {
+            kern::LazyArgsT<T> la = lazy_args<T>(second, device_out, forward_table, Modulus<T>(), modulus, mod_count,
+                                                 nullptr, cfg.n_power, cfg.reduction_poly, batch_size, cfg.stream);
+            la.mul_in = first;
+            host::run_transform_lazy<T, false>(la, 0u, 0u, cfg.stream);
+            skip_flag = la.go_flag;
+        }
+        {
+            kern::PassArgs<T> a = base_args<T>(second, device_out, forward_table, cfg.n_power, cfg.reduction_poly,
+                                               batch_size);
+            a.mods = modulus;
+            a.mod_count = mod_count;
+            a.skip_flag = skip_flag;
+            set_multi(a);
+            host::run_transform<T, false>(a, 0u, 0u, cfg.stream);
+        }
+        pointwise_launch<T>(first, device_out, device_out, modulus, Modulus<T>(), mod_count, cfg.n_power, batch_size,
+                            cfg.stream, skip_flag);
         f.ntt_type = INVERSE;
         GPU_INTT<T>(device_out, device_out, inverse_table, modulus, f, batch_size, mod_count);
     }

@@ -420,6 +420,11 @@ def test_polymul_vs_schoolbook_and_oracle(g, bits):
             g.GPU_PolyMul(da, db, da, c.fwd_dev, c.inv_dev, c.prm.modulus, c.cfg(inverse=True), batch)
             torch.cuda.synchronize()
             assert np.array_equal(g.to_host(da), want)
+            # in place on b
+            da, db = g.to_device(a), g.to_device(b)
+            g.GPU_PolyMul(da, db, db, c.fwd_dev, c.inv_dev, c.prm.modulus, c.cfg(inverse=True), batch)
+            torch.cuda.synchronize()
+            assert np.array_equal(g.to_host(db), want)
 
 
 def test_polymul_rns(g):
