@@ -16,31 +16,40 @@ namespace gpuntt
 {
     using stream_t = hipStream_t; // the reference's cudaStream_t slot in every config struct
 
+    // Failed HIP runtime call: carries the call site and the runtime's error text.
     class HipException : public std::exception
     {
+        hipError_t code_;
+        std::string text_;
+
+        static std::string describe(const std::string& where, int line, hipError_t code)
+        {
+            std::string s("HIP Error in ");
+            s += where;
+            s += " at line ";
+            s += std::to_string(line);
+            s += ": ";
+            s += hipGetErrorString(code);
+            return s;
+        }
+
       public:
         HipException(const std::string& file, int line, hipError_t error)
-            : error_(error), message_("HIP Error in " + file + " at line " +
-                                      std::to_string(line) + ": " +
-                                      hipGetErrorString(error))
+            : code_(error), text_(describe(file, line, error))
         {
         }
-        const char* what() const noexcept override { return message_.c_str(); }
-        hipError_t code() const noexcept { return error_; }
-
-      private:
-        hipError_t error_;
-        std::string message_;
+        hipError_t code() const noexcept { return code_; }
+        const char* what() const noexcept override { return text_.c_str(); }
     };
-    using CudaException = HipException;
+    using CudaException = HipException; // the name caller code catches
 
-#define GPUNTT_HIP_CHECK(expr)                                                 \
-    do                                                                         \
-    {                                                                          \
-        hipError_t gpuntt_err_ = (expr);                                       \
-        if (gpuntt_err_ != hipSuccess)                                         \
-            throw ::gpuntt::HipException(__FILE__, __LINE__, gpuntt_err_);     \
-    } while (0)
+    // every runtime call and every launch (hipGetLastError) goes through this check
+    inline void throw_on_hip_error(hipError_t status, const char* file, int line)
+    {
+        if (status != hipSuccess)
+            throw HipException(file, line, status);
+    }
+#define GPUNTT_HIP_CHECK(expr) ::gpuntt::throw_on_hip_error((expr), __FILE__, __LINE__)
 #define GPUNTT_CUDA_CHECK(expr) GPUNTT_HIP_CHECK(expr)
 
     // throws std::invalid_argument(errorMessage) when !condition   (reference common.cu:5-11)
