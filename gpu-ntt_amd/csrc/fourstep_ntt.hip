@@ -172,7 +172,7 @@ namespace gpuntt
             unsigned char* tail = reinterpret_cast<unsigned char*>(ws + pairs);
             unsigned* go_flag = mods_dev ? reinterpret_cast<unsigned*>(tail) : nullptr;
             auto* norm_arr = mods_dev ? reinterpret_cast<lazy::NormConst*>(tail + 16) : nullptr;
-            const int tl2 = host::lazy_tile_log<T>(log_n2);
+            const int tl2 = host::lazy_tile_log<T>(log_n2, INV, static_cast<unsigned long long>(batch_size) << log_n1);
             // one preparation launch; inverse: n^-1 rides on the last row stage (fold = 2)
             host::launch_prep_fourstep<T>(n1_table, n2_table, w_table, ws_n1, ws_w, ws_n2, log_n1, log_n2,
                                           (log_n2 >= tl2) ? tl2 : 0, false, INV ? 2 : 0, mod.value, ninv, mods_dev,

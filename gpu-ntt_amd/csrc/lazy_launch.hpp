@@ -21,18 +21,25 @@ namespace gpuntt
         // stages): measured in profiles/u32_tile_ab_r01.txt.  GPUNTT_U32_TILE=12|14 overrides the
         // choice above 2^14 (A/B timing).
         int lazy_u32_tile_override();
-        // largest ring (log2) that 64-bit calls transform inside one big tile: 13 by default,
-        // GPUNTT_U64_BIG_TILES=14 adds the 16384-coefficient tile, =0 turns both off
+        // largest ring (log2) that 64-bit calls may transform inside one big tile (default 14;
+        // GPUNTT_U64_BIG_TILES=13 drops the 16384-coefficient tile, =0 both)
         int lazy_u64_big_tiles();
-        template <typename T> inline int lazy_tile_log(int n)
+        // `inverse` and `polys` (transforms in the call) must be the same wherever one call asks:
+        // the twiddle preparation lays the table out for the tile the passes will use
+        template <typename T> inline int lazy_tile_log(int n, bool inverse = false, unsigned long long polys = 0)
         {
             if (sizeof(T) == 8)
             {
                 // a 64-bit ring of 2^13 fits one 8192-coefficient tile (68 KiB of LDS, two blocks per CU):
                 // one HBM sweep instead of two, 0.45 -> 0.33 ms per 2^26 coefficients.  2^14 in one
-                // 16384-coefficient tile (136 KiB, one block per CU) gains 7 % forward and loses 9 % inverse.
-                if ((n == 13 || n == 14) && lazy_u64_big_tiles() >= n)
-                    return n;
+                // 16384-coefficient tile (136 KiB, ONE block per CU) gains 7 % forward on a full chip and
+                // loses 9 % inverse (its first round waits for per-lane twiddles with nothing else
+                // resident): forward calls of at least 256 transforms only.
+                const int big = lazy_u64_big_tiles();
+                if (n == 13 && big >= 13)
+                    return 13;
+                if (n == 14 && big >= 14 && !inverse && polys >= 256)
+                    return 14;
                 return 12;
             }
             if (n <= 12)
@@ -180,7 +187,7 @@ namespace gpuntt
         inline void run_transform_lazy(kern::LazyArgsT<T> base, unsigned first_in_flags,
                                        unsigned last_out_flags, hipStream_t stream)
         {
-            const int tl = lazy_tile_log<T>(base.n);
+            const int tl = lazy_tile_log<T>(base.n, INV, base.total >> base.n);
             const Plan pl = make_plan_tl(base.n, tl, tl == 12 ? lazy_contig_k(base.n) : tl);
             const void* src = base.in;
             for (int i = 0; i < pl.count; i++)

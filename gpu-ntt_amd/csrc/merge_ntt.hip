@@ -115,7 +115,8 @@ namespace gpuntt
         {
             using TW = lazy::Tw<TU>;
             const bool neg = (poly == ReductionPolynomial::X_N_plus);
-            const int tl = host::lazy_tile_log<TU>(n_power);
+            const int tl = host::lazy_tile_log<TU>(n_power, ninv_dev != nullptr || ninv_single != nullptr,
+                                                   static_cast<unsigned long long>(batch_size));
             const int perm_tile_log = (n_power >= tl) ? tl : 0;
             const size_t entries = (static_cast<size_t>(mod_count) << n_power) + mod_count;
             // workspace: twiddle pairs | n^-1 pairs | go-flag | per-modulus normalisation constants

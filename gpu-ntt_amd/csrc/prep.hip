@@ -340,7 +340,7 @@ namespace gpuntt
         {
             static const int v = [] {
                 const char* e = std::getenv("GPUNTT_U64_BIG_TILES");
-                return e ? std::atoi(e) : 13; // 2^14 in one 16384-tile: forward -7 %, inverse +9 % -> off by default
+                return e ? std::atoi(e) : 14;
             }();
             return v;
         }

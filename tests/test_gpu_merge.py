@@ -40,6 +40,20 @@ def test_forward_inverse_all_sizes(g, bits, poly):
         assert np.array_equal(c.gpu_inverse(x), c.P.merge_ntt(x, c.oprm, inverse=True))
 
 
+def test_u64_ring_2_14_in_one_big_tile(g):
+    """forward 64-bit calls of >= 256 transforms of length 2^14 run in one 16384-coefficient tile
+    per polynomial (one sweep); smaller batches and the inverse keep the two-pass plan"""
+    for poly in (O.X_N_plus, O.X_N_minus):
+        c = MergeCase(g, 64, 14, poly)
+        for batch in (256, 300, 255):
+            x = c.random(batch, 14000 + batch)
+            y = c.gpu_forward(x, inplace=(batch == 300))
+            for p in (0, 1, batch // 2, batch - 1):
+                sl = slice(p * c.n, (p + 1) * c.n)
+                assert np.array_equal(y[sl], c.P.merge_ntt(x[sl], c.oprm)), (poly, batch, p)
+            assert np.array_equal(c.gpu_inverse(y, inplace=True), x)
+
+
 def test_random_configurations(g):
     """seeded sweep over (word size, ring size, polynomial, batch, direction, in place, custom prime):
     the pass planner, tile choice and path heuristics see combinations the structured tests do not"""
