@@ -40,6 +40,12 @@ namespace gpuntt
                     return 13;
                 if (n == 14 && big >= 14 && !inverse && polys >= 256)
                     return 14;
+                // 2^21 (2^22 forward): an 8-stage strided pass on 4096-coefficient tiles + the big
+                // contiguous tile = two sweeps instead of three
+                if (n == 21 && big >= 13)
+                    return 13;
+                if (n == 22 && big >= 14 && !inverse)
+                    return 14;
                 return 12;
             }
             if (n <= 12)
@@ -200,7 +206,9 @@ namespace gpuntt
                     a.flags |= first_in_flags;
                 if (i == pl.count - 1)
                     a.flags |= last_out_flags;
-                launch_pass_lazy<T, INV>(p, tl, i == 0, i == pl.count - 1, a, stream);
+                // 64-bit: only the contiguous pass runs on a big tile
+                const int tlp = (sizeof(T) == 8 && !p.contig) ? 12 : tl;
+                launch_pass_lazy<T, INV>(p, tlp, i == 0, i == pl.count - 1, a, stream);
                 src = base.out;
             }
         }

@@ -36,9 +36,24 @@ namespace gpuntt
     return launch_lazy_one<T, TLOG, INV, CONTIG_, K_, IN_, LAST_>(a, grid, stream)
             if constexpr (sizeof(T) == 8 && TLOG >= 13)
             {
-                // 64-bit big tiles exist for exactly one shape: the whole ring in one pass
-                if (p.contig && in_first && last && p.k == TLOG)
-                    GPUNTT_ONE(true, TLOG, 1, true);
+                // 64-bit big tiles: contiguous passes over the whole tile only -- the single pass of a
+                // ring that fits, or the contiguous end of a two-pass plan (2^21, 2^22) whose strided
+                // pass runs on 4096-coefficient tiles
+                if (p.contig && p.k == TLOG)
+                {
+                    if (in_first && last)
+                        GPUNTT_ONE(true, TLOG, 1, true);
+                    if constexpr (!INV)
+                    {
+                        if (!in_first && last)
+                            GPUNTT_ONE(true, TLOG, LIM, true);
+                    }
+                    else if constexpr (TLOG == 13)
+                    {
+                        if (in_first && !last)
+                            GPUNTT_ONE(true, TLOG, 1, false);
+                    }
+                }
                 throw std::invalid_argument("internal: unsupported 64-bit big-tile pass");
             }
             else
@@ -287,10 +302,10 @@ namespace gpuntt
         {
             if (tile_log == 12)
                 return dispatch_tl<T, 12, INV>(p, in_first, last, a, stream);
-            if (tile_log == 14 && (sizeof(T) == 4 || (p.contig && in_first && last)))
+            if (tile_log == 14 && (sizeof(T) == 4 || p.contig))
                 return dispatch_tl<T, 14, INV>(p, in_first, last, a, stream);
             if constexpr (sizeof(T) == 8)
-                if (tile_log == 13 && p.contig && in_first && last)
+                if (tile_log == 13 && p.contig)
                     return dispatch_tl<T, 13, INV>(p, in_first, last, a, stream);
             throw std::invalid_argument("internal: unsupported tile size in the fast path");
         }

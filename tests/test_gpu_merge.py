@@ -571,9 +571,10 @@ def test_modulus_ordered_and_poly_ordered(g, bits):
         g.GPU_NTT_Modulus_Ordered(d, d, fwd, mods, g.ntt_rns_configuration(n_power=9), 1, 1, d_order)
 
 
-@pytest.mark.parametrize("bits,logn", [(64, 22), (64, 24), (32, 23), (64, 25), (32, 25)])
+@pytest.mark.parametrize("bits,logn", [(64, 21), (64, 22), (64, 24), (32, 21), (32, 23), (64, 25), (32, 25)])
 def test_large_rings(g, bits, logn):
-    """Three-sweep plans (2^21..2^24, fast path) and rings above the fast path's table limit
+    """Two-sweep plans with a big contiguous tile (u64 2^21 both directions, 2^22 forward), three-sweep
+    plans (up to 2^24, fast path) and rings above the fast path's table limit
     (2^25+, generic kernels; the reference needs its grid-swapped ForwardCore_ there,
     ntt.cu:763-1084).  Batch 2 so the fast path is eligible where it applies."""
     c = MergeCase(g, bits, logn, O.X_N_minus if logn % 2 else O.X_N_plus)
