@@ -283,6 +283,7 @@ namespace gpuntt
                 lazy_in = true;
                 b.poly_shift = log_n2;
                 b.p_lo = k_last;
+                b.batch = 0; // plain block order
                 const host::Pass sp{false, log_n2 - k_last, k_last};
                 host::launch_pass_lazy<T, false>(sp, 12, true, false, b, stream);
             }
@@ -356,6 +357,7 @@ namespace gpuntt
                 b.in = out;
                 b.poly_shift = log_n2;
                 b.p_lo = k_first;
+                b.batch = 0; // plain block order
                 const host::Pass sp{false, log_n2 - k_first, k_first};
                 host::launch_pass_lazy<T, true>(sp, 12, false, false, b, stream);
             }

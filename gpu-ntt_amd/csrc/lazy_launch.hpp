@@ -208,6 +208,13 @@ namespace gpuntt
                     a.flags |= last_out_flags;
                 // 64-bit: only the contiguous pass runs on a big tile
                 const int tlp = (sizeof(T) == 8 && !p.contig) ? 12 : tl;
+                // rings from 2^20: the per-lane twiddles of a contiguous pass are tens of MiB per
+                // polynomial -- poly-minor block order lets a batch share them through L2
+                const unsigned long long polys = base.total >> base.n;
+                a.batch = (p.contig && base.n >= 20 && base.n >= tlp && polys >= 2 && polys <= 0x7fffffffull &&
+                           (polys << base.n) == base.total)
+                              ? static_cast<int>(polys)
+                              : 0;
                 launch_pass_lazy<T, INV>(p, tlp, i == 0, i == pl.count - 1, a, stream);
                 src = base.out;
             }

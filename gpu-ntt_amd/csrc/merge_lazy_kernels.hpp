@@ -37,7 +37,7 @@ namespace gpuntt
             const T* mul_in;                 // GPU_PolyMul: canonical operand multiplied into the final forward store, or nullptr
             const lazy::Tw<T>* w_pairs;      // 4-step phase 1: prepared W matrix (N pairs)
             int n2_log;                      // 4-step phase 1: log2 n2
-            int batch;                       // 4-step phase 1: polynomials (block order is poly-minor)
+            int batch;                       // > 1: polynomials of the call, blocks are ordered poly-minor (4-step phase 1; big-ring passes)
             unsigned long long total;
             int n;
             int poly_shift;
@@ -778,9 +778,18 @@ namespace gpuntt
             // are routed to the generic kernels by the host)
             T qv = a.q, qb = a.q_bit, qm = a.q_mu;
             int mi = 0;
+            // a.batch > 1: poly-minor block order (block b -> tile b / batch of polynomial b % batch), asked
+            // for by the host for big rings so that the polynomials of a batch read each slice of the
+            // twiddle table back to back (L2 hits instead of one HBM read per polynomial)
+            long long blk = -1;
+            if (a.batch > 1)
+                blk = static_cast<long long>(
+                    (static_cast<unsigned long long>(blockIdx.x % static_cast<unsigned>(a.batch)) << (a.n - TLOG)) |
+                    (blockIdx.x / static_cast<unsigned>(a.batch)));
             if (a.mods != nullptr)
             {
-                const LTileMap<TLOG, CONTIG, K> map(a.n, a.p_lo);
+                const LTileMap<TLOG, CONTIG, K> map(a.n, a.p_lo, blk >= 0 ? static_cast<unsigned long long>(blk)
+                                                                          : static_cast<unsigned long long>(blockIdx.x));
                 const unsigned long long poly = map.flat(0) >> a.poly_shift;
                 mi = static_cast<int>(poly % static_cast<unsigned>(a.mod_count));
                 const Modulus<T> md = a.mods[a.mod_order != nullptr ? a.mod_order[mi] : mi];
@@ -788,7 +797,7 @@ namespace gpuntt
                 qb = md.bit;
                 qm = md.mu;
             }
-            pass_body<T, TLOG, false, INV, CONTIG, K, IN_BOUND, LAST>(a, lds, qv, qb, qm, mi);
+            pass_body<T, TLOG, false, INV, CONTIG, K, IN_BOUND, LAST>(a, lds, qv, qb, qm, mi, 0, 0, blk);
         }
 
         // natural-order 4-step, forward pass 1: STRIDED column transforms (K = log2 n1 top bits of the
