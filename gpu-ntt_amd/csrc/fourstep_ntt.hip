@@ -113,7 +113,10 @@ namespace gpuntt
             a.p_lo = 0;
             a.n2_log = log_n2;
             a.flags = 0;
-            const unsigned grid = static_cast<unsigned>(a.total >> kern::TL);
+            // behind the go-flag (one device-side modulus) this is a shadow launch: capped grid that
+            // walks the tiles, like the Merge shadow launches (launch_impl.hpp)
+            const unsigned long long tiles = a.total >> kern::TL;
+            const unsigned grid = (skip_flag != nullptr && tiles > 1024) ? 1024u : static_cast<unsigned>(tiles);
             switch (log_n1)
             {
                 case 5:
@@ -392,7 +395,16 @@ namespace gpuntt
             if ((static_cast<unsigned long long>(batch_size) << n_power) >> kern::TL > 0x7fffffffull)
                 throw std::invalid_argument("batch_size * N too large for one launch");
             const unsigned* skip_flag = nullptr;
-            if (mods != nullptr && mod_count == 1)
+            const char* path_env = std::getenv("GPUNTT_PATH");
+            if (mods != nullptr && mod_count == 1 && path_env != nullptr && std::strcmp(path_env, "generic-capped") == 0)
+            {
+                // test hook: the generic kernels as they run behind a go-flag that says "yours" (what a
+                // 61/62-bit modulus produces) -- capped grid walking the tiles, flag word = 0
+                auto* flag = static_cast<unsigned*>(host::lazy_workspace(stream, 16));
+                GPUNTT_HIP_CHECK(hipMemsetAsync(flag, 0, 16, stream));
+                skip_flag = flag;
+            }
+            else if (mods != nullptr && mod_count == 1)
             {
                 // one device-side modulus: fast kernels + generic kernels behind the go-flag
                 if (ntt_type == FORWARD)

@@ -121,6 +121,31 @@ def test_fourstep_natural_order_vs_oracle(g, bits):
         g.GPU_4STEP_NTT_NaturalOrder(d_in, d_in, *tf, p4.modulus, cf, batch)
 
 
+def test_fourstep_rns_overload_generic_kernels_on_capped_grid(g):
+    """the RNS overload with one device-side modulus enqueues the generic kernels behind the fast
+    ones; when they own the call (61/62-bit modulus) they run on a capped grid that walks the tiles.
+    GPUNTT_PATH=generic-capped forces exactly that state for a pool prime."""
+    import torch
+    P = O.Port(64)
+    logn, batch = 20, 8  # 2048 tiles > 1024 blocks
+    p4 = g.NTTParameters4Step(logn, 64)
+    oprm = P.fourstep_params(logn)
+    x = P.splitmix(901, 0, batch * p4.n, p4.modulus.value)
+    want = P.fourstep_ntt(x, oprm)
+    old = os.environ.get("GPUNTT_PATH")
+    os.environ["GPUNTT_PATH"] = "generic-capped"
+    try:
+        got = run_fourstep(g, p4, x, batch, inverse=False, rns=True)
+        back = run_fourstep(g, p4, P.fourstep_intt_first_transpose(want, oprm), batch, inverse=True, rns=True)
+    finally:
+        if old is None:
+            del os.environ["GPUNTT_PATH"]
+        else:
+            os.environ["GPUNTT_PATH"] = old
+    assert np.array_equal(got, want)
+    assert np.array_equal(back, x)
+
+
 def test_fourstep_natural_order_generic_fallback(g):
     """no fast path (forced here; also what a 61/62-bit modulus gets): generic 4-step kernels
     between two transposes, same result"""
