@@ -361,9 +361,14 @@ namespace gpuntt
                 });
             };
 
-            // ... and no signed conversion
             const bool full_tile = tile_in_range;
-            const bool plain_io = full_tile && !(a.flags & F_SIGNED_IN);
+            const bool plain_io = full_tile; // signed input is converted after the unguarded loads
+            // (only the first pass of a forward transform can see signed words)
+            const bool signed_in = (!INV && IN_BOUND == 1 && !FST && !WMUL) ? ((a.flags & F_SIGNED_IN) != 0u) : false;
+            auto to_residue = [&](T x) -> T {
+                using S = typename std::make_signed<T>::type;
+                return (static_cast<S>(x) < 0) ? static_cast<T>(x + m.q) : x;
+            };
 
             // 64-bit: request a round's twiddles one round ahead (in front of the exchange barrier);
             // 32-bit big tiles: at the start of the round (halves the live twiddle registers; the
@@ -455,6 +460,12 @@ namespace gpuntt
 #pragma unroll
                             for (int j = 0; j < EPT; j++)
                                 v[j] = (src + (map.base + map.part(static_cast<unsigned>(j) << WL)))[lane];
+                            if (signed_in)
+                            {
+#pragma unroll
+                                for (int j = 0; j < EPT; j++)
+                                    v[j] = to_residue(v[j]);
+                            }
                         }
                         else
                         {
@@ -472,6 +483,12 @@ namespace gpuntt
 #pragma unroll
                             for (int j = 0; j < EPT; j++)
                                 tmp[j] = (src + (map.base + map.part(static_cast<unsigned>(NT * j))))[lane];
+                            if (signed_in)
+                            {
+#pragma unroll
+                                for (int j = 0; j < EPT; j++)
+                                    tmp[j] = to_residue(tmp[j]);
+                            }
                             T* lc = lds + lds_pad(t);
 #pragma unroll
                             for (int j = 0; j < EPT; j++)
