@@ -67,6 +67,29 @@ namespace gpuntt
             return n;
         }
 
+        // d = a * b + c (32 x 32 + 64 -> 64) pinned to ONE v_mad_u64_u32.  SB: b is wave-uniform and is
+        // read straight from a scalar register (a VOP3 instruction may name one).  The carry-out lands
+        // in a dead scalar pair.  Written as asm because the compiler narrows a 64-bit product whose
+        // high word is dead into v_mul_lo_u32 + v_add3_u32 chains (one more instruction per two terms).
+        template <bool SB> __device__ __forceinline__ uint64_t mad32(uint32_t a, uint32_t b, uint64_t c)
+        {
+            uint64_t d, cy;
+            if constexpr (SB)
+                asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(cy) : "v"(a), "s"(b), "v"(c));
+            else
+                asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(cy) : "v"(a), "v"(b), "v"(c));
+            return d;
+        }
+        template <bool SB> __device__ __forceinline__ uint64_t mad32z(uint32_t a, uint32_t b)
+        {
+            uint64_t d, cy;
+            if constexpr (SB)
+                asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(d), "=s"(cy) : "v"(a), "s"(b));
+            else
+                asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(d), "=s"(cy) : "v"(a), "v"(b));
+            return d;
+        }
+
         // ---- 64-bit: sloppy-quotient Shoup product in [0, 4q); LIMIT 16 needs q < 2^60 ------
         template <> struct Mod<uint64_t>
         {
@@ -93,8 +116,14 @@ namespace gpuntt
             }
             __device__ __forceinline__ uint64_t kq(int k) const { return q * static_cast<uint64_t>(k); }
 
-            // x * w  (mod q), any x < 2^64, result in [0, 4q)
-            __device__ __forceinline__ uint64_t mul(uint64_t x, const Tw64& t) const
+            // acc + x * w - qh * q  (mod 2^64)  =  acc + T  with  T = x * w (mod q) + {0..3} q  in [0, 4q),
+            // for any x < 2^64: 11 instructions, the 64-bit add of the butterfly included --
+            //   qh ~ hi64(x * w')      2 v_mul_hi_u32 + 2 v_mad_u64_u32 (low partial products dropped: 3 short at most)
+            //   cross terms (word 1)   4 v_mad_u64_u32 chained through one accumulator whose low word is the sum
+            //   words 0..1             2 v_mad_u64_u32 chained from `acc`, 1 v_add_u32 for the cross sum
+            // UNI: the twiddle is wave-uniform (scalar registers).  ZERO: acc = 0.
+            template <bool UNI, bool ZERO = false>
+            __device__ __forceinline__ uint64_t mul_acc(uint64_t x, const Tw64& t, uint64_t acc) const
             {
                 const uint32_t x0 = lo32(x), x1 = hi32(x);
                 const uint32_t h1 = __umulhi(x1, lo32(t.wp)), h2 = __umulhi(x0, hi32(t.wp));
@@ -103,7 +132,20 @@ namespace gpuntt
                 // costs a zero-extending move plus a 64-bit add
                 uint64_t carry;
                 asm("v_mad_u64_u32 %0, %1, %2, 1, %3" : "=v"(qh), "=s"(carry) : "v"(h2), "v"(qh));
-                return x * t.w + qh * qneg;
+                uint64_t c = mad32z<UNI>(x0, hi32(t.w));
+                c = mad32<UNI>(x1, lo32(t.w), c);
+                c = mad32<true>(lo32(qh), hi32(qneg), c);
+                c = mad32<true>(hi32(qh), lo32(qneg), c);
+                uint64_t a = ZERO ? mad32z<UNI>(x0, lo32(t.w)) : mad32<UNI>(x0, lo32(t.w), acc);
+                a = mad32<true>(lo32(qh), lo32(qneg), a);
+                uint32_t ah;
+                asm("v_add_u32 %0, %1, %2" : "=v"(ah) : "v"(hi32(a)), "v"(lo32(c)));
+                return (static_cast<uint64_t>(ah) << 32) | lo32(a);
+            }
+            // x * w  (mod q), any x < 2^64, result in [0, 4q)
+            template <bool UNI = false> __device__ __forceinline__ uint64_t mul(uint64_t x, const Tw64& t) const
+            {
+                return mul_acc<UNI, true>(x, t, 0);
             }
 
             // if (x >= k*q) x -= k*q   -- 4 instructions: v_lshl_add_u64 with the negated constant
@@ -131,10 +173,16 @@ namespace gpuntt
             __device__ __forceinline__ uint32_t reduce_2q(uint32_t x) const { return csub<2>(x); }
             __device__ __forceinline__ uint32_t kq(int k) const { return q * static_cast<uint32_t>(k); }
 
-            __device__ __forceinline__ uint32_t mul(uint32_t x, const Tw32& t) const
+            template <bool UNI = false> __device__ __forceinline__ uint32_t mul(uint32_t x, const Tw32& t) const
             {
                 const uint32_t qh = __umulhi(x, t.wp);
                 return x * t.w - qh * q;
+            }
+            // acc + T, T = x * w (mod q) + {0, 1} q
+            template <bool UNI, bool ZERO = false>
+            __device__ __forceinline__ uint32_t mul_acc(uint32_t x, const Tw32& t, uint32_t acc) const
+            {
+                return acc + mul<UNI>(x, t);
             }
 
             // x < 2*k*q:  min(x, x - k*q) as unsigned (the difference wraps above x when x < k*q)

@@ -71,15 +71,15 @@ namespace gpuntt
                          bool negacyclic, int perm_tile_log, const T* ninv_arr, lazy::Tw<T>* ws_ninv,
                          unsigned* go_flag, lazy::NormConst* norm_arr, hipStream_t stream,
                          const int* mod_order = nullptr, const T* fold_ninv_single = nullptr,
-                         bool fold_ninv_rns = false);
+                         bool fold_ninv_rns = false, unsigned* fused_ctl = nullptr);
         extern template void launch_prep<uint64_t>(const uint64_t*, lazy::Tw64*, const Modulus<uint64_t>*,
                                                    uint64_t, int, int, bool, int, const uint64_t*,
                                                    lazy::Tw64*, unsigned*, lazy::NormConst*, hipStream_t, const int*,
-                                                   const uint64_t*, bool);
+                                                   const uint64_t*, bool, unsigned*);
         extern template void launch_prep<uint32_t>(const uint32_t*, lazy::Tw32*, const Modulus<uint32_t>*,
                                                    uint32_t, int, int, bool, int, const uint32_t*,
                                                    lazy::Tw32*, unsigned*, lazy::NormConst*, hipStream_t, const int*,
-                                                   const uint32_t*, bool);
+                                                   const uint32_t*, bool, unsigned*);
 
         template <typename T>
         void launch_prep_pairs(const T* src, lazy::Tw<T>* dst, unsigned long long count, T q, hipStream_t stream,
@@ -176,6 +176,29 @@ namespace gpuntt
         // stages handled by the contiguous pass of the fast path (GPUNTT_CONTIG_K overrides, 8..12)
         int lazy_contig_k(int n);
 
+        // single-launch kernel (merge_lazy_kernels.hpp: merge_fused_lazy) for two-pass plans on 4096-coefficient
+        // tiles, 64-bit rings 2^14 .. 2^18.  OFF unless GPUNTT_FUSED=1: measured on MI355X (profiles/
+        // r02_fused_single_sweep.md) the XCD's L2 does not keep a line that was just stored (write-around:
+        // a read-back by the same workgroup misses, tools/ubench_l2.hip), so the hand-off between the two
+        // passes goes through the fabric whatever the placement, the launch moves the same 2 x 1 GiB as the
+        // two launches it replaces, and its group barriers make it slower (0.55 vs 0.45 ms at 2^16 x 1024).
+        // GPUNTT_FUSED_MODE=1 builds groups from consecutive block indices, =2 forces the fence protocol
+        // (tests of the placement-independent path).
+        int lazy_fused_env();
+        int lazy_fused_mode();
+        template <typename T> inline bool lazy_use_fused(int n, int tile_log, bool inverse, unsigned long long polys)
+        {
+            (void) inverse;
+            if (sizeof(T) != 8 || tile_log != 12 || polys == 0)
+                return false;
+            return lazy_fused_env() == 1 && n >= 13 && n <= 18;
+        }
+        // one launch for the whole transform; a.fused_ctl must point at zeroed control words
+        template <typename T, bool INV>
+        void launch_fused_lazy(int n, int contig_k, const kern::LazyArgsT<T>& a, hipStream_t stream);
+        extern template void launch_fused_lazy<uint64_t, false>(int, int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
+        extern template void launch_fused_lazy<uint64_t, true>(int, int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
+
         // in_first: the pass reads canonical input (first pass of the transform)
         template <typename T, bool INV>
         void launch_pass_lazy(const Pass& p, int tile_log, bool in_first, bool last,
@@ -195,6 +218,17 @@ namespace gpuntt
         {
             const int tl = lazy_tile_log<T>(base.n, INV, base.total >> base.n);
             const Plan pl = make_plan_tl(base.n, tl, tl == 12 ? lazy_contig_k(base.n) : tl);
+            if constexpr (sizeof(T) == 8)
+            {
+                if (pl.count == 2 && base.fused_ctl != nullptr && lazy_use_fused<T>(base.n, tl, INV, base.total >> base.n))
+                {
+                    kern::LazyArgsT<T> a = base;
+                    a.flags |= first_in_flags | last_out_flags;
+                    a.batch = 0;
+                    launch_fused_lazy<T, INV>(base.n, pl.pass[1].k, a, stream);
+                    return;
+                }
+            }
             const void* src = base.in;
             for (int i = 0; i < pl.count; i++)
             {

@@ -119,16 +119,21 @@ namespace gpuntt
                                                    static_cast<unsigned long long>(batch_size));
             const int perm_tile_log = (n_power >= tl) ? tl : 0;
             const size_t entries = (static_cast<size_t>(mod_count) << n_power) + mod_count;
-            // workspace: twiddle pairs | n^-1 pairs | go-flag | per-modulus normalisation constants
-            const size_t tail = 16 + sizeof(lazy::NormConst) * static_cast<size_t>(mod_count);
+            // workspace: twiddle pairs | n^-1 pairs | go-flag | per-modulus normalisation constants |
+            // control words of the single-sweep kernel (zeroed by the preparation launch)
+            const size_t norm_bytes = (sizeof(lazy::NormConst) * static_cast<size_t>(mod_count) + 15u) & ~size_t(15);
+            const bool fused = host::lazy_use_fused<TU>(n_power, tl, ninv_dev != nullptr || ninv_single != nullptr,
+                                                        static_cast<unsigned long long>(batch_size));
+            const size_t tail = 16 + norm_bytes + (fused ? sizeof(unsigned) * kern::FUSED_CTL_WORDS : 0);
             auto* ws = static_cast<TW*>(host::lazy_workspace(stream, sizeof(TW) * entries + tail));
             TW* ws_ninv = ws + (static_cast<size_t>(mod_count) << n_power);
             unsigned char* tail_p = reinterpret_cast<unsigned char*>(ws + entries);
             unsigned* go_flag = mods ? reinterpret_cast<unsigned*>(tail_p) : nullptr;
             auto* norm_arr = mods ? reinterpret_cast<lazy::NormConst*>(tail_p + 16) : nullptr;
+            unsigned* fused_ctl = fused ? reinterpret_cast<unsigned*>(tail_p + 16 + norm_bytes) : nullptr;
             host::launch_prep<TU>(roots, ws, mods, m.value, mod_count, n_power, neg, perm_tile_log, ninv_dev,
                                   ninv_dev ? ws_ninv : nullptr, go_flag, norm_arr, stream, mod_order, ninv_single,
-                                  ninv_dev != nullptr);
+                                  ninv_dev != nullptr, fused_ctl);
             kern::LazyArgsT<TU> a{};
             a.in = in;
             a.out = out;
@@ -140,6 +145,7 @@ namespace gpuntt
             a.ninv_arr = ninv_dev ? ws_ninv : nullptr;
             a.ninv = TW{0, 0};
             a.go_flag = go_flag;
+            a.fused_ctl = fused_ctl;
             a.mod_order = mod_order;
             a.poly_order = nullptr;
             a.norm = lazy::make_norm_const(static_cast<uint64_t>(m.value), static_cast<uint64_t>(m.bit));

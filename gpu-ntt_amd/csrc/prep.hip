@@ -93,9 +93,15 @@ namespace gpuntt
                                                              unsigned* __restrict__ go_flag,
                                                              lazy::NormConst* __restrict__ norm_arr,
                                                              const int* __restrict__ mod_order,
-                                                             T ninv_single, int fold_ninv)
+                                                             T ninv_single, int fold_ninv,
+                                                             unsigned* __restrict__ fused_ctl)
         {
             const unsigned long long gid = blockIdx.x * 256ull + threadIdx.x;
+            // control words of the single-sweep kernel launched behind this one (grid-stride: tiny tables)
+            if (fused_ctl != nullptr)
+                for (unsigned long long i = gid; i < static_cast<unsigned long long>(FUSED_CTL_WORDS);
+                     i += static_cast<unsigned long long>(gridDim.x) * 256ull)
+                    fused_ctl[i] = 0u;
             if (gid == 0 && go_flag != nullptr)
             {
                 // every modulus must leave the lazy kernels their headroom
@@ -336,6 +342,41 @@ namespace gpuntt
             return 12;
         }
 
+        int lazy_fused_env()
+        {
+            static const int v = [] {
+                const char* e = std::getenv("GPUNTT_FUSED");
+                return e ? std::atoi(e) : -1; // -1: size heuristic
+            }();
+            return v;
+        }
+        int lazy_fused_mode()
+        {
+            static const int v = [] {
+                const char* e = std::getenv("GPUNTT_FUSED_MODE");
+                return e ? std::atoi(e) : 0;
+            }();
+            return v;
+        }
+        int device_cu_count()
+        {
+            // per device, cached: the grid of the persistent kernel is sized from it
+            static std::mutex mu;
+            static std::map<int, int> cache;
+            int dev = 0;
+            GPUNTT_HIP_CHECK(hipGetDevice(&dev));
+            std::lock_guard<std::mutex> lock(mu);
+            auto it = cache.find(dev);
+            if (it != cache.end())
+                return it->second;
+            int cus = 0;
+            GPUNTT_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+            if (cus <= 0)
+                cus = 256;
+            cache[dev] = cus;
+            return cus;
+        }
+
         int lazy_u64_big_tiles()
         {
             static const int v = [] {
@@ -381,14 +422,14 @@ namespace gpuntt
         void launch_prep(const T* roots, lazy::Tw<T>* ws, const Modulus<T>* mods, T q, int mod_count, int n,
                          bool negacyclic, int perm_tile_log, const T* ninv_arr, lazy::Tw<T>* ws_ninv,
                          unsigned* go_flag, lazy::NormConst* norm_arr, hipStream_t stream, const int* mod_order,
-                         const T* fold_ninv_single, bool fold_ninv_rns)
+                         const T* fold_ninv_single, bool fold_ninv_rns, unsigned* fused_ctl)
         {
             const unsigned long long entries = static_cast<unsigned long long>(mod_count) << n;
             const unsigned grid = static_cast<unsigned>((entries + 255) / 256);
             hipLaunchKernelGGL((kern::prep_twiddles<T>), dim3(grid), dim3(256), 0, stream, roots, ws, mods, q,
                                (mods == nullptr) ? recip_norm_host<T>(q) : static_cast<T>(0), mod_count, n, negacyclic ? 1 : 0, perm_tile_log, ninv_arr, ws_ninv, go_flag, norm_arr, mod_order,
                                fold_ninv_single ? *fold_ninv_single : static_cast<T>(0),
-                               (fold_ninv_single != nullptr || (fold_ninv_rns && ninv_arr != nullptr)) ? 1 : 0);
+                               (fold_ninv_single != nullptr || (fold_ninv_rns && ninv_arr != nullptr)) ? 1 : 0, fused_ctl);
             GPUNTT_HIP_CHECK(hipGetLastError());
         }
         template <typename T>
@@ -441,9 +482,9 @@ namespace gpuntt
 
         template void launch_prep<uint64_t>(const uint64_t*, lazy::Tw64*, const Modulus<uint64_t>*, uint64_t, int,
                                             int, bool, int, const uint64_t*, lazy::Tw64*, unsigned*, lazy::NormConst*, hipStream_t, const int*,
-                                            const uint64_t*, bool);
+                                            const uint64_t*, bool, unsigned*);
         template void launch_prep<uint32_t>(const uint32_t*, lazy::Tw32*, const Modulus<uint32_t>*, uint32_t, int,
                                             int, bool, int, const uint32_t*, lazy::Tw32*, unsigned*, lazy::NormConst*, hipStream_t, const int*,
-                                            const uint32_t*, bool);
+                                            const uint32_t*, bool, unsigned*);
     } // namespace host
 } // namespace gpuntt

@@ -1,0 +1,148 @@
+// ubench_bfly.hip -- register-only microbenchmark of the 64-bit lazy butterfly (gfx950): how many
+// SIMD cycles one radix-2 butterfly costs when nothing but the VALU is involved (no LDS, no memory).
+// One "round" = 4 stages on 16 registers = 32 butterflies with the range corrections of a steady-state
+// forward pass (one conditional subtraction of 8q on U every second stage), twiddles per lane (VGPR)
+// or wave-uniform (SGPR).  Variants: the multiply written in plain C++ (round-1 formulation: mul_lo +
+// add3 cross terms, separate U + T) and the multiply-add chain of lazy.hpp.
+//   hipcc --offload-arch=gfx950 -O3 -I gpu-ntt_amd/csrc -I include tools/ubench_bfly.hip -o tools/ubench_bfly
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+
+#include "lazy.hpp"
+
+using namespace gpuntt::lazy;
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+// round-1 formulation (kept here for the A/B only)
+__device__ __forceinline__ uint64_t mul_r1(const Mod<uint64_t>& m, uint64_t x, const Tw64& t)
+{
+    const uint32_t x0 = lo32(x), x1 = hi32(x);
+    const uint32_t h1 = __umulhi(x1, lo32(t.wp)), h2 = __umulhi(x0, hi32(t.wp));
+    uint64_t qh = static_cast<uint64_t>(x1) * hi32(t.wp) + h1;
+    uint64_t carry;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %3" : "=v"(qh), "=s"(carry) : "v"(h2), "v"(qh));
+    return x * t.w + qh * m.qneg;
+}
+
+template <int VARIANT, bool UNI, bool CSUB>
+__global__ __launch_bounds__(256, 4) void bfly_rounds(uint64_t* out, const Tw64* tw, uint64_t q, int iters)
+{
+    Mod<uint64_t> m;
+    m.set(q, make_norm_const(q, 60));
+    uint64_t v[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++)
+        v[j] = (threadIdx.x * 16 + j) * 0x9E3779B97F4A7C15ull % q;
+    // 8 distinct twiddles per thread keep the per-lane variant inside the 128-VGPR budget of 4 waves per SIMD
+    Tw64 t[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        t[i] = UNI ? tw[i + (blockIdx.x & 1)] : tw[threadIdx.x * 8 + i];
+    for (int it = 0; it < iters; it++)
+    {
+        int off = 0;
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+        {
+            const int jb = 3 - s;
+#pragma unroll
+            for (int h = 0; h < 8; h++)
+            {
+                const int j0 = (h & ((1 << jb) - 1)) | ((h >> jb) << (jb + 1));
+                const int j1 = j0 | (1 << jb);
+                const Tw64 w = t[(off + (j0 >> (jb + 1))) & 7];
+                uint64_t U = v[j0];
+                if (CSUB && (s & 1))
+                    U = m.csub<8>(U);
+                if (VARIANT == 0)
+                {
+                    const uint64_t T = mul_r1(m, v[j1], w);
+                    v[j0] = U + T;
+                    v[j1] = U + m.kq(4) - T;
+                }
+                else
+                {
+                    const uint64_t nu = m.mul_acc<UNI>(v[j1], w, U);
+                    v[j0] = nu;
+                    v[j1] = (U << 1) + m.kq(4) - nu;
+                }
+            }
+            off += 1 << (3 - jb);
+        }
+        // keep the values in range for the next round without extra work in the loop: the
+        // arithmetic is mod 2^64 either way, only the timing is read
+    }
+    uint64_t r = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++)
+        r ^= v[j];
+    if (r == 0x1234567)
+        out[0] = r;
+}
+
+static bool g_sustained = false;
+
+template <int VARIANT, bool UNI, bool CSUB>
+int run(const char* name, uint64_t* d_out, const Tw64* d_tw, uint64_t q, int blocks_per_cu)
+{
+    const int iters = 200;
+    const int grid = 256 * blocks_per_cu;
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    for (int w = 0; w < 3; w++)
+        hipLaunchKernelGGL((bfly_rounds<VARIANT, UNI, CSUB>), dim3(grid), dim3(256), 0, 0, d_out, d_tw, q, iters);
+    CHECK(hipDeviceSynchronize());
+    // sustained = true: ~1.5 s of back-to-back launches first, so the timed launches run at the clock the
+    // part holds under its power cap rather than at the boost clock of a short burst
+    if (g_sustained)
+    {
+        for (int w = 0; w < int(1500.0 / (0.19 * blocks_per_cu)); w++)
+            hipLaunchKernelGGL((bfly_rounds<VARIANT, UNI, CSUB>), dim3(grid), dim3(256), 0, 0, d_out, d_tw, q, iters);
+    }
+    const int reps = 10;
+    CHECK(hipEventRecord(e0));
+    for (int w = 0; w < reps; w++)
+        hipLaunchKernelGGL((bfly_rounds<VARIANT, UNI, CSUB>), dim3(grid), dim3(256), 0, 0, d_out, d_tw, q, iters);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    ms /= reps;
+    // per SIMD: blocks_per_cu waves, each iters * 32 butterflies
+    const double bf_per_simd = double(blocks_per_cu) * iters * 32.0;
+    const double cyc = ms * 1e-3 * 2.4e9 / bf_per_simd;
+    printf("%-34s %d wave/SIMD  %8.3f ms  %6.1f cycles/butterfly/SIMD (@2.4 GHz nominal)\n", name, blocks_per_cu, ms, cyc);
+    return 0;
+}
+
+int main(int argc, char** argv)
+{
+    g_sustained = (argc > 1 && argv[1][0] == 's');
+    printf("%s\n", g_sustained ? "sustained (1.5 s of load before each timing)" : "burst");
+    const uint64_t q = 576460756061519873ull;
+    uint64_t* d_out;
+    Tw64* d_tw;
+    CHECK(hipMalloc(&d_out, 64));
+    std::vector<Tw64> h(256 * 15 + 16);
+    for (size_t i = 0; i < h.size(); i++)
+    {
+        h[i].w = (i * 0x9E3779B97F4A7C15ull + 12345) % q;
+        h[i].wp = static_cast<uint64_t>((static_cast<unsigned __int128>(h[i].w) << 64) / q);
+    }
+    CHECK(hipMalloc(&d_tw, h.size() * sizeof(Tw64)));
+    CHECK(hipMemcpy(d_tw, h.data(), h.size() * sizeof(Tw64), hipMemcpyHostToDevice));
+    for (int occ = (g_sustained ? 4 : 1); occ <= 4; occ *= 2)
+    {
+        run<0, false, true>("r1 mul, lane twiddles, csub/2", d_out, d_tw, q, occ);
+        run<1, false, true>("mad chain, lane twiddles, csub/2", d_out, d_tw, q, occ);
+        run<0, true, true>("r1 mul, scalar twiddles, csub/2", d_out, d_tw, q, occ);
+        run<1, true, true>("mad chain, scalar twiddles, csub/2", d_out, d_tw, q, occ);
+        run<0, false, false>("r1 mul, lane twiddles, no csub", d_out, d_tw, q, occ);
+        run<1, false, false>("mad chain, lane twiddles, no csub", d_out, d_tw, q, occ);
+    }
+    return 0;
+}
