@@ -87,8 +87,9 @@ EXPORTED_SYMBOLS = ["gpuntt_last_error", "gpuntt_version"] + [
     for f in ("modulus", "ntt", "intt", "ntt_rns", "intt_rns", "ntt_modulus_ordered",
               "ntt_poly_ordered", "polymul", "polymul_rns", "4step", "4step_rns", "4step_natural", "transpose",
               "merge_params",
-              "4step_params")
-    for s in ("u32", "u64")]
+              "4step_params", "plan_workspace_bytes", "plan_create", "plan_execute", "plan_fast_path",
+              "plan_destroy", "operator_gpu")
+    for s in ("u32", "u64")] + ["gpuntt_release_workspaces"]
 
 
 def _check(rc):
@@ -414,6 +415,77 @@ def GPU_4STEP_NTT_NaturalOrder(device_in, device_out, n1_root_of_unity_table, n2
     _check(fn(_ptr(device_in), _ptr(device_out), _ptr(n1_root_of_unity_table),
               _ptr(n2_root_of_unity_table), _ptr(W_root_of_unity_table), modulus.c(), cfg.n_power,
               cfg.ntt_type, _ct(bits)(cfg.mod_inverse), _stream(cfg.stream), batch_size))
+
+
+class NTTPlan:
+    """Extension NTTPlan<T> (include/gpuntt/ntt_merge/ntt.cuh): twiddles prepared once into a workspace;
+    execute() launches the transform kernels only (no allocation, synchronisation or preparation).
+    `moduli` is a Modulus or a list of Modulus (RNS: polynomial p uses modulus p % len); `mod_inverse`
+    an int or list of ints (inverse plans); `workspace` an optional uint8 device tensor of
+    workspace_bytes() bytes owned by the caller."""
+
+    def __init__(self, table_device, moduli, n_power, reduction_poly=X_N_minus, ntt_type=FORWARD,
+                 mod_inverse=None, batch_hint=1024, stream=None, workspace=None):
+        lib = load_library()
+        _require_gpu(table_device)
+        moduli = [moduli] if isinstance(moduli, Modulus) else list(moduli)
+        self.bits = moduli[0].bits
+        self.n_power, self.ntt_type, self.mod_count = n_power, ntt_type, len(moduli)
+        T = _ct(self.bits)
+        marr = ((_M32 if self.bits == 32 else _M64) * len(moduli))(*[m.c() for m in moduli])
+        ninv = None
+        if mod_inverse is not None:
+            vals = [mod_inverse] if isinstance(mod_inverse, int) else list(mod_inverse)
+            ninv = (T * len(vals))(*vals)
+        self._keep = (table_device, workspace)
+        self._h = ctypes.c_void_p()
+        fn = getattr(lib, "gpuntt_plan_create_u%d" % self.bits)
+        _check(fn(ctypes.byref(self._h), _ptr(table_device), marr, len(moduli), n_power, reduction_poly,
+                  ntt_type, ninv, int(batch_hint), _ptr(workspace), _stream(stream)))
+
+    @staticmethod
+    def workspace_bytes(n_power, mod_count=1, bits=64):
+        lib = load_library()
+        out = ctypes.c_uint64()
+        _check(getattr(lib, "gpuntt_plan_workspace_bytes_u%d" % bits)(n_power, mod_count, ctypes.byref(out)))
+        return int(out.value)
+
+    @property
+    def fast_path(self):
+        return bool(getattr(load_library(), "gpuntt_plan_fast_path_u%d" % self.bits)(self._h))
+
+    def execute(self, device_in, device_out, batch_size, stream=None, io_signed=False):
+        _require_gpu(device_in, device_out)
+        fn = getattr(load_library(), "gpuntt_plan_execute_u%d" % self.bits)
+        _check(fn(self._h, _ptr(device_in), _ptr(device_out), int(batch_size), int(io_signed), _stream(stream)))
+
+    def close(self):
+        if self._h:
+            getattr(load_library(), "gpuntt_plan_destroy_u%d" % self.bits)(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def release_workspaces():
+    """GPU_NTT_ReleaseWorkspaces(): frees the library-owned twiddle scratch of the drop-in calls."""
+    _check(load_library().gpuntt_release_workspaces())
+
+
+def operator_gpu(op, a, b, modulus):
+    """diagnostic: OPERATOR_GPU<T>::{add, sub, mult, reduce, reduce(signed), centered_reduction}
+    (op 0..5) elementwise on device tensors; returns a new tensor"""
+    import torch
+    lib = load_library()
+    _require_gpu(a, b)
+    out = torch.empty_like(a)
+    fn = getattr(lib, "gpuntt_operator_gpu_u%d" % modulus.bits)
+    _check(fn(int(op), _ptr(a), _ptr(b), _ptr(out), modulus.c(), ctypes.c_uint64(a.numel()), _stream(None)))
+    return out
 
 
 # ------------------------------------------------------------------ multi-GPU batch shard

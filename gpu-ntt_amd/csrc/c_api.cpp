@@ -4,6 +4,7 @@
 #include <initializer_list>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "gpuntt/ntt_4step/ntt_4step.cuh"
 #include "gpuntt/ntt_merge/ntt.cuh"
@@ -317,9 +318,74 @@ namespace
     }
 } // namespace
 
+namespace
+{
+    // OPERATOR_GPU<T> applied elementwise (diagnostic entry point: the public device class on real hardware)
+    template <typename T>
+    __global__ __launch_bounds__(256) void operator_gpu_apply(int op, const T* a, const T* b, T* out, Modulus<T> m,
+                                                              unsigned long long count)
+    {
+        using S = typename std::make_signed<T>::type;
+        for (unsigned long long i = blockIdx.x * 256ull + threadIdx.x; i < count;
+             i += static_cast<unsigned long long>(gridDim.x) * 256ull)
+        {
+            const T x = a[i];
+            const T y = (b != nullptr) ? b[i] : T(0);
+            T r = 0;
+            switch (op)
+            {
+                case 0: r = OPERATOR_GPU<T>::add(x, y, m); break;
+                case 1: r = OPERATOR_GPU<T>::sub(x, y, m); break;
+                case 2: r = OPERATOR_GPU<T>::mult(x, y, m); break;
+                case 3: r = OPERATOR_GPU<T>::reduce(x, m); break;
+                case 4: r = OPERATOR_GPU<T>::reduce(static_cast<S>(x), m); break;
+                default: r = static_cast<T>(OPERATOR_GPU<T>::centered_reduction(x, m)); break;
+            }
+            out[i] = r;
+        }
+    }
+    template <typename T, typename CM>
+    int operator_gpu(int op, const T* a, const T* b, T* out, const CM& cm, uint64_t count, void* stream)
+    {
+        return guarded([&] {
+            if (op < 0 || op > 5)
+                throw std::invalid_argument("Invalid operator!");
+            if (count == 0)
+                return;
+            unsigned long long blocks = (count + 255) / 256;
+            if (blocks > 65536)
+                blocks = 65536;
+            hipLaunchKernelGGL((operator_gpu_apply<T>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0,
+                               static_cast<hipStream_t>(stream), op, a, b, out, to_mod<T>(cm), count);
+            GPUNTT_HIP_CHECK(hipGetLastError());
+        });
+    }
+
+    template <typename T, typename CM>
+    int plan_create(gpuntt_plan** plan, const T* table, const CM* moduli, int mod_count, int n_power, int poly,
+                    int ntt_type, const T* ninv, int batch_hint, void* ws, void* stream)
+    {
+        return guarded([&] {
+            if (plan == nullptr || moduli == nullptr || mod_count <= 0)
+                throw std::invalid_argument("Invalid mod_count!");
+            std::vector<Modulus<T>> ms;
+            for (int i = 0; i < mod_count; i++)
+                ms.push_back(to_mod<T>(moduli[i]));
+            auto* p = new NTTPlan<T>(table, ms.data(), mod_count, n_power, static_cast<ReductionPolynomial>(poly),
+                                     static_cast<type>(ntt_type), ninv, batch_hint,
+                                     static_cast<hipStream_t>(stream), ws);
+            *plan = reinterpret_cast<gpuntt_plan*>(p);
+        });
+    }
+} // namespace
+
 extern "C"
 {
     const char* gpuntt_last_error(void) { return g_last_error.c_str(); }
+    int gpuntt_release_workspaces(void)
+    {
+        return guarded([] { GPU_NTT_ReleaseWorkspaces(); });
+    }
     int gpuntt_version(void) { return 100; }
 
     int gpuntt_modulus_u32(uint32_t q, gpuntt_modulus32* out)
@@ -455,6 +521,45 @@ extern "C"
     {                                                                                             \
         return fourstep_params<T>(logn, inverse, info_host, n1_table_host, n2_table_host,         \
                                   w_table_host);                                                  \
+    }                                                                                             \
+    int gpuntt_plan_workspace_bytes_##S(int n_power, int mod_count, uint64_t* bytes_host)         \
+    {                                                                                             \
+        GPUNTT_NEED(bytes_host)                                                                   \
+        return guarded([&] { *bytes_host = NTTPlan<T>::workspace_bytes(n_power, mod_count); });    \
+    }                                                                                             \
+    int gpuntt_plan_create_##S(gpuntt_plan** plan_host, const T* table, const CM* moduli_host,    \
+                               int mod_count, int n_power, int reduction_poly, int ntt_type,      \
+                               const T* mod_inverse_host, int batch_hint, void* workspace_device, \
+                               void* stream)                                                      \
+    {                                                                                             \
+        GPUNTT_NEED(plan_host, table, moduli_host)                                                \
+        return plan_create<T>(plan_host, table, moduli_host, mod_count, n_power, reduction_poly,  \
+                              ntt_type, mod_inverse_host, batch_hint, workspace_device, stream);  \
+    }                                                                                             \
+    int gpuntt_plan_execute_##S(const gpuntt_plan* plan, const void* in, void* out,               \
+                                int batch_size, int io_signed, void* stream)                      \
+    {                                                                                             \
+        GPUNTT_NEED(plan, in, out)                                                                \
+        return guarded([&] {                                                                      \
+            reinterpret_cast<const NTTPlan<T>*>(plan)->execute(in, out, batch_size,               \
+                                                               static_cast<hipStream_t>(stream),  \
+                                                               io_signed != 0);                   \
+        });                                                                                       \
+    }                                                                                             \
+    int gpuntt_plan_fast_path_##S(const gpuntt_plan* plan)                                        \
+    {                                                                                             \
+        GPUNTT_NEED(plan)                                                                         \
+        return reinterpret_cast<const NTTPlan<T>*>(plan)->fast_path() ? 1 : 0;                    \
+    }                                                                                             \
+    int gpuntt_plan_destroy_##S(gpuntt_plan* plan)                                                \
+    {                                                                                             \
+        return guarded([&] { delete reinterpret_cast<NTTPlan<T>*>(plan); });                      \
+    }                                                                                             \
+    int gpuntt_operator_gpu_##S(int op, const T* a, const T* b, T* out, CM modulus,               \
+                                uint64_t count, void* stream)                                     \
+    {                                                                                             \
+        GPUNTT_NEED(a, out)                                                                       \
+        return operator_gpu<T>(op, a, b, out, modulus, count, stream);                            \
     }
 
     GPUNTT_C_API(u32, uint32_t, gpuntt_modulus32)

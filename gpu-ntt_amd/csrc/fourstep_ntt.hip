@@ -62,10 +62,16 @@ namespace gpuntt
         {
             if (batch_size <= 0 || row <= 0 || col <= 0)
                 return;
-            const dim3 grid((col + 31) / 32, (row + 31) / 32, batch_size);
-            hipLaunchKernelGGL((kern::transpose_batch<T>), grid, dim3(256), 0, stream, in, out, row, col,
-                               1ull << n_power);
-            GPUNTT_HIP_CHECK(hipGetLastError());
+            // gridDim.z is limited to 65535: larger batches go out in slices
+            for (int done = 0; done < batch_size; done += 65535)
+            {
+                const int part = (batch_size - done < 65535) ? (batch_size - done) : 65535;
+                const dim3 grid((col + 31) / 32, (row + 31) / 32, part);
+                const unsigned long long off = static_cast<unsigned long long>(done) << n_power;
+                hipLaunchKernelGGL((kern::transpose_batch<T>), grid, dim3(256), 0, stream, in + off, out + off, row,
+                                   col, 1ull << n_power);
+                GPUNTT_HIP_CHECK(hipGetLastError());
+            }
         }
     } // namespace
 
@@ -439,6 +445,7 @@ namespace gpuntt
                                 Root<T>* n2_root_of_unity_table, Root<T>* W_root_of_unity_table,
                                 Modulus<T> modulus, ntt4step_configuration<T> cfg, int batch_size)
     {
+        host::WorkspaceScope ws_scope; // scratch lock held until the last launch of this call
         fourstep_dispatch<T>(device_in, device_out, n1_root_of_unity_table, n2_root_of_unity_table,
                              W_root_of_unity_table, nullptr, modulus, 1, nullptr, cfg.mod_inverse,
                              cfg.n_power, cfg.ntt_type, batch_size, cfg.stream);
@@ -450,6 +457,7 @@ namespace gpuntt
                                 Modulus<T>* modulus, ntt4step_rns_configuration<T> cfg,
                                 int batch_size, int mod_count)
     {
+        host::WorkspaceScope ws_scope; // scratch lock held until the last launch of this call
         if (mod_count <= 0 || modulus == nullptr)
             throw std::invalid_argument("Invalid mod_count!");
         fourstep_dispatch<T>(device_in, device_out, n1_root_of_unity_table, n2_root_of_unity_table,
@@ -469,6 +477,7 @@ namespace gpuntt
                                              Root<T>* n2_root_of_unity_table, Root<T>* W_root_of_unity_table,
                                              Modulus<T> modulus, ntt4step_configuration<T> cfg, int batch_size)
     {
+        host::WorkspaceScope ws_scope; // scratch lock held until the last launch of this call
         int l1 = 0, l2 = 0;
         if ((cfg.ntt_type != FORWARD && cfg.ntt_type != INVERSE) || !fourstep_shape(cfg.n_power, l1, l2))
         {

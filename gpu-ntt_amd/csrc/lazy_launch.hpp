@@ -58,8 +58,19 @@ namespace gpuntt
             return (n >= 20 && n <= 22) ? 14 : 12;
         }
 
-        // per-(device, stream) scratch for prepared twiddles; grows on demand, stream-ordered reuse
+        // per-(device, stream) scratch for prepared twiddles; grows on demand, stream-ordered reuse.
+        // Inside a WorkspaceScope (every public entry point opens one) the calling thread keeps the
+        // buffer's lock until the scope ends, i.e. from the preparation launch to the last kernel launch
+        // of the call: two host threads on one stream can no longer interleave A.prep, B.prep, A.kernels.
         void* lazy_workspace(hipStream_t stream, size_t bytes);
+        struct WorkspaceScope
+        {
+            WorkspaceScope();
+            ~WorkspaceScope();
+            WorkspaceScope(const WorkspaceScope&) = delete;
+            WorkspaceScope& operator=(const WorkspaceScope&) = delete;
+        };
+        void release_workspaces();
 
         // fills ws[0 .. mod_count*N) with Shoup pairs of the caller's table (device order) and
         // ws_ninv[0 .. mod_count) with the pairs of n^-1 (RNS only); perm_tile_log > 0 permutes
@@ -212,11 +223,12 @@ namespace gpuntt
         extern template void launch_pass_lazy<uint32_t, true>(const Pass&, int, bool, bool,
                                                               const kern::LazyArgsT<uint32_t>&, hipStream_t);
 
+        // forced_tl: tile size the twiddle table was prepared for (NTTPlan); 0 = choose from the batch
         template <typename T, bool INV>
         inline void run_transform_lazy(kern::LazyArgsT<T> base, unsigned first_in_flags,
-                                       unsigned last_out_flags, hipStream_t stream)
+                                       unsigned last_out_flags, hipStream_t stream, int forced_tl = 0)
         {
-            const int tl = lazy_tile_log<T>(base.n, INV, base.total >> base.n);
+            const int tl = forced_tl ? forced_tl : lazy_tile_log<T>(base.n, INV, base.total >> base.n);
             const Plan pl = make_plan_tl(base.n, tl, tl == 12 ? lazy_contig_k(base.n) : tl);
             if constexpr (sizeof(T) == 8)
             {

@@ -48,7 +48,8 @@ namespace gpuntt
             F_SCALE = 4u,      // inverse last pass: multiply by n^-1
             F_CENTERED = 8u,   // inverse last pass: emit centred signed residues
             F_FOURSTEP_T = 16u, // 4-step phase 1: transposed store with W multiply
-            F_MULTI = 32u // a tile may span polynomials with different moduli (RNS, N < tile)
+            F_MULTI = 32u, // a tile may span polynomials with different moduli (RNS, N < tile)
+            F_COLMOD = 64u // PerCoefficient RNS: the modulus follows the COLUMN (flat & (2^n2_log - 1)) % mod_count
         };
 
         template <typename T> struct PassArgs
@@ -177,6 +178,17 @@ namespace gpuntt
             return c;
         }
 
+        // index of the polynomial a flat coefficient index belongs to: the row-major batch slot, or --
+        // PerCoefficient layout -- the matrix column (reference ForwardCoreTranspose, ntt.cu:1737-1741:
+        // batch_index % mod_count picks the modulus, tables at mod_index << log_row)
+        template <typename T>
+        __device__ __forceinline__ unsigned long long poly_of(const PassArgs<T>& a, unsigned long long flat)
+        {
+            if (a.flags & F_COLMOD)
+                return flat & ((1ull << a.n2_log) - 1ull);
+            return flat >> a.poly_shift;
+        }
+
         // logical flat index (polynomial p, coefficient i) -> memory index; only *_Poly_Ordered
         // calls remap the polynomial slot (reference ForwardCorePolyOrdered, ntt.cu:3797-3798)
         template <typename T>
@@ -237,7 +249,7 @@ namespace gpuntt
                         const unsigned idx = static_cast<unsigned>(flat) & ((1u << a.n) - 1u);
                         Ctx<T> c = blk_ctx;
                         if (a.flags & F_MULTI)
-                            c = make_ctx(a, flat >> a.poly_shift);
+                            c = make_ctx(a, poly_of(a, flat));
                         unsigned ti = idx >> (P + 1);
                         if (a.flags & F_NEGACYCLIC)
                             ti += 1u << (a.n - 1 - P);
@@ -275,7 +287,7 @@ namespace gpuntt
             const TileMap<T, CONTIG, K> map(a, tile);
             // block-uniform context (exact when the tile lies inside one polynomial; with
             // F_MULTI it is refreshed per butterfly)
-            const Ctx<T> ctx = make_ctx(a, map.flat(0) >> a.poly_shift);
+            const Ctx<T> ctx = make_ctx(a, poly_of(a, map.flat(0)));
 
             T v[EPT];
 
@@ -295,7 +307,7 @@ namespace gpuntt
                             const unsigned long long f = map.flat(elem_of<WL>(t, j));
                             T q = ctx.m.q;
                             if ((a.flags & (F_MULTI | F_SIGNED_IN)) == (F_MULTI | F_SIGNED_IN))
-                                q = make_ctx(a, f >> a.poly_shift).m.q;
+                                q = make_ctx(a, poly_of(a, f)).m.q;
                             v[j] = load_in(a, f, q);
                         }
                     }
@@ -309,7 +321,7 @@ namespace gpuntt
                             const unsigned long long f = map.flat(e);
                             T q = ctx.m.q;
                             if ((a.flags & (F_MULTI | F_SIGNED_IN)) == (F_MULTI | F_SIGNED_IN))
-                                q = make_ctx(a, f >> a.poly_shift).m.q;
+                                q = make_ctx(a, poly_of(a, f)).m.q;
                             lds[lds_pad(e)] = load_in(a, f, q);
                         }
                         __syncthreads();
@@ -336,7 +348,7 @@ namespace gpuntt
                         {
                             Ctx<T> c = ctx;
                             if (a.flags & F_MULTI)
-                                c = make_ctx(a, f >> a.poly_shift);
+                                c = make_ctx(a, poly_of(a, f));
                             x = c.m.mul(x, c.ninv);
                             if (a.flags & F_CENTERED)
                             {
@@ -416,10 +428,25 @@ namespace gpuntt
         __global__ __launch_bounds__(256) void column_ntt_small(PassArgs<T> a, int n, int log_w, int cols_log)
         {
             using S = typename std::make_signed<T>::type;
-            const dev::ModCtx<T> m = (a.mods != nullptr)
-                                         ? dev::ModCtx<T>{a.mods[0].value, a.mods[0].bit, a.mods[0].mu}
-                                         : dev::ModCtx<T>{a.mod.value, a.mod.bit, a.mod.mu};
-            const T ninv = (a.ninv_arr != nullptr) ? a.ninv_arr[0] : a.ninv;
+            // column c uses modulus c % mod_count, its table at (c % mod_count) << n and its n^-1
+            auto ctx_of = [&](unsigned c) -> Ctx<T> {
+                Ctx<T> r;
+                if (a.mods != nullptr)
+                {
+                    const int mi = static_cast<int>(c % static_cast<unsigned>(a.mod_count));
+                    const Modulus<T> md = a.mods[mi];
+                    r.m = dev::ModCtx<T>{md.value, md.bit, md.mu};
+                    r.ninv = (a.ninv_arr != nullptr) ? a.ninv_arr[mi] : a.ninv;
+                    r.root_base = (a.mod_count > 1) ? (static_cast<unsigned long long>(mi) << n) : 0ull;
+                }
+                else
+                {
+                    r.m = dev::ModCtx<T>{a.mod.value, a.mod.bit, a.mod.mu};
+                    r.ninv = a.ninv;
+                    r.root_base = 0;
+                }
+                return r;
+            };
             const unsigned w = 1u << log_w, nrow = 1u << n, cols = 1u << cols_log;
             const unsigned col0 = blockIdx.x << cols_log;
             const unsigned half = (nrow >> 1) << cols_log; // butterflies per stage in this block
@@ -432,7 +459,7 @@ namespace gpuntt
                 if (a.flags & F_SIGNED_IN)
                 {
                     const S sv = static_cast<const S*>(a.in)[f];
-                    x = (sv < 0) ? static_cast<T>(m.q + static_cast<T>(sv)) : static_cast<T>(sv);
+                    x = (sv < 0) ? static_cast<T>(ctx_of(c).m.q + static_cast<T>(sv)) : static_cast<T>(sv);
                 }
                 else
                     x = static_cast<const T*>(a.in)[f];
@@ -451,7 +478,9 @@ namespace gpuntt
                     unsigned ti = grp;
                     if (a.flags & F_NEGACYCLIC)
                         ti += 1u << (n - 1 - P);
-                    const T tw = a.roots[ti];
+                    const Ctx<T> cx = ctx_of(c);
+                    const dev::ModCtx<T>& m = cx.m;
+                    const T tw = a.roots[cx.root_base + ti];
                     const unsigned long long f0 = static_cast<unsigned long long>(r0) * w + c;
                     const unsigned long long f1 = f0 + (static_cast<unsigned long long>(1u << P) * w);
                     T U = a.out[f0], V = a.out[f1];
@@ -469,9 +498,10 @@ namespace gpuntt
                 {
                     const unsigned r = e >> cols_log, c = col0 + (e & (cols - 1));
                     const unsigned long long f = static_cast<unsigned long long>(r) * w + c;
-                    T x = m.mul(a.out[f], ninv);
+                    const Ctx<T> cx = ctx_of(c);
+                    T x = cx.m.mul(a.out[f], cx.ninv);
                     if (a.flags & F_CENTERED)
-                        x = (x > (m.q >> 1)) ? static_cast<T>(x - m.q) : x;
+                        x = (x > (cx.m.q >> 1)) ? static_cast<T>(x - cx.m.q) : x;
                     a.out[f] = x;
                 }
         }

@@ -8,6 +8,7 @@
 // `device_out`, cfg.ntt_type / cfg.zero_padding ignored.
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "gpuntt/ntt_merge/ntt.cuh"
 #include "launch.hpp"
@@ -174,8 +175,6 @@ namespace gpuntt
                 return;
             if ((batch_size & (batch_size - 1)) != 0)
                 throw std::invalid_argument("PerCoefficient batch_size must be a power of two!");
-            if (a.mod_count > 1)
-                throw std::invalid_argument("PerCoefficient with mod_count > 1 is not supported!");
             int log_w = 0;
             while ((1 << log_w) < batch_size)
                 log_w++;
@@ -184,6 +183,15 @@ namespace gpuntt
             a.poly_shift = nv;
             a.root_shift = -1;
             a.total = 1ull << nv;
+            if (a.mods != nullptr && a.mod_count > 1)
+            {
+                // RNS: column c is a polynomial of modulus c % mod_count with its own table slot and n^-1
+                // (the intent of reference ForwardCoreTranspose / InverseCoreTranspose, ntt.cu:1693-1835,
+                // 1957-2074: mod_index = batch_index % mod_count, roots at mod_index << log_row)
+                a.flags |= kern::F_MULTI | kern::F_COLMOD;
+                a.n2_log = log_w;
+                a.root_shift = n_power;
+            }
             // stages split into strided passes of <= 8, highest first (forward order)
             host::Plan pl{};
             const int np = (n_power + 7) / 8;
@@ -234,6 +242,7 @@ namespace gpuntt
                           ntt_configuration<typename std::make_unsigned<T>::type> cfg,
                           int batch_size)
     {
+        host::WorkspaceScope ws_scope; // scratch lock held until the last launch of this call
         using TU = typename std::make_unsigned<T>::type;
         check_layout_and_range(cfg.ntt_layout, cfg.n_power);
         const unsigned in_flags = std::is_signed<T>::value ? kern::F_SIGNED_IN : 0u;
@@ -267,6 +276,7 @@ namespace gpuntt
                            ntt_configuration<typename std::make_unsigned<T>::type> cfg,
                            int batch_size)
     {
+        host::WorkspaceScope ws_scope; // scratch lock held until the last launch of this call
         using TU = typename std::make_unsigned<T>::type;
         check_layout_and_range(cfg.ntt_layout, cfg.n_power);
         const unsigned out_flags =
@@ -322,6 +332,7 @@ namespace gpuntt
                           ntt_rns_configuration<typename std::make_unsigned<T>::type> cfg,
                           int batch_size, int mod_count)
     {
+        host::WorkspaceScope ws_scope; // scratch lock held until the last launch of this call
         using TU = typename std::make_unsigned<T>::type;
         check_layout_and_range(cfg.ntt_layout, cfg.n_power);
         if (mod_count <= 0 || modulus == nullptr)
@@ -361,6 +372,7 @@ namespace gpuntt
                            ntt_rns_configuration<typename std::make_unsigned<T>::type> cfg,
                            int batch_size, int mod_count)
     {
+        host::WorkspaceScope ws_scope; // scratch lock held until the last launch of this call
         using TU = typename std::make_unsigned<T>::type;
         check_layout_and_range(cfg.ntt_layout, cfg.n_power);
         if (mod_count <= 0 || modulus == nullptr)
@@ -512,12 +524,24 @@ namespace gpuntt
                               Root<T>* inverse_table, Modulus<T> modulus, ntt_configuration<T> cfg,
                               int batch_size)
     {
+        host::WorkspaceScope ws_scope; // scratch lock held until the last launch of this call
         check_layout_and_range(PerPolynomial, cfg.n_power);
         if (batch_size <= 0)
             return;
         ntt_configuration<T> f = cfg;
         f.ntt_type = FORWARD;
         f.ntt_layout = PerPolynomial;
+        if (device_a == device_b)
+        {
+            // squaring: one forward transform, pointwise square, inverse (transforming the shared
+            // buffer twice would compute INTT(NTT(NTT(a)) . NTT(a)))
+            GPU_NTT<T>(device_a, device_a, forward_table, modulus, f, batch_size);
+            pointwise_launch<T>(device_a, device_a, device_out, nullptr, modulus, 1, cfg.n_power, batch_size,
+                                cfg.stream);
+            f.ntt_type = INVERSE;
+            GPU_INTT<T>(device_out, device_out, inverse_table, modulus, f, batch_size);
+            return;
+        }
         T* first = (device_out == device_a) ? device_b : device_a;  // transformed in place
         T* second = (device_out == device_a) ? device_a : device_b; // transformed into device_out
         GPU_NTT<T>(first, first, forward_table, modulus, f, batch_size);
@@ -543,6 +567,7 @@ namespace gpuntt
                               Root<T>* inverse_table, Modulus<T>* modulus, ntt_rns_configuration<T> cfg,
                               int batch_size, int mod_count)
     {
+        host::WorkspaceScope ws_scope; // scratch lock held until the last launch of this call
         check_layout_and_range(PerPolynomial, cfg.n_power);
         if (mod_count <= 0 || modulus == nullptr)
             throw std::invalid_argument("Invalid mod_count!");
@@ -551,6 +576,15 @@ namespace gpuntt
         ntt_rns_configuration<T> f = cfg;
         f.ntt_type = FORWARD;
         f.ntt_layout = PerPolynomial;
+        if (device_a == device_b)
+        {
+            GPU_NTT<T>(device_a, device_a, forward_table, modulus, f, batch_size, mod_count);
+            pointwise_launch<T>(device_a, device_a, device_out, modulus, Modulus<T>(), mod_count, cfg.n_power,
+                                batch_size, cfg.stream);
+            f.ntt_type = INVERSE;
+            GPU_INTT<T>(device_out, device_out, inverse_table, modulus, f, batch_size, mod_count);
+            return;
+        }
         T* first = (device_out == device_a) ? device_b : device_a;
         T* second = (device_out == device_a) ? device_a : device_b;
         GPU_NTT<T>(first, first, forward_table, modulus, f, batch_size, mod_count);
@@ -590,6 +624,227 @@ namespace gpuntt
     GPUNTT_INST_POLYMUL(Data64)
 #undef GPUNTT_INST_POLYMUL
 
+    // --------------------------------------------------------------------- NTTPlan ----
+    // Prepared transform (extension): everything lazy_args() derives per call is derived once.
+    template <typename T> struct NTTPlan<T>::Impl
+    {
+        const T* table = nullptr;
+        std::vector<Modulus<T>> moduli;
+        std::vector<T> ninv;
+        int mod_count = 1, n = 0, tile_log = 12;
+        ReductionPolynomial poly = ReductionPolynomial::X_N_minus;
+        bool inverse = false, fast = false, owns_ws = false;
+        unsigned char* ws = nullptr;
+        // workspace layout
+        lazy::Tw<T>* tw = nullptr;
+        lazy::Tw<T>* ninv_pairs = nullptr;
+        unsigned* go_flag = nullptr;
+        lazy::NormConst* norm_arr = nullptr;
+        Modulus<T>* mods_dev = nullptr;
+        T* ninv_dev = nullptr;
+    };
+
+    namespace
+    {
+        inline size_t up16(size_t v) { return (v + 15u) & ~size_t(15); }
+        template <typename T> struct PlanLayout
+        {
+            size_t tw, ninv_pairs, go_flag, norm, mods, ninv, total;
+            PlanLayout(int n_power, int mod_count)
+            {
+                const size_t mc = static_cast<size_t>(mod_count);
+                size_t off = 0;
+                tw = off;
+                off += up16(sizeof(lazy::Tw<T>) * (mc << n_power));
+                ninv_pairs = off;
+                off += up16(sizeof(lazy::Tw<T>) * mc);
+                go_flag = off;
+                off += 16;
+                norm = off;
+                off += up16(sizeof(lazy::NormConst) * mc);
+                mods = off;
+                off += up16(sizeof(Modulus<T>) * mc);
+                ninv = off;
+                off += up16(sizeof(T) * mc);
+                total = off;
+            }
+        };
+    } // namespace
+
+    template <typename T> size_t NTTPlan<T>::workspace_bytes(int n_power, int mod_count)
+    {
+        if (n_power <= 0 || n_power >= 29 || mod_count <= 0)
+            throw std::invalid_argument("Invalid n_power range!");
+        return PlanLayout<T>(n_power, mod_count).total;
+    }
+
+    template <typename T>
+    NTTPlan<T>::NTTPlan(const Root<T>* table_device, const Modulus<T>* moduli_host, int mod_count, int n_power,
+                        ReductionPolynomial reduction_poly, type ntt_type, const Ninverse<T>* mod_inverse_host,
+                        int batch_hint, stream_t stream, void* workspace_device)
+        : p_(nullptr)
+    {
+        if (n_power <= 0 || n_power >= 29)
+            throw std::invalid_argument("Invalid n_power range!");
+        if (mod_count <= 0 || moduli_host == nullptr || table_device == nullptr)
+            throw std::invalid_argument("Invalid mod_count!");
+        if (ntt_type != FORWARD && ntt_type != INVERSE)
+            throw std::invalid_argument("Invalid ntt_type!");
+        const bool inverse = (ntt_type == INVERSE);
+        if (inverse && mod_inverse_host == nullptr)
+            throw std::invalid_argument("Invalid mod_inverse!");
+        Impl* p = new Impl();
+        p_ = p;
+        try
+        {
+            p->table = table_device;
+            p->moduli.assign(moduli_host, moduli_host + mod_count);
+            if (inverse)
+                p->ninv.assign(mod_inverse_host, mod_inverse_host + mod_count);
+            p->mod_count = mod_count;
+            p->n = n_power;
+            p->poly = reduction_poly;
+            p->inverse = inverse;
+            if (batch_hint < 1)
+                batch_hint = 1;
+            p->tile_log = host::lazy_tile_log<T>(n_power, inverse, static_cast<unsigned long long>(batch_hint));
+            bool fast = lazy_eligible<T>(n_power, batch_hint > 1 ? batch_hint : 2, mod_count);
+            for (int i = 0; i < mod_count; i++)
+            {
+                const Modulus<T>& m = p->moduli[i];
+                if (m.value < 3 || m.bit > T(lazy::Mod<T>::MAX_BIT))
+                    fast = false;
+                if (inverse && p->ninv[i] >= m.value)
+                    fast = false;
+            }
+            p->fast = fast;
+            const PlanLayout<T> lay(n_power, mod_count);
+            if (workspace_device != nullptr)
+                p->ws = static_cast<unsigned char*>(workspace_device);
+            else
+            {
+                void* mem = nullptr;
+                GPUNTT_HIP_CHECK(hipMalloc(&mem, lay.total));
+                p->ws = static_cast<unsigned char*>(mem);
+                p->owns_ws = true;
+            }
+            p->tw = reinterpret_cast<lazy::Tw<T>*>(p->ws + lay.tw);
+            p->ninv_pairs = reinterpret_cast<lazy::Tw<T>*>(p->ws + lay.ninv_pairs);
+            p->go_flag = reinterpret_cast<unsigned*>(p->ws + lay.go_flag);
+            p->norm_arr = reinterpret_cast<lazy::NormConst*>(p->ws + lay.norm);
+            p->mods_dev = reinterpret_cast<Modulus<T>*>(p->ws + lay.mods);
+            p->ninv_dev = reinterpret_cast<T*>(p->ws + lay.ninv);
+            // device copies of the moduli / n^-1 values (the host vectors live as long as the plan)
+            GPUNTT_HIP_CHECK(hipMemcpyAsync(p->mods_dev, p->moduli.data(), sizeof(Modulus<T>) * mod_count,
+                                            hipMemcpyHostToDevice, stream));
+            if (inverse)
+                GPUNTT_HIP_CHECK(hipMemcpyAsync(p->ninv_dev, p->ninv.data(), sizeof(T) * mod_count,
+                                                hipMemcpyHostToDevice, stream));
+            if (fast)
+            {
+                const bool neg = (reduction_poly == ReductionPolynomial::X_N_plus);
+                const int perm_tile_log = (n_power >= p->tile_log) ? p->tile_log : 0;
+                if (mod_count == 1)
+                    host::launch_prep<T>(table_device, p->tw, nullptr, p->moduli[0].value, 1, n_power, neg,
+                                         perm_tile_log, nullptr, nullptr, nullptr, nullptr, stream, nullptr,
+                                         inverse ? &p->ninv[0] : nullptr, false, nullptr);
+                else
+                    host::launch_prep<T>(table_device, p->tw, p->mods_dev, T(0), mod_count, n_power, neg,
+                                         perm_tile_log, inverse ? p->ninv_dev : nullptr,
+                                         inverse ? p->ninv_pairs : nullptr, p->go_flag, p->norm_arr, stream,
+                                         nullptr, nullptr, inverse, nullptr);
+            }
+        }
+        catch (...)
+        {
+            if (p->owns_ws && p->ws != nullptr)
+                (void) hipFree(p->ws);
+            delete p;
+            p_ = nullptr;
+            throw;
+        }
+    }
+
+    template <typename T> NTTPlan<T>::~NTTPlan()
+    {
+        if (p_ != nullptr)
+        {
+            if (p_->owns_ws && p_->ws != nullptr)
+                (void) hipFree(p_->ws);
+            delete p_;
+        }
+    }
+
+    template <typename T> bool NTTPlan<T>::fast_path() const { return p_->fast; }
+
+    template <typename T>
+    void NTTPlan<T>::execute(const void* device_in, void* device_out, int batch_size, stream_t stream,
+                             bool io_signed) const
+    {
+        const Impl& p = *p_;
+        if (batch_size <= 0)
+            return;
+        if (device_in == nullptr || device_out == nullptr)
+            throw std::invalid_argument("null pointer argument");
+        const unsigned in_flags = (!p.inverse && io_signed) ? kern::F_SIGNED_IN : 0u;
+        const unsigned out_flags = p.inverse ? (kern::F_SCALE | (io_signed ? kern::F_CENTERED : 0u)) : 0u;
+        T* out = static_cast<T*>(device_out);
+        if (p.fast)
+        {
+            kern::LazyArgsT<T> a{};
+            a.in = device_in;
+            a.out = out;
+            a.tw = p.tw;
+            const Modulus<T>& m0 = p.moduli[0];
+            if (p.mod_count > 1)
+            {
+                a.mods = p.mods_dev;
+                a.norm_arr = p.norm_arr;
+                a.ninv_arr = p.inverse ? p.ninv_pairs : nullptr;
+            }
+            else
+            {
+                a.q = m0.value;
+                a.q_bit = m0.bit;
+                a.q_mu = m0.mu;
+                a.norm = lazy::make_norm_const(static_cast<uint64_t>(m0.value), static_cast<uint64_t>(m0.bit));
+                if (p.inverse)
+                    a.ninv = lazy::Tw<T>{p.ninv[0], host::shoup_host(p.ninv[0], m0.value)};
+            }
+            a.total = static_cast<unsigned long long>(batch_size) << p.n;
+            a.n = p.n;
+            a.poly_shift = p.n;
+            a.mod_count = p.mod_count;
+            if (p.inverse)
+                host::run_transform_lazy<T, true>(a, in_flags, out_flags, stream, p.tile_log);
+            else
+                host::run_transform_lazy<T, false>(a, in_flags, out_flags, stream, p.tile_log);
+            return;
+        }
+        kern::PassArgs<T> a = base_args<T>(device_in, out, p.table, p.n, p.poly, batch_size);
+        if (p.mod_count > 1)
+        {
+            a.mods = p.mods_dev;
+            a.mod_count = p.mod_count;
+            a.ninv_arr = p.inverse ? p.ninv_dev : nullptr;
+            set_multi(a);
+        }
+        else
+        {
+            a.mod = p.moduli[0];
+            a.ninv = p.inverse ? p.ninv[0] : T(0);
+        }
+        if (p.inverse)
+            host::run_transform<T, true>(a, in_flags, out_flags, stream);
+        else
+            host::run_transform<T, false>(a, in_flags, out_flags, stream);
+    }
+
+    template class NTTPlan<Data32>;
+    template class NTTPlan<Data64>;
+
+    void GPU_NTT_ReleaseWorkspaces() { host::release_workspaces(); }
+
     // ---------------------------------------------------------------- ordered RNS ----
     namespace
     {
@@ -598,6 +853,7 @@ namespace gpuntt
                          const ntt_rns_configuration<T>& cfg, int batch_size, int mod_count,
                          const int* mod_order, const int* poly_order)
         {
+            host::WorkspaceScope ws_scope;
             // reference ntt.cu:3607-3610 / 4288-4291
             if (cfg.n_power <= 9 || cfg.n_power >= 29)
                 throw std::invalid_argument("Invalid n_power range!");

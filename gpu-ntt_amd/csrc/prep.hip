@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <map>
 #include <mutex>
+#include <vector>
 
 #include "lazy_launch.hpp"
 
@@ -309,10 +310,40 @@ namespace gpuntt
             {
                 void* ptr = nullptr;
                 size_t bytes = 0;
+                std::recursive_mutex mu; // held by a host thread for the duration of one API call
             };
-            std::mutex g_ws_mutex;
+            std::mutex g_ws_mutex; // guards the map itself
             std::map<std::pair<int, hipStream_t>, Slot> g_ws;
+            thread_local int t_scope_depth = 0;
+            thread_local std::vector<std::recursive_mutex*> t_held;
         } // namespace
+
+        WorkspaceScope::WorkspaceScope() { ++t_scope_depth; }
+        WorkspaceScope::~WorkspaceScope()
+        {
+            if (--t_scope_depth == 0)
+            {
+                for (auto it = t_held.rbegin(); it != t_held.rend(); ++it)
+                    (*it)->unlock();
+                t_held.clear();
+            }
+        }
+
+        void release_workspaces()
+        {
+            std::lock_guard<std::mutex> lock(g_ws_mutex);
+            for (auto& kv : g_ws)
+            {
+                Slot& s = kv.second;
+                std::lock_guard<std::recursive_mutex> sl(s.mu);
+                if (s.ptr != nullptr)
+                {
+                    (void) hipFree(s.ptr); // synchronises the device
+                    s.ptr = nullptr;
+                    s.bytes = 0;
+                }
+            }
+        }
 
         // host twin of kern::recip_norm
         template <typename T> static T recip_norm_host(T q)
@@ -400,8 +431,27 @@ namespace gpuntt
         {
             int dev = 0;
             GPUNTT_HIP_CHECK(hipGetDevice(&dev));
-            std::lock_guard<std::mutex> lock(g_ws_mutex);
-            Slot& s = g_ws[std::make_pair(dev, stream)];
+            Slot* sp;
+            {
+                std::lock_guard<std::mutex> lock(g_ws_mutex);
+                sp = &g_ws[std::make_pair(dev, stream)]; // map nodes never move
+            }
+            Slot& s = *sp;
+            s.mu.lock();
+            struct Unlock
+            {
+                std::recursive_mutex* m;
+                ~Unlock()
+                {
+                    if (m != nullptr)
+                        m->unlock();
+                }
+            } unlock{&s.mu};
+            if (t_scope_depth > 0)
+            {
+                t_held.push_back(&s.mu); // released by the outermost WorkspaceScope of this thread
+                unlock.m = nullptr;
+            }
             if (s.bytes < bytes)
             {
                 if (s.ptr != nullptr)

@@ -145,8 +145,8 @@ namespace modular_operation_gpu
             else
             {
                 const Data64 zlo = a * b, zhi = __umul64hi(a, b);
-                const int s1 = static_cast<int>(m.bit) - 2; // 1 <= s1 <= 60
-                Data64 w = (zlo >> s1) | (zhi << (64 - s1));
+                const int s1 = static_cast<int>(m.bit) - 2; // 0 <= s1 <= 60
+                Data64 w = (s1 == 0) ? zlo : ((zlo >> s1) | (zhi << (64 - s1)));
                 const Data64 plo = w * m.mu, phi = __umul64hi(w, m.mu);
                 const int s2 = static_cast<int>(m.bit) + 3; // 6 <= s2 <= 65
                 w = (s2 >= 64) ? (phi >> (s2 - 64)) : ((plo >> s2) | (phi << (64 - s2)));

@@ -19,7 +19,14 @@
 //   * cfg.ntt_type and cfg.zero_padding are ignored (direction = function name)
 //   * signed instantiations: GPU_NTT<Data64s> takes inputs in (-q, q); GPU_INTT<Data64s>
 //     returns centred residues
-//   * asynchronous on cfg.stream; in == out allowed; no allocation, no synchronisation
+//   * asynchronous on cfg.stream; in == out allowed.  The fast kernels read twiddles that every call
+//     re-derives from the caller's table into a library-owned scratch buffer kept per (device, stream):
+//     the first call on a stream (and a call that needs a larger buffer) allocates it with hipMalloc,
+//     a growing call also synchronises that stream once.  A host thread holds the buffer's lock from
+//     the preparation launch to its last kernel launch, so threads sharing a stream are serialised
+//     there and stream order keeps their launches apart.  GPU_NTT_ReleaseWorkspaces() frees the
+//     buffers.  Callers that want zero allocation / synchronisation / preparation per call use
+//     NTTPlan<T> below (caller-owned workspace, tables prepared once).
 //   * throws std::invalid_argument("Invalid n_power range!") / ("Invalid ntt_layout!"),
 //     HipException (alias CudaException) on a failed launch
 #pragma once
@@ -149,5 +156,42 @@ namespace gpuntt
     template <typename T>
     __host__ void GPU_PointwiseMul(T* device_a, T* device_b, T* device_out, Modulus<T>* modulus, int n_power,
                                    int batch_size, int mod_count, stream_t stream);
+
+    // ---- extension: prepared transform (no counterpart in the reference) -------------------
+    // What GPU_NTT / GPU_INTT re-derive on every call -- Shoup pairs of the twiddle table in the
+    // kernels' stage layout, n^-1 pairs, the choice between the fast (lazy-residue) and the generic
+    // kernels -- is done ONCE here, on `stream`, into `workspace_device` (workspace_bytes() bytes,
+    // caller-owned; nullptr = the plan allocates and owns it).  execute() then launches the transform
+    // kernels and nothing else: no allocation, no synchronisation, no preparation launch, no shadow
+    // launches for RNS stacks (the moduli are host values here, so the path is known), and it can be
+    // captured into a hipGraph without a warm-up call.
+    //   table_device       the caller's table exactly as for GPU_NTT / GPU_INTT (slot i at i << n_power);
+    //                      it is only read during construction (fast path) -- the generic path keeps
+    //                      reading it at execute()
+    //   moduli_host        mod_count moduli; polynomial p uses modulus p % mod_count
+    //   mod_inverse_host   n^-1 per modulus (INVERSE only)
+    //   batch_hint         the batch size the tile plan is chosen for (any batch size runs correctly)
+    // PerPolynomial layout only.  execute(): in == out allowed; io_signed selects the Data64s / Data32s
+    // behaviour (signed input for FORWARD, centred output for INVERSE).
+    template <typename T> class NTTPlan
+    {
+      public:
+        static size_t workspace_bytes(int n_power, int mod_count);
+        NTTPlan(const Root<T>* table_device, const Modulus<T>* moduli_host, int mod_count, int n_power,
+                ReductionPolynomial reduction_poly, type ntt_type, const Ninverse<T>* mod_inverse_host,
+                int batch_hint, stream_t stream, void* workspace_device = nullptr);
+        ~NTTPlan();
+        NTTPlan(const NTTPlan&) = delete;
+        NTTPlan& operator=(const NTTPlan&) = delete;
+        void execute(const void* device_in, void* device_out, int batch_size, stream_t stream,
+                     bool io_signed = false) const;
+        bool fast_path() const; // false: moduli without lazy headroom / ring outside the prepared range
+      private:
+        struct Impl;
+        Impl* p_;
+    };
+
+    // frees the per-(device, stream) scratch buffers of the drop-in entry points (synchronises the device)
+    void GPU_NTT_ReleaseWorkspaces();
 
 } // namespace gpuntt

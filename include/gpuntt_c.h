@@ -23,9 +23,17 @@
  *                               src/include/gpuntt/common/modular_arith.cuh:28-57,
  *                               src/include/gpuntt/common/nttparameters.cuh:56-170
  *
+ *   gpuntt_plan_*               extension NTTPlan<T> (include/gpuntt/ntt_merge/ntt.cuh): tables prepared once,
+ *                               caller-owned workspace; execute = transform kernels only
+ *   gpuntt_operator_gpu_*       diagnostic: the public device class OPERATOR_GPU<T>
+ *                               (src/include/gpuntt/common/modular_arith.cuh:174-454) applied elementwise
+ *
  * All data/table/modulus-array pointers are DEVICE pointers unless the name ends in _host.
  * Calls are asynchronous on `stream` (a hipStream_t passed as void*; NULL = default
- * stream), allocate nothing and never synchronise.
+ * stream).  The transform entry points keep a library-owned twiddle scratch buffer per
+ * (device, stream): its first use (or growth) allocates, growth synchronises that stream once;
+ * gpuntt_release_workspaces() frees them.  gpuntt_plan_execute_* allocates nothing, never
+ * synchronises and launches no preparation kernel.
  *
  * Return value: GPUNTT_OK, or a negative code with the text available from
  * gpuntt_last_error() (thread-local).  GPUNTT_ERR_INVALID_ARGUMENT corresponds to the
@@ -189,6 +197,42 @@ extern "C"
     int gpuntt_4step_params_u64(int logn, int inverse, uint64_t* info_host,
                                 uint64_t* n1_table_host, uint64_t* n2_table_host,
                                 uint64_t* w_table_host);
+
+    /* ---- extension: prepared transforms (NTTPlan<T>) ----------------------------------------
+     * moduli_host[mod_count], mod_inverse_host[mod_count] (GPUNTT_INVERSE only) are HOST arrays;
+     * workspace_device: gpuntt_plan_workspace_bytes_*() bytes of device memory owned by the caller, or
+     * NULL (the plan allocates).  Construction runs on `stream`; execute: in == out allowed, io_signed
+     * = signed input (forward) / centred output (inverse); PerPolynomial layout. */
+    typedef struct gpuntt_plan gpuntt_plan;
+    int gpuntt_plan_workspace_bytes_u32(int n_power, int mod_count, uint64_t* bytes_host);
+    int gpuntt_plan_workspace_bytes_u64(int n_power, int mod_count, uint64_t* bytes_host);
+    int gpuntt_plan_create_u32(gpuntt_plan** plan_host, const uint32_t* table, const gpuntt_modulus32* moduli_host,
+                               int mod_count, int n_power, int reduction_poly, int ntt_type,
+                               const uint32_t* mod_inverse_host, int batch_hint, void* workspace_device,
+                               void* stream);
+    int gpuntt_plan_create_u64(gpuntt_plan** plan_host, const uint64_t* table, const gpuntt_modulus64* moduli_host,
+                               int mod_count, int n_power, int reduction_poly, int ntt_type,
+                               const uint64_t* mod_inverse_host, int batch_hint, void* workspace_device,
+                               void* stream);
+    int gpuntt_plan_execute_u32(const gpuntt_plan* plan, const void* in, void* out, int batch_size, int io_signed,
+                                void* stream);
+    int gpuntt_plan_execute_u64(const gpuntt_plan* plan, const void* in, void* out, int batch_size, int io_signed,
+                                void* stream);
+    int gpuntt_plan_fast_path_u32(const gpuntt_plan* plan); /* 1 / 0, negative on error */
+    int gpuntt_plan_fast_path_u64(const gpuntt_plan* plan);
+    int gpuntt_plan_destroy_u32(gpuntt_plan* plan);
+    int gpuntt_plan_destroy_u64(gpuntt_plan* plan);
+
+    /* frees the library-owned scratch buffers of the drop-in entry points (synchronises the device) */
+    int gpuntt_release_workspaces(void);
+
+    /* ---- diagnostic: OPERATOR_GPU<T> elementwise on device arrays -----------------------------
+     * op: 0 add, 1 sub, 2 mult, 3 reduce (unsigned a), 4 reduce (a read as signed), 5 centered_reduction;
+     * b is ignored by ops 3..5 */
+    int gpuntt_operator_gpu_u32(int op, const uint32_t* a, const uint32_t* b, uint32_t* out,
+                                gpuntt_modulus32 modulus, uint64_t count, void* stream);
+    int gpuntt_operator_gpu_u64(int op, const uint64_t* a, const uint64_t* b, uint64_t* out,
+                                gpuntt_modulus64 modulus, uint64_t count, void* stream);
 
 #ifdef __cplusplus
 }

@@ -76,11 +76,13 @@ def test_transpose(g, bits):
 def test_fourstep_vs_oracle(g, bits):
     # every n1 x n2 shape class: n1 in {32, 64, 128}, n2 from 128 (one tile) to 32768 (strided)
     P = O.Port(bits)
-    for logn in (12, 13, 14, 15, 16, 17, 18, 20):
+    # 2^19 runs with batch 8: n2 = 16384 rows x (8 x 32) transforms reaches the 16384-coefficient
+    # tile of the 64-bit row pass (lazy_tile_log: >= 256 transforms), which batch 1 never does
+    for logn in (12, 13, 14, 15, 16, 17, 18, 19, 20):
         p4 = g.NTTParameters4Step(logn, bits)
         oprm = P.fourstep_params(logn)
         assert np.array_equal(p4.tables["fwd"][2], oprm["W_fwd"])
-        batch = 2 if logn <= 16 else 1
+        batch = 2 if logn <= 16 else (8 if logn == 19 else 1)
         x = P.splitmix(400 + logn, 0, batch * p4.n, p4.modulus.value)
         want = P.fourstep_ntt(x, oprm)
         got = run_fourstep(g, p4, x, batch, inverse=False, rns=(logn % 2 == 0))
@@ -194,6 +196,65 @@ def test_fourstep_golden(g, bits, golden_dir):
         if "l%d_fwd" % r["logn"] in gold:
             assert np.array_equal(fwd, gold["l%d_fwd" % r["logn"]])
             assert np.array_equal(inv, gold["l%d_inv" % r["logn"]])
+
+
+def test_fourstep_natural_order_2_24_by_digest(g, golden_dir):
+    """BASELINE config 3's own ring (u64, 2^24 = 256 x 65536) through the one-call natural-order
+    form, forward and inverse, against the reference build's digests (tests/golden/digests.json)"""
+    import torch
+    P = O.Port(64)
+    r = [r for r in json.load(open(os.path.join(golden_dir, "digests.json")))["fourstep"]
+         if r["bits"] == 64 and r["logn"] == 24][0]
+    p4 = g.NTTParameters4Step(24, 64)
+    x = P.splitmix(r["seed"], 0, p4.n, r["q"])
+    assert sha(x) == r["sha_in"]
+    tf = [g.to_device(t) for t in p4.tables["fwd"]]
+    d_in = g.to_device(x)
+    d_out = torch.zeros_like(d_in)
+    g.GPU_4STEP_NTT_NaturalOrder(d_in, d_out, *tf, p4.modulus, g.ntt4step_configuration(n_power=24, ntt_type=g.FORWARD), 1)
+    torch.cuda.synchronize()
+    assert sha(g.to_host(d_out)) == r["sha_fwd"]
+    del tf
+    ti = [g.to_device(t) for t in p4.tables["inv"]]
+    d_x = g.to_device(x)  # the forward call used its input as scratch
+    d_back = torch.zeros_like(d_x)
+    ci = g.ntt4step_configuration(n_power=24, ntt_type=g.INVERSE, mod_inverse=p4.n_inv)
+    g.GPU_4STEP_NTT_NaturalOrder(d_x, d_back, *ti, p4.modulus, ci, 1)
+    torch.cuda.synchronize()
+    assert sha(g.to_host(d_back)) == r["sha_inv"]
+
+
+def test_full_size_c3_properties(g, golden_dir):
+    """BASELINE config 3 at full size (u64, 2^24, batch 64, 8 GiB in + 8 GiB out): 4 distinct
+    polynomials repeated 16 times; the distinct ones are pinned by the reference digest (polynomial 0
+    is the golden input) and by the forward -> inverse round trip, the repeats must be identical copies."""
+    import torch
+    P = O.Port(64)
+    r = [r for r in json.load(open(os.path.join(golden_dir, "digests.json")))["fourstep"]
+         if r["bits"] == 64 and r["logn"] == 24][0]
+    p4 = g.NTTParameters4Step(24, 64)
+    n, batch, distinct = p4.n, 64, 4
+    base = np.concatenate([P.splitmix(r["seed"] + 7 * i, 0, n, r["q"]) for i in range(distinct)])
+    tf = [g.to_device(t) for t in p4.tables["fwd"]]
+    d_base = g.to_device(base)
+    d_in = d_base.repeat(batch // distinct)
+    d_mid = torch.zeros_like(d_in)
+    cf = g.ntt4step_configuration(n_power=24, ntt_type=g.FORWARD)
+    g.GPU_4STEP_NTT_NaturalOrder(d_in, d_mid, *tf, p4.modulus, cf, batch)
+    torch.cuda.synchronize()
+    y = d_mid.view(batch // distinct, distinct * n)
+    assert bool((y == y[0:1]).all()), "copies of the same polynomial transformed differently"
+    y0 = g.to_host(d_mid[: distinct * n].clone())
+    assert sha(y0[:n]) == r["sha_fwd"]
+    assert int(y0.max()) < r["q"]
+    del tf
+    ti = [g.to_device(t) for t in p4.tables["inv"]]
+    d_back = d_in  # reuse
+    ci = g.ntt4step_configuration(n_power=24, ntt_type=g.INVERSE, mod_inverse=p4.n_inv)
+    g.GPU_4STEP_NTT_NaturalOrder(d_mid, d_back, *ti, p4.modulus, ci, batch)
+    torch.cuda.synchronize()
+    z = d_back.view(batch // distinct, distinct * n)
+    assert bool((z == d_base.view(1, -1)).all()), "forward -> inverse is not the identity at batch 64"
 
 
 def test_fourstep_unsupported_size_is_silent(g, capfd):

@@ -271,6 +271,56 @@ def test_full_size_c2_properties(g):
     assert np.array_equal(g.to_host(out), x)
 
 
+def test_full_size_c4_properties(g):
+    """BASELINE config 4 (u32, N = 2^14): one GPU's shard (batch 1024) and the whole batch (8192) at
+    full size -- sampled polynomials against the oracle, range, exact round trip, linearity."""
+    import torch
+    c = MergeCase(g, 32, 14, O.X_N_minus)
+    n, q = c.n, c.q
+    for batch in (1024, 8192):
+        x = c.random(batch, 0x5EED0004 + batch)
+        d = g.to_device(x)
+        out = torch.empty_like(d)
+        g.GPU_NTT(d, out, c.fwd_dev, c.prm.modulus, c.cfg(), batch)
+        torch.cuda.synchronize()
+        y = g.to_host(out)
+        for p in (0, 1, batch // 2 - 1, batch - 1):
+            assert np.array_equal(y[p * n:(p + 1) * n], c.P.merge_ntt(x[p * n:(p + 1) * n], c.oprm)), (batch, p)
+        assert int(y.max()) < q
+        h = batch // 2
+        s = ((x[:h * n].astype(np.uint64) + x[h * n:].astype(np.uint64)) % np.uint64(q)).astype(np.uint32)
+        ys = c.gpu_forward(s)
+        want = ((y[:h * n].astype(np.uint64) + y[h * n:].astype(np.uint64)) % np.uint64(q)).astype(np.uint32)
+        assert np.array_equal(ys, want)
+        g.GPU_INTT_Inplace(out, c.inv_dev, c.prm.modulus, c.cfg(True), batch)
+        torch.cuda.synchronize()
+        assert np.array_equal(g.to_host(out), x)
+
+
+def test_single_launch_kernel_opt_in(g):
+    """GPUNTT_FUSED=1 (the per-XCD persistent kernel, off by default: profiles/r02_fused_single_sweep.md)
+    in its three placement modes -- XCD-aligned groups, groups spanning XCDs (run-time placement check
+    falls back to the fence protocol) and forced fences -- stays bit-exact; run in subprocesses because
+    the switches are read once per process."""
+    code = """
+import numpy as np, sys, os
+sys.path.insert(0, os.path.join(os.path.dirname(os.environ["PYTHONPATH"]), ""))
+from conftest import load_pkg
+from gpu_utils import MergeCase
+from oracle import oracle as O
+g = load_pkg(); g.load_library()
+for logn, batch in ((14, 5), (16, 40), (17, 3)):
+    for poly in (O.X_N_minus, O.X_N_plus):
+        c = MergeCase(g, 64, logn, poly)
+        x = c.random(batch, 31 + logn)
+        want = c.P.merge_ntt(x, c.oprm)
+        assert np.array_equal(c.gpu_forward(x, inplace=bool(logn & 1)), want)
+        assert np.array_equal(c.gpu_inverse(want, inplace=not (logn & 1)), x)
+"""
+    for mode in ("0", "1", "2"):
+        _run_in_subprocess(code, {"GPUNTT_FUSED": "1", "GPUNTT_FUSED_MODE": mode})
+
+
 def test_streams_are_honoured(g):
     import torch
     c = MergeCase(g, 64, 14, O.X_N_minus)
@@ -304,7 +354,8 @@ def _run_in_subprocess(code, env_path):
     """the path override is read once per process, so A/B runs need their own interpreter"""
     import subprocess
     import sys
-    env = dict(os.environ, GPUNTT_PATH=env_path, PYTHONPATH=os.path.dirname(os.path.abspath(__file__)))
+    extra = env_path if isinstance(env_path, dict) else {"GPUNTT_PATH": env_path}
+    env = dict(os.environ, PYTHONPATH=os.path.dirname(os.path.abspath(__file__)), **extra)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     return r.stdout
@@ -571,7 +622,7 @@ def test_modulus_ordered_and_poly_ordered(g, bits):
         g.GPU_NTT_Modulus_Ordered(d, d, fwd, mods, g.ntt_rns_configuration(n_power=9), 1, 1, d_order)
 
 
-@pytest.mark.parametrize("bits,logn", [(64, 21), (64, 22), (64, 24), (32, 21), (32, 23), (64, 25), (32, 25)])
+@pytest.mark.parametrize("bits,logn", [(64, 21), (64, 22), (64, 24), (32, 21), (32, 23), (64, 25), (32, 25), (64, 26)])
 def test_large_rings(g, bits, logn):
     """Two-sweep plans with a big contiguous tile (u64 2^21 both directions, 2^22 forward), three-sweep
     plans (up to 2^24, fast path) and rings above the fast path's table limit

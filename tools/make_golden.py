@@ -32,7 +32,7 @@ OUT = os.path.join(ROOT, "tests", "golden")
 FULL_LOGN = (1, 2, 3, 5, 9, 10, 11, 12)
 DIGEST_LOGN = (14, 16, 17, 20)
 FOURSTEP_FULL = (12, 13)
-FOURSTEP_DIGEST = (14, 15, 16, 17, 20, 24)
+FOURSTEP_DIGEST = (14, 15, 16, 17, 19, 20, 21, 22, 23, 24)
 SEED = 0x5EED0000
 
 # BASELINE config 5: 8 distinct ~60-bit primes from the reference's own pools
@@ -55,7 +55,49 @@ def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
+def fourstep_record(R, P, bits, logn):
+    """digest record of one 4-step shape from the reference build (+ the full outputs)"""
+    prm = R.fourstep_params(logn)
+    q = prm["mod"][0]
+    seed = SEED + 1000 + logn * 2 + (bits == 32)
+    x = P.splitmix(seed, 0, prm["n"], q)
+    fwd = R.fourstep_run(x, prm, 0)
+    inv = R.fourstep_run(x, prm, 1)
+    ft = R.fourstep_run(x, prm, 2)
+    rec = dict(bits=bits, logn=logn, seed=seed, q=q, bit=prm["mod"][1],
+               mu=prm["mod"][2], omega=prm["omega"], psi=prm["psi"],
+               n_inv=prm["n_inv"], n1=prm["n1"], n2=prm["n2"], sha_in=sha(x),
+               sha_W_fwd=sha(prm["W_fwd"]), sha_W_inv=sha(prm["W_inv"]),
+               sha_n1_fwd_gpu=sha(prm["n1_fwd_gpu"]),
+               sha_n2_fwd_gpu=sha(prm["n2_fwd_gpu"]),
+               sha_n1_inv_gpu=sha(prm["n1_inv_gpu"]),
+               sha_n2_inv_gpu=sha(prm["n2_inv_gpu"]), sha_fwd=sha(fwd),
+               sha_inv=sha(inv), sha_first_transpose=sha(ft))
+    R.fourstep_free(prm)
+    return rec, fwd, inv
+
+
+def add_fourstep(shapes):
+    """`make_golden.py --add-fourstep 64:19 64:21 ...`: append digest records of further 4-step shapes to
+    digests.json without regenerating the rest (2^24 parameter generation alone takes minutes)"""
+    path = os.path.join(OUT, "digests.json")
+    digests = json.load(open(path))
+    have = {(r["bits"], r["logn"]) for r in digests["fourstep"]}
+    for item in shapes:
+        bits, logn = (int(v) for v in item.split(":"))
+        if (bits, logn) in have:
+            continue
+        rec, _, _ = fourstep_record(O.Ref(bits), O.Port(bits), bits, logn)
+        digests["fourstep"].append(rec)
+        print("4step", bits, logn, "added", flush=True)
+    digests["fourstep"].sort(key=lambda r: (r["bits"], r["logn"]))
+    with open(path, "w") as f:
+        json.dump(digests, f, indent=1)
+
+
 def main():
+    if len(sys.argv) > 2 and sys.argv[1] == "--add-fourstep":
+        return add_fourstep(sys.argv[2:])
     os.makedirs(OUT, exist_ok=True)
     digests = {"seed": SEED, "merge": [], "fourstep": [], "mt19937": []}
     for bits in (32, 64):
@@ -91,27 +133,11 @@ def main():
         for logn in FOURSTEP_FULL + FOURSTEP_DIGEST:
             if bits == 32 and logn == 24:
                 continue  # one 2^24 parameter generation (u64) is enough wall-clock
-            prm = R.fourstep_params(logn)
-            q = prm["mod"][0]
-            seed = SEED + 1000 + logn * 2 + (bits == 32)
-            x = P.splitmix(seed, 0, prm["n"], q)
-            fwd = R.fourstep_run(x, prm, 0)
-            inv = R.fourstep_run(x, prm, 1)
-            ft = R.fourstep_run(x, prm, 2)
-            rec = dict(bits=bits, logn=logn, seed=seed, q=q, bit=prm["mod"][1],
-                       mu=prm["mod"][2], omega=prm["omega"], psi=prm["psi"],
-                       n_inv=prm["n_inv"], n1=prm["n1"], n2=prm["n2"], sha_in=sha(x),
-                       sha_W_fwd=sha(prm["W_fwd"]), sha_W_inv=sha(prm["W_inv"]),
-                       sha_n1_fwd_gpu=sha(prm["n1_fwd_gpu"]),
-                       sha_n2_fwd_gpu=sha(prm["n2_fwd_gpu"]),
-                       sha_n1_inv_gpu=sha(prm["n1_inv_gpu"]),
-                       sha_n2_inv_gpu=sha(prm["n2_inv_gpu"]), sha_fwd=sha(fwd),
-                       sha_inv=sha(inv), sha_first_transpose=sha(ft))
+            rec, fwd, inv = fourstep_record(R, P, bits, logn)
             digests["fourstep"].append(rec)
             if logn in FOURSTEP_FULL:
                 store["l%d_fwd" % logn] = fwd
                 store["l%d_inv" % logn] = inv
-            R.fourstep_free(prm)
             print("4step", bits, logn, "done", flush=True)
         np.savez(os.path.join(OUT, "fourstep_u%d.npz" % bits), **store)
 
