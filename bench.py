@@ -1,20 +1,33 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark: forward Merge NTT, 64-bit, N = 2^16, batch = 1024 per GPU.
+"""bench.py -- headline benchmark of the MI355X NTT library.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c4|c5] [--api dropin|plan]
+                    [--no-cpu-baseline] [--no-traffic] [--no-e2e]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one gpuntt GPU_NTT call (all of its kernel launches) over one batch of synthetic
-random polynomials already resident in HBM.  Rank r owns its own batch (weak scaling, no
-data-path collective: polynomials are independent); the only collectives are
-the timing barrier and the max-reduction of the elapsed time.
+Default = BASELINE.json's metric configuration (configs[1], "c2"): forward Merge NTT, 64-bit, N = 2^16,
+batch = 1024 per GPU, through the drop-in GPU_NTT call.  One "step" = one library call (all of its kernel
+launches) over one batch of synthetic random polynomials already resident in HBM.
 
-Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for the roofline arithmetic).
+    c2  Merge u64 2^16 x 1024 per GPU, forward, X^N-1                    (weak scaling)
+    c3  4-Step u64 2^24 x 64 per GPU, forward + inverse pair              (weak scaling)
+    c4  Merge u32 2^14, 8192 polynomials in total sharded over the ranks  (strong scaling: the config is
+        DEFINED as 8-way sharded; N = 1 runs the whole batch on one GPU)
+    c5  RNS Merge u64 2^16 x 512 per GPU, 8 primes, X^N+1                 (weak scaling)
+
+Multi-GPU: rank r owns its own shard (polynomials are independent): the timed region has
+no data-path collective, only the barrier and the MAX-reduction of the elapsed time.  With N > 1 the run
+also reports (outside `value`) the end-to-end leg of SURVEY.md 8e(ii): RCCL broadcast of the twiddle
+table, scatter of a batch that starts on rank 0, transform, gather back -- each part timed on its own.
+
+Prints ONE JSON line on rank 0 (DESIGN.md "Measurement" has the roofline arithmetic).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -23,18 +36,29 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 from __graft_entry__ import _load_pkg  # noqa: E402
 
-LOGN = 16
-BATCH = 1024
-BITS = 64
-CPU_PASSES = 6  # ~10 s of single-core CPU work at ~580 NTT/s
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-METRIC = "forward-NTTs/sec + achieved HBM GB/s, 64-bit Merge N=2^16 batch=1024"
+CPU_SECONDS = 5.0      # per CPU-baseline leg (1 thread, then all threads)
+
+CONFIGS = {
+    "c2": dict(kind="merge", bits=64, logn=16, batch=1024, poly="minus", scaling="weak",
+               metric="forward-NTTs/sec + achieved HBM GB/s, 64-bit Merge N=2^16 batch=1024",
+               workload="Merge-NTT Data64 log2N=16 batch=1024 forward (BASELINE configs[1])"),
+    "c3": dict(kind="4step", bits=64, logn=24, batch=64, poly="minus", scaling="weak",
+               metric="4-Step transforms/sec (forward + inverse pairs, each counted), 64-bit N=2^24 batch=64",
+               workload="4-Step NTT+INTT Data64 log2N=24 batch=64 (BASELINE configs[2])"),
+    "c4": dict(kind="merge", bits=32, logn=14, batch=8192, poly="minus", scaling="strong",
+               metric="forward-NTTs/sec + achieved HBM GB/s, 32-bit Merge N=2^14, 8192 polynomials sharded",
+               workload="Merge-NTT Data32 log2N=14 batch=8192 sharded over the ranks (BASELINE configs[3])"),
+    "c5": dict(kind="rns", bits=64, logn=16, batch=512, poly="plus", scaling="weak", mod_count=8,
+               metric="forward-NTTs/sec + achieved HBM GB/s, RNS 8 x 60-bit primes, N=2^16 batch=512",
+               workload="RNS Merge-NTT 8 primes Data64 log2N=16 batch=512 forward (BASELINE configs[4])"),
+}
 
 
-def splitmix64_mod(seed, count, q):
-    """x[k] = splitmix64(seed ^ k) mod q, k = 0..count-1 (the portable synthetic input of
-    SURVEY.md 8d), vectorised with numpy's wrapping uint64 arithmetic."""
-    k = np.arange(count, dtype=np.uint64)
+def splitmix64_mod(seed, count, q, offset=0):
+    """x[k] = splitmix64(seed ^ (offset + k)) mod q (the portable synthetic input of SURVEY.md 8d),
+    vectorised with numpy's wrapping uint64 arithmetic."""
+    k = np.arange(offset, offset + count, dtype=np.uint64)
     x = (np.uint64(seed) ^ k) + np.uint64(0x9E3779B97F4A7C15)
     x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
     x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
@@ -42,50 +66,253 @@ def splitmix64_mod(seed, count, q):
     return x % np.uint64(q)
 
 
-def cpu_baseline(modulus_value, x_sample, y_gpu_sample, logn):
-    """The CPU leg (the only place bench.py touches oracle/): times the CPU path on a bounded
-    sample of the same workload on this host -- oracle/_ref (the reference's own NTTCPU::ntt,
-    kind 'reference') when the prebuilt file is present, else this repo's C restatement (kind
-    'port') -- and uses its output to check the GPU result of the same polynomials bit for bit."""
-    from oracle import oracle as O
-    n = 1 << logn
-    polys = x_sample.size // n
-    if O.have_ref():
-        R = O.Ref(BITS)
-        prm = R.merge_params(logn, O.X_N_minus)
-        assert prm["mod"][0] == modulus_value
-        R.merge_ntt(x_sample[:n], prm)  # warm
-        t0 = time.perf_counter()
-        for _ in range(CPU_PASSES):
-            y = R.merge_ntt(x_sample, prm)
-        dt = time.perf_counter() - t0
-        kind = "reference"
+# ------------------------------------------------------------------------------ CPU baseline
+def _timed_cpu(run_one, polys_total, threads, seconds):
+    """run_one(lo, hi) transforms polynomials [lo, hi); repeat over the sample until `seconds` passed."""
+    from concurrent.futures import ThreadPoolExecutor
+    done = 0
+    t0 = time.perf_counter()
+    if threads == 1:
+        while time.perf_counter() - t0 < seconds:
+            run_one(0, polys_total)
+            done += polys_total
     else:
-        P = O.Port(BITS)
-        prm = P.merge_params(logn, O.X_N_minus)
-        P.merge_ntt(x_sample[:n], prm)
+        per = max(1, polys_total // threads)
+        spans = [(i, min(i + per, polys_total)) for i in range(0, polys_total, per)]
+        with ThreadPoolExecutor(max_workers=threads) as ex:
+            while time.perf_counter() - t0 < seconds:
+                list(ex.map(lambda s: run_one(*s), spans))  # ctypes releases the GIL inside the C call
+                done += polys_total
+    return done / (time.perf_counter() - t0)
+
+
+def cpu_baseline(cfg, case, y_gpu_sample):
+    """The CPU leg (the only place bench.py touches oracle/): the reference's own CPU transform
+    (oracle/_ref, kind 'reference'; this repo's C restatement, kind 'port', when the prebuilt file is absent)
+    timed on a bounded sample of the same workload on this host, once on one thread and once on every host
+    thread; its output also checks the GPU result of the same polynomials bit for bit."""
+    from oracle import oracle as O
+    bits, logn = cfg["bits"], cfg["logn"]
+    n = 1 << logn
+    kind = "reference" if O.have_ref() else "port"
+    B = O.Ref(bits) if O.have_ref() else O.Port(bits)
+    threads = os.cpu_count() or 1
+    x = case["x_sample"]
+    polys = x.size // n
+    if cfg["kind"] == "4step":
+        prm = B.fourstep_params(logn)
+        fwd = (lambda a: B.fourstep_run(a, prm, 0)) if O.have_ref() else (lambda a: B.fourstep_ntt(a, prm))
         t0 = time.perf_counter()
-        for _ in range(CPU_PASSES):
-            y = P.merge_ntt(x_sample, prm)
+        y = fwd(x[:n])
         dt = time.perf_counter() - t0
-        kind = "port"
+        ok = np.array_equal(y, y_gpu_sample[:n])
+        if not ok:
+            raise SystemExit("bench: GPU result differs from the CPU reference path")
+        return {"value": 1.0 / dt, "unit": "NTT/s", "cores": 1, "kind": kind, "gpu_output_bit_exact": True,
+                "sample": "one forward NTT_4STEP_CPU::ntt of N=2^%d on one host core, %.1f s" % (logn, dt)}
+    poly = O.X_N_minus if cfg["poly"] == "minus" else O.X_N_plus
+    if cfg["kind"] == "rns":
+        prms = [B.merge_params(logn, poly, f) for f in case["factors"]]
+        mc = len(prms)
+
+        def run_one(lo, hi):
+            return [B.merge_ntt(x[p * n:(p + 1) * n], prms[p % mc]) for p in range(lo, hi)]
+    else:
+        prm = B.merge_params(logn, poly)
+
+        def run_one(lo, hi):
+            return [B.merge_ntt(x[lo * n:hi * n], prm)]
+    y = np.concatenate(run_one(0, polys))
     if not np.array_equal(y, y_gpu_sample):
         raise SystemExit("bench: GPU result differs from the CPU reference path")
-    return {"value": CPU_PASSES * polys / dt, "unit": "NTT/s", "cores": 1, "kind": kind,
+    v1 = _timed_cpu(run_one, polys, 1, CPU_SECONDS)
+    vt = _timed_cpu(run_one, polys, threads, CPU_SECONDS) if threads > 1 else v1
+    return {"value": vt, "unit": "NTT/s", "cores": threads, "kind": kind, "value_1_core": v1,
             "gpu_output_bit_exact": True,
-            "sample": "%d passes over %d of the %d polynomials of one batch (u64, N=2^%d), "
-                      "NTTCPU::ntt on one host core, %.1f s of CPU work"
-                      % (CPU_PASSES, polys, BATCH, logn, dt)}
+            "sample": "%d polynomials of one batch (u%d, N=2^%d) repeated for %.0f s on 1 host thread and "
+                      "%.0f s on %d host threads (batch-parallel), NTTCPU::ntt"
+                      % (polys, bits, logn, CPU_SECONDS, CPU_SECONDS, threads)}
 
 
+# --------------------------------------------------------------------------- HBM traffic (PMC)
+def measure_traffic(config, api):
+    """HBM bytes per call from the PMC counters, measured in THIS run: two short rocprofv3 --pmc child
+    passes of this script (FETCH_SIZE, WRITE_SIZE -- separate passes, MI355X_MICROARCH.md), gfx950 x2
+    correction on the fetch side.  Returns (bytes_per_call, detail) or (None, reason)."""
+    import glob
+    import shutil
+    import sqlite3
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None, "rocprofv3 not found"
+    steps = 5
+    totals = {}
+    tmp = tempfile.mkdtemp(prefix="gpuntt_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [rocprof, "--pmc", counter, "-d", out, "-o", "pmc", "--", sys.executable,
+                   os.path.join(ROOT, "bench.py"), "--config", config, "--api", api, "--steps", str(steps),
+                   "--warmup", "0", "--child"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
+            dbs = glob.glob(out + "/**/*.db", recursive=True)
+            if r.returncode != 0 or not dbs:
+                return None, "rocprofv3 --pmc %s failed: %s" % (counter, (r.stderr or r.stdout)[-300:])
+            c = sqlite3.connect(dbs[0])
+            names = [x[0] for x in c.execute("select name from sqlite_master where type='table'")]
+            t = lambda p: [n for n in names if n.startswith(p)][0]  # noqa: E731
+            q = (f"select s.kernel_name, count(distinct d.id), sum(p.value) from {t('rocpd_pmc_event')} p "
+                 f"join {t('rocpd_info_pmc')} i on p.pmc_id=i.id "
+                 f"join {t('rocpd_kernel_dispatch')} d on p.event_id=d.event_id "
+                 f"join {t('rocpd_info_kernel_symbol')} s on d.kernel_id=s.id "
+                 f"where i.name='{counter}' and s.kernel_name like '%gpuntt%' group by s.kernel_name")
+            totals[counter] = {k: (nl, v) for k, nl, v in c.execute(q)}
+        calls = None
+        bytes_per_call = 0.0
+        detail = {}
+        for counter, corr in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
+            for k, (launches, kb) in totals[counter].items():
+                # child run: 1 check call + `steps` timed calls, every call launches each kernel once
+                calls = steps + 1
+                b = kb * 1024.0 * corr / calls
+                bytes_per_call += b
+                detail.setdefault(k[:96], {})[counter] = b
+        return bytes_per_call, {"per_kernel_bytes_per_call": detail, "fetch_correction": 2.0,
+                                "calls_profiled": calls, "method": "rocprofv3 --pmc, two passes, this run"}
+    except Exception as e:  # profiling must never take the bench line down
+        return None, "traffic measurement failed: %r" % (e,)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def quoted_traffic():
+    try:
+        pm = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles")) if p.endswith("_pmc_traffic.json"))
+        if pm:
+            return json.load(open(os.path.join(ROOT, "profiles", pm[-1])))["bytes_per_call"], pm[-1]
+    except Exception:
+        pass
+    return None, None
+
+
+# ------------------------------------------------------------------------------- workloads
+def build_case(g, cfg, rank, world, dev, api):
+    """Returns a dict with step(), the shard geometry, a sample for the CPU check and the pieces the
+    end-to-end leg needs."""
+    import torch
+    bits, logn = cfg["bits"], cfg["logn"]
+    n = 1 << logn
+    poly = g.X_N_minus if cfg["poly"] == "minus" else g.X_N_plus
+    batch = cfg["batch"] // world if cfg["scaling"] == "strong" else cfg["batch"]
+    if cfg["scaling"] == "strong" and cfg["batch"] % world:
+        raise SystemExit("config batch must divide over the ranks")
+    case = {"batch": batch, "n": n, "transforms_per_step": batch}
+    seed = 0x5EED0000 + {"c2": 2, "c3": 3, "c4": 4, "c5": 5}.get(cfg.get("name", ""), 9) + 16 * rank
+    if cfg["kind"] == "merge":
+        prm = g.NTTParameters(logn, poly, bits)
+        x = splitmix64_mod(seed, batch * n, prm.modulus.value).astype(g.np_dtype(bits))
+        d_in = g.to_device(x, dev)
+        d_out = torch.empty_like(d_in)
+        table = g.to_device(prm.forward_table_device_order, dev)
+        c = g.ntt_configuration(n_power=logn, ntt_type=g.FORWARD, reduction_poly=poly)
+        if api == "plan":
+            plan = g.NTTPlan(table, prm.modulus, logn, poly, g.FORWARD, batch_hint=batch)
+            case["step"] = lambda: plan.execute(d_in, d_out, batch)
+            case["plan"] = plan
+        else:
+            case["step"] = lambda: g.GPU_NTT(d_in, d_out, table, prm.modulus, c, batch)
+        def other_step():
+            if api == "plan":
+                return lambda: g.GPU_NTT(d_in, d_out, table, prm.modulus, c, batch)
+            p2 = g.NTTPlan(table, prm.modulus, logn, poly, g.FORWARD, batch_hint=batch)
+            case["plan"] = p2
+            return lambda: p2.execute(d_in, d_out, batch)
+        case.update(x=x, d_in=d_in, d_out=d_out, table=table, modulus=prm.modulus.value, other_step=other_step,
+                    run_shard=lambda a, b: g.GPU_NTT(a, b, table, prm.modulus, c, batch))
+    elif cfg["kind"] == "rns":
+        rns = json.load(open(os.path.join(ROOT, "tests", "golden", "rns_c5.json")))
+        mc = cfg["mod_count"]
+        factors = [(e["q"], e["omega"], e["psi"]) for e in rns["primes"][:mc]]
+        prms = [g.NTTParameters(logn, poly, bits, f) for f in factors]
+        tab = np.zeros(mc * n, dtype=np.uint64)
+        for i, p in enumerate(prms):
+            tab[i * n:i * n + p.root_of_unity_size] = p.forward_table_device_order
+        x = np.concatenate([splitmix64_mod(seed, n, prms[p % mc].modulus.value, offset=p * n) for p in range(batch)])
+        d_in = g.to_device(x, dev)
+        d_out = torch.empty_like(d_in)
+        table = g.to_device(tab, dev)
+        mods = g.modulus_array_to_device([p.modulus for p in prms], bits, dev)
+        c = g.ntt_rns_configuration(n_power=logn, ntt_type=g.FORWARD, reduction_poly=poly)
+        if api == "plan":
+            plan = g.NTTPlan(table, [p.modulus for p in prms], logn, poly, g.FORWARD, batch_hint=batch)
+            case["step"] = lambda: plan.execute(d_in, d_out, batch)
+            case["plan"] = plan
+        else:
+            case["step"] = lambda: g.GPU_NTT(d_in, d_out, table, mods, c, batch, mc)
+        def other_step():
+            if api == "plan":
+                return lambda: g.GPU_NTT(d_in, d_out, table, mods, c, batch, mc)
+            p2 = g.NTTPlan(table, [p.modulus for p in prms], logn, poly, g.FORWARD, batch_hint=batch)
+            case["plan"] = p2
+            return lambda: p2.execute(d_in, d_out, batch)
+        case.update(x=x, d_in=d_in, d_out=d_out, table=table, factors=factors, modulus=factors[0][0],
+                    other_step=other_step,
+                    run_shard=lambda a, b: g.GPU_NTT(a, b, table, mods, c, batch, mc))
+    else:  # 4-step, forward + inverse pair on the transposed-order form the library entry point defines
+        p4 = g.NTTParameters4Step(logn, bits)
+        distinct = 4  # 4 distinct polynomials repeated: 8 GiB of splitmix on the host would take minutes
+        base = np.concatenate([splitmix64_mod(seed + 7 * i, n, p4.modulus.value) for i in range(distinct)])
+        d_in = g.to_device(base, dev).repeat(batch // distinct)
+        d_mid = torch.empty_like(d_in)
+        tf = [g.to_device(t, dev) for t in p4.tables["fwd"]]
+        ti = [g.to_device(t, dev) for t in p4.tables["inv"]]
+        cf = g.ntt4step_configuration(n_power=logn, ntt_type=g.FORWARD)
+        ci = g.ntt4step_configuration(n_power=logn, ntt_type=g.INVERSE, mod_inverse=p4.n_inv)
+        d_back = torch.empty_like(d_in)
+
+        def step():
+            g.GPU_4STEP_NTT(d_in, d_mid, *tf, p4.modulus, cf, batch)
+            g.GPU_4STEP_NTT(d_mid, d_back, *ti, p4.modulus, ci, batch)
+        case.update(step=step, x=base, d_in=d_in, d_out=d_mid, table=tf[2], modulus=p4.modulus.value,
+                    transforms_per_step=2 * batch, p4=p4, natural=(tf, cf), run_shard=None)
+    return case
+
+
+def gpu_sample_for_check(g, cfg, case, polys):
+    """GPU output of the first `polys` polynomials in the order the CPU path produces"""
+    import torch
+    n = case["n"]
+    if cfg["kind"] != "4step":
+        return g.to_host(case["d_out"])[:polys * n].copy()
+    # natural-order forward of polynomial 0 = NTT_4STEP_CPU::ntt
+    tf, cf = case["natural"]
+    a = g.to_device(case["x"][:n])
+    b = torch.zeros_like(a)
+    g.GPU_4STEP_NTT_NaturalOrder(a, b, *tf, case["p4"].modulus, cf, 1)
+    torch.cuda.synchronize()
+    return g.to_host(b)
+
+
+# ------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
+    ap.add_argument("--api", choices=("dropin", "plan"), default="dropin")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-polys", type=int, default=BATCH)
+    ap.add_argument("--no-traffic", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--cpu-polys", type=int, default=64)
+    ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)  # PMC child pass: calls only
     args = ap.parse_args()
+    cfg = dict(CONFIGS[args.config], name=args.config)
+    if cfg["kind"] == "4step" and args.api == "plan":
+        raise SystemExit("the 4-step entry points have no plan form")
+    if args.config == "c3" and args.steps == 200:
+        args.steps, args.warmup = 10, 2  # a step is ~25 ms and 16 GiB of traffic
 
     import importlib
     import torch
@@ -101,27 +328,27 @@ def main():
     dev = "cuda:%d" % local_rank
     dist, rank, world = dist_mod.init_process_group("nccl", dev)
 
-    prm = g.NTTParameters(LOGN, g.X_N_minus, BITS)
-    n = 1 << LOGN
-    # synthetic input x[p][i] = splitmix64(seed ^ (p*N+i)) mod q, seed per rank
-    x = splitmix64_mod(0x5EED0002 + rank, BATCH * n, prm.modulus.value)
-    d_in = g.to_device(x, dev)
-    d_out = torch.empty_like(d_in)
-    table = g.to_device(prm.forward_table_device_order, dev)
-    cfg = g.ntt_configuration(n_power=LOGN, ntt_type=g.FORWARD, reduction_poly=g.X_N_minus)
-
-    def step():
-        g.GPU_NTT(d_in, d_out, table, prm.modulus, cfg, BATCH)
-
+    case = build_case(g, cfg, rank, world, dev, args.api)
+    step = case["step"]
     step()
     torch.cuda.synchronize()
-    y_first = g.to_host(d_out)[:args.cpu_polys * n].copy()  # checked in the cpu_baseline leg
+    if args.child:
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        return
+
+    bits, logn, n = cfg["bits"], cfg["logn"], case["n"]
+    cpu_polys = min(max(args.cpu_polys, os.cpu_count() or 1), case["batch"])  # >= one polynomial per host thread
+    if cfg["kind"] == "rns":
+        cpu_polys = max(cfg["mod_count"], cpu_polys - cpu_polys % cfg["mod_count"])
+    y_first = gpu_sample_for_check(g, cfg, case, cpu_polys) if rank == 0 else None
 
     # clock settle (untimed, before the W warm-up steps): the part needs ~60 ms of load to leave its
     # idle clocks; without this a short --steps/--warmup run reads 10-15 % slow
     t_settle = time.perf_counter()
     while time.perf_counter() - t_settle < 0.15:
-        for _ in range(8):
+        for _ in range(4):
             step()
         torch.cuda.synchronize()
     for _ in range(args.warmup):
@@ -144,50 +371,79 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dev_ms = float(t[0])
 
-    if rank == 0:
-        # HBM bytes per call from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-        # passes of this same command, summarised by tools/pmc_summary.py with the gfx950 x2 fetch
-        # correction); a profile cannot be taken from inside the timed run, so the committed
-        # summary of the current round is quoted
-        traffic = None
+    # the other API form on the same buffers, timed the same way for the record (never `value`)
+    other = None
+    if "other_step" in case:
         try:
-            pm = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles")) if p.endswith("_pmc_traffic.json"))
-            if pm:
-                traffic = json.load(open(os.path.join(ROOT, "profiles", pm[-1])))["bytes_per_call"]
-        except Exception:
-            traffic = None
+            ostep = case["other_step"]()
+            ostep()
+            torch.cuda.synchronize()
+            for _ in range(max(args.warmup, 10)):
+                ostep()
+            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a0.record()
+            for _ in range(args.steps):
+                ostep()
+            a1.record()
+            torch.cuda.synchronize()
+            other = a0.elapsed_time(a1) / args.steps
+        except Exception as e:  # informational only
+            other = "failed: %r" % (e,)
+
+    e2e = None
+    if dist is not None and not args.no_e2e and case.get("run_shard") is not None:
+        try:
+            e2e = dist_mod.end_to_end_leg(dist, rank, world, dev, case["table"], case["d_in"], case["d_out"],
+                                          case["run_shard"], case["batch"])
+        except Exception as e:
+            e2e = {"error": repr(e)}
+
+    if rank == 0:
         ms_per_step = wall * 1e3 / args.steps
         call_ms = dev_ms / args.steps
-        alg_bytes = 2 * n * (BITS // 8) * BATCH  # every coefficient read once + written once
+        per_step = case["transforms_per_step"]
+        alg_bytes = 2 * n * (bits // 8) * per_step  # every coefficient read once + written once per transform
         achieved = alg_bytes / (call_ms * 1e-3) / 1e9
+        traffic, traffic_info = None, None
+        if world == 1 and not args.no_traffic:
+            traffic, traffic_info = measure_traffic(args.config, args.api)
+        quoted = False
+        if traffic is None:
+            reason = traffic_info
+            traffic, src = quoted_traffic() if args.config == "c2" else (None, None)
+            quoted = traffic is not None
+            traffic_info = {"quoted": quoted, "source": src, "why_not_measured": reason or "disabled / multi-GPU run"}
         line = {
-            "metric": METRIC,
-            "value": world * BATCH * args.steps / wall,
+            "metric": cfg["metric"],
+            "value": world * per_step * args.steps / wall,
             "unit": "NTT/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": cfg["scaling"],
             "vs_baseline": None,
-            "dtype": "u64",
+            "dtype": "u%d" % bits,
             "data": "synthetic",
-            "config": {"workload": "Merge-NTT Data64 log2N=16 batch=1024 forward (BASELINE configs[1])",
-                       "log2N": LOGN, "batch_per_gpu": BATCH, "reduction_poly": "X_N_minus",
-                       "modulus": prm.modulus.value, "out_of_place": True,
+            "config": {"workload": cfg["workload"], "log2N": logn, "batch_per_gpu": case["batch"],
+                       "reduction_poly": "X_N_" + cfg["poly"], "modulus": int(case["modulus"]),
+                       "out_of_place": True, "api": args.api,
                        "parallelism": "batch-shard x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_info": traffic_info,
                          "algorithmic_bytes_per_call": alg_bytes,
                          "call_ms_hip_events": call_ms,
-                         "note": "one call = every launch of one GPU_NTT (twiddle prep + 6-stage strided "
-                                 "pass + 10-stage contiguous pass = 2 HBM sweeps, traffic = PMC bytes per "
-                                 "call); the contiguous pass dominates and is VALU-issue bound; per-kernel "
-                                 "averages in profiles/"},
+                         "note": "one call = every launch of one library call; achieved = algorithmic bytes "
+                                 "per call / HIP-event time per call; per-kernel averages in profiles/"},
         }
+        if isinstance(other, float):
+            line["other_api_ms_per_call"] = {"api": "plan" if args.api == "dropin" else "dropin", "ms": other}
+        if e2e is not None:
+            line["end_to_end"] = e2e
         if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only
-            line["cpu_baseline"] = cpu_baseline(prm.modulus.value, x[:args.cpu_polys * n], y_first, LOGN)
+            case["x_sample"] = case["x"][:cpu_polys * n] if cfg["kind"] != "4step" else case["x"][:n]
+            line["cpu_baseline"] = cpu_baseline(cfg, case, y_first)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -7,6 +7,12 @@ that axis: rank r of G owns polynomials [lo, hi) and runs the ordinary single-GP
 on its shard.  A transform never crosses a GPU, so there is NO data-path collective; the only
 collectives are control-plane: a barrier around timed regions, a MAX-reduction of elapsed
 times, and (optionally) a digest all-gather to check results.
+
+When the batch ORIGINATES on one GPU there is data movement around the transform (SURVEY.md 8e ii):
+one broadcast of the twiddle table at set-up, a scatter of the shards before and a gather after.
+`scatter_transform_gather` / `end_to_end_leg` do exactly that with RCCL (grouped send/recv under
+torch.distributed.scatter / gather) and time each part on its own, so a multi-GPU run reports the
+resident-shard throughput and the end-to-end figure side by side.
 """
 import hashlib
 import os
@@ -77,3 +83,53 @@ def gather_digests(local_array, dist=None):
     out = [None] * dist.get_world_size()
     dist.all_gather_object(out, h)
     return out
+
+
+def _timed_collective(fn, dist, device):
+    """seconds of fn() bracketed by barrier + device synchronise, MAX over ranks"""
+    import torch
+    _sync(device)
+    dist.barrier()
+    _sync(device)
+    t0 = time.perf_counter()
+    fn()
+    _sync(device)
+    dist.barrier()
+    _sync(device)
+    dt = time.perf_counter() - t0
+    dev = device if (device is not None and dist.get_backend() == "nccl") else "cpu"
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t[0])
+
+
+def scatter_transform_gather(dist, rank, world, full, shard_in, shard_out, run_shard, device=None):
+    """The batch starts on rank 0 (`full`: world equal shards back to back, None elsewhere): scatter,
+    run_shard(shard_in, shard_out) on every rank, gather on rank 0.  Returns (gathered tensor on rank 0 |
+    None, {"scatter_s", "transform_s", "gather_s"}), every part MAX-reduced over the ranks."""
+    import torch
+    scatter_list = list(full.chunk(world)) if rank == 0 else None
+    t_s = _timed_collective(lambda: dist.scatter(shard_in, scatter_list, src=0), dist, device)
+    t_c = _timed_collective(lambda: run_shard(shard_in, shard_out), dist, device)
+    gathered = torch.empty(world * shard_out.numel(), dtype=shard_out.dtype, device=shard_out.device) \
+        if rank == 0 else None
+    gather_list = list(gathered.chunk(world)) if rank == 0 else None
+    t_g = _timed_collective(lambda: dist.gather(shard_out, gather_list, dst=0), dist, device)
+    return gathered, {"scatter_s": t_s, "transform_s": t_c, "gather_s": t_g}
+
+
+def end_to_end_leg(dist, rank, world, device, table, d_in, d_out, run_shard, batch):
+    """SURVEY.md 8e(ii) for bench.py: table broadcast (set-up, once), then scatter + transform + gather of
+    a batch that lives on rank 0.  The shard contents are this rank's synthetic input replicated (the
+    timing does not depend on the values).  Returns a JSON-ready dict."""
+    import torch
+    t_b = _timed_collective(lambda: dist.broadcast(table, src=0), dist, device)
+    full = torch.cat([d_in] * world) if rank == 0 else None
+    shard = torch.empty_like(d_in)
+    _, t = scatter_transform_gather(dist, rank, world, full, shard, d_out, run_shard, device)
+    total = t["scatter_s"] + t["transform_s"] + t["gather_s"]
+    return {"table_broadcast_ms": t_b * 1e3, "scatter_ms": t["scatter_s"] * 1e3,
+            "transform_ms": t["transform_s"] * 1e3, "gather_ms": t["gather_s"] * 1e3,
+            "ntt_per_s_including_scatter_gather": world * batch / total,
+            "bytes_scattered": int(d_in.numel() * d_in.element_size() * (world - 1)),
+            "note": "batch resident on rank 0 before and after; one call, not averaged (set-up excluded)"}

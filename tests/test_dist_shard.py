@@ -40,6 +40,23 @@ assert wall > 0
 digs = dist_mod.gather_digests(state["y"], dist)
 if rank == 0:
     print("DIGESTS", " ".join(digs), "SPAN", lo, hi, flush=True)
+# the end-to-end leg (batch starts and ends on rank 0): scatter -> per-rank transform -> gather
+import torch
+shard_len = (hi - lo) * n
+full = None
+if rank == 0:
+    full_np = np.concatenate([P.splitmix(100 + p, 0, n, prms[p % mc]["mod"][0]) for p in range(batch)])
+    full = torch.from_numpy(full_np.view(np.int64).copy())
+shard_in = torch.empty(shard_len, dtype=torch.int64)
+shard_out = torch.empty(shard_len, dtype=torch.int64)
+def run_shard(a, b):
+    xa = a.numpy().view(np.uint64)
+    y = np.concatenate([P.merge_ntt(xa[i * n:(i + 1) * n], prms[(lo + i) % mc]) for i in range(hi - lo)])
+    b.copy_(torch.from_numpy(y.view(np.int64).copy()))
+gathered, times = dist_mod.scatter_transform_gather(dist, rank, world, full, shard_in, shard_out, run_shard, None)
+assert set(times) == {"scatter_s", "transform_s", "gather_s"} and all(v > 0 for v in times.values())
+if rank == 0:
+    print("E2E", hashlib.sha256(gathered.numpy().tobytes()).hexdigest(), flush=True)
 dist.barrier()
 dist.destroy_process_group()
 '''
@@ -72,3 +89,5 @@ def test_two_rank_gloo_sharded_equals_unsharded(tmp_path):
     want = [hashlib.sha256(np.concatenate(full[0:12]).tobytes()).hexdigest(),
             hashlib.sha256(np.concatenate(full[12:24]).tobytes()).hexdigest()]
     assert digs == want
+    e2e = [l for l in r.stdout.splitlines() if l.startswith("E2E")][0].split()[1]
+    assert e2e == hashlib.sha256(np.concatenate(full).tobytes()).hexdigest()
