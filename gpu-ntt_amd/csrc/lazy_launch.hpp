@@ -11,7 +11,11 @@ namespace gpuntt
 {
     namespace host
     {
-        constexpr int LAZY_MAX_N_POWER = 24; // prepared table = 2 words * N per modulus
+        // largest ring of the fast kernels = the reference's own limit (reference ntt.cu:2088-2091).  The prepared
+        // table is 2 words x N per modulus (4 GiB of scratch at 2^28 in 64-bit words -- 1.4 % of the part's HBM);
+        // rings above 2^24 take two strided passes + the contiguous pass like 2^24 does (the reference switches
+        // to its grid-swapped ForwardCore_ / InverseCore_ there, ntt.cu:763-1084, 1320-1552)
+        constexpr int LAZY_MAX_N_POWER = 28;
 
         // tile size (log2) used by the fast kernels for element type T and ring size 2^n:
         // 64-bit: 4096 coefficients (32 KiB of LDS).  32-bit: 16384 coefficients (64 KiB) for rings

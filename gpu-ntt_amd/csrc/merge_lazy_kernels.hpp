@@ -268,8 +268,17 @@ namespace gpuntt
                 return *p;
         }
 
+        // exchange point of a pass whose LDS traffic never leaves the wave: LDS operations of one wave
+        // execute in order, so only the compiler has to be kept from moving the reads above the writes
+        __device__ __forceinline__ void wave_sync()
+        {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+
         template <typename T, int TLOG, bool EXACT, bool INV, bool CONTIG, int K, int IN_BOUND, bool LAST,
-                  int FST = 0, bool WMUL = false, bool COH_IN = false>
+                  int FST = 0, bool WMUL = false, bool COH_IN = false, bool PERSIST = false>
         __device__ __forceinline__ void pass_body(const LazyArgsT<T>& a, T* lds, T q_value, T q_bit, T q_mu,
                                                   int mi, unsigned long long fst_poly = 0,
                                                   unsigned fst_tile = 0, long long blk_override = -1,
@@ -284,12 +293,20 @@ namespace gpuntt
 
             // single-pass transforms of rings smaller than a tile: the tile holds several polynomials
             constexpr bool MULTI_POLY = CONTIG && (K < TL) && (IN_BOUND == 1) && (LAST || FST);
+            // Forward contiguous pass of at most 10 stages on a 4096-coefficient tile: the tile is four
+            // independent 1024-coefficient sub-blocks and wave w (thread bits 7..6 = tile bits 11..10 in
+            // every register window) owns sub-block w through all rounds, so no exchange crosses a wave:
+            // the block barriers become wave-level ordering points and the four waves run unsynchronised.
+            // The final store leaves through the 64-contiguous window (512-byte runs per wave instruction).
+            constexpr bool WAVE_LOCAL = CONTIG && !INV && !FST && !MULTI_POLY && !EXACT && (TL == 12) && (K <= TL - 2) &&
+                                        (K >= 8);
 
-            // opaque copy: inside the persistent single-sweep kernel nothing derived from the thread id
-            // (lane offsets, LDS addresses of either pass) may be hoisted out of the polynomial loop and
+            // PERSIST (persistent single-launch kernel): opaque copy of the thread id, so that nothing derived
+            // from it (lane offsets, LDS addresses of either pass) is hoisted out of the polynomial loop and
             // kept alive across both passes
             int t = threadIdx.x;
-            asm volatile("" : "+v"(t));
+            if constexpr (PERSIST)
+                asm volatile("" : "+v"(t));
             constexpr bool SEG = (FST == 2);
             using Map = LTileMap<TLOG, CONTIG, K, SEG>;
             Map map = SEG   ? Map((fst_poly << a.poly_shift) +
@@ -682,6 +699,31 @@ namespace gpuntt
                             }
                         }
                     }
+                    else if constexpr (WAVE_LOCAL)
+                    {
+                        // registers (16 contiguous coefficients per thread) -> LDS -> the wave's own
+                        // 64-contiguous window -> 512-byte runs per store instruction
+                        constexpr int OWL = 6;
+                        T* lw = lds + lds_pad(elem_of<WL>(t, 0));
+#pragma unroll
+                        for (int j = 0; j < EPT; j++)
+                            lw[lds_joff<WL>(j)] = v[j];
+                        wave_sync();
+                        const T* lo = lds + lds_pad(elem_of<OWL>(t, 0));
+#pragma unroll
+                        for (int j = 0; j < EPT; j++)
+                            v[j] = lo[lds_joff<OWL>(j)];
+                        const unsigned lane = map.part(elem_of<OWL>(t, 0));
+                        if (PMUL_OK && mul_in != nullptr)
+                        {
+#pragma unroll
+                            for (int j = 0; j < EPT; j++)
+                                v[j] = em.mul(v[j], (mul_in + (map.base + map.part(static_cast<unsigned>(j) << OWL)))[lane]);
+                        }
+#pragma unroll
+                        for (int j = 0; j < EPT; j++)
+                            (a.out + (map.base + map.part(static_cast<unsigned>(j) << OWL)))[lane] = v[j];
+                    }
                     else if constexpr (DIRECT_IO)
                     {
                         if constexpr (WMUL && !INV)
@@ -792,7 +834,10 @@ namespace gpuntt
 #pragma unroll
                     for (int j = 0; j < EPT; j++)
                         lw[lds_joff<WL>(j)] = v[j];
-                    __syncthreads();
+                    if constexpr (WAVE_LOCAL)
+                        wave_sync();
+                    else
+                        __syncthreads();
                 }
             });
         }
@@ -973,9 +1018,9 @@ namespace gpuntt
                     }
                     // first pass: input -> lazy intermediate in `out`
                     if constexpr (!INV)
-                        pass_body<T, TLOG, false, false, false, KS, 1, false>(a1, lds, qv, qb, qm, mi, 0, 0, blk);
+                        pass_body<T, TLOG, false, false, false, KS, 1, false, 0, false, false, true>(a1, lds, qv, qb, qm, mi, 0, 0, blk);
                     else
-                        pass_body<T, TLOG, false, true, true, KC, 1, false>(a1, lds, qv, qb, qm, mi, 0, 0, blk);
+                        pass_body<T, TLOG, false, true, true, KC, 1, false, 0, false, false, true>(a1, lds, qv, qb, qm, mi, 0, 0, blk);
                 }
                 target += G;
                 group_barrier(cnt, target, slow, err);
@@ -994,9 +1039,9 @@ namespace gpuntt
                         qm = md.mu;
                     }
                     if constexpr (!INV)
-                        pass_body<T, TLOG, false, false, true, KC, M::LIMIT, true, 0, false, true>(a2, lds, qv, qb, qm, mi, 0, 0, blk);
+                        pass_body<T, TLOG, false, false, true, KC, M::LIMIT, true, 0, false, true, true>(a2, lds, qv, qb, qm, mi, 0, 0, blk);
                     else
-                        pass_body<T, TLOG, false, true, false, KS, M::LIMIT, true, 0, false, true>(a2, lds, qv, qb, qm, mi, 0, 0, blk);
+                        pass_body<T, TLOG, false, true, false, KS, M::LIMIT, true, 0, false, true, true>(a2, lds, qv, qb, qm, mi, 0, 0, blk);
                 }
                 __syncthreads(); // the next polynomial's first pass reuses the exchange buffer
             }

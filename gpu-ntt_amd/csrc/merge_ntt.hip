@@ -78,6 +78,8 @@ namespace gpuntt
                     return 1;
                 if (std::strcmp(e, "fast") == 0)
                     return 2;
+                if (std::strcmp(e, "fast-strict") == 0)
+                    return 3; // test hook: like "fast", and a call the fast kernels cannot take throws
                 return 0;
             }();
             return mode;
@@ -85,15 +87,14 @@ namespace gpuntt
 
         template <typename TU> inline bool lazy_eligible(int n_power, int batch_size, int mod_count)
         {
-            if (n_power > host::LAZY_MAX_N_POWER)
+            const bool can = n_power <= host::LAZY_MAX_N_POWER &&
+                             !(mod_count > 1 && n_power < host::lazy_tile_log<TU>(n_power)) && // a tile would mix moduli
+                             (static_cast<unsigned long long>(mod_count) << n_power) <= (1ull << 28); // 4 GiB table
+            if (forced_path() == 3 && !can)
+                throw std::invalid_argument("fast path unavailable for this call (GPUNTT_PATH=fast-strict)");
+            if (!can || forced_path() == 1)
                 return false;
-            if (mod_count > 1 && n_power < host::lazy_tile_log<TU>(n_power))
-                return false; // a tile would mix moduli
-            if ((static_cast<unsigned long long>(mod_count) << n_power) > (1ull << 26))
-                return false; // prepared table would exceed 1 GiB
-            if (forced_path() == 1)
-                return false;
-            if (forced_path() == 2)
+            if (forced_path() >= 2)
                 return true;
             // Single modulus: measured at batch = 1 (profiles/batch1_r01.txt) the prepared-twiddle
             // kernels win from 2^5 (64-bit) / 2^11 (32-bit) upwards even though they cost one

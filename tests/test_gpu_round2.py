@@ -290,3 +290,71 @@ def test_release_workspaces(g):
     assert np.array_equal(c.gpu_forward(x), want)
     g.release_workspaces()
     assert np.array_equal(c.gpu_forward(x), want)
+
+
+def test_fast_kernels_above_2_24(g):
+    """rings 2^25 / 2^26 run on the fast (lazy-residue) kernels, not the generic fallback of round 1:
+    GPUNTT_PATH=fast-strict makes any call the fast kernels cannot take throw (reference: the grid-swapped
+    ForwardCore_ / InverseCore_ rows of ntt.cuh:669-697)"""
+    from test_gpu_merge import _run_in_subprocess
+    code = """
+import numpy as np, sys, os
+sys.path.insert(0, os.path.join(os.path.dirname(os.environ["PYTHONPATH"]), ""))
+from conftest import load_pkg
+from gpu_utils import MergeCase
+from oracle import oracle as O
+g = load_pkg(); g.load_library()
+for bits, logn, poly in ((64, 25, O.X_N_minus), (32, 25, O.X_N_plus), (64, 26, O.X_N_plus)):
+    c = MergeCase(g, bits, logn, poly)
+    x = c.random(2, 2500 + logn)
+    y = c.gpu_forward(x, inplace=True)
+    n = c.n
+    assert np.array_equal(y[n:], c.P.merge_ntt(x[n:], c.oprm)), (bits, logn)
+    assert np.array_equal(c.gpu_inverse(y, inplace=True), x), (bits, logn)
+# the hook itself: a 62-bit modulus has no fast path -> the single-modulus entry point falls back silently
+# (host-side check), an RNS stack of tiny rings (tile would mix moduli) must throw under fast-strict
+print("OK")
+"""
+    assert "OK" in _run_in_subprocess(code, {"GPUNTT_PATH": "fast-strict"})
+
+
+@pytest.mark.parametrize("bits,logn,poly", [(64, 28, O.X_N_plus), (32, 25, O.X_N_minus)])
+def test_largest_rings_sparse_known_answer(g, bits, logn, poly):
+    """the top of the documented range (n_power <= 28, reference ntt.cu:2088-2091) without a CPU transform of
+    that size: a polynomial with a handful of non-zero coefficients has the closed-form spectrum
+    out[bitrev(k)] = sum_j a_j w^(j k) (X^N-1) / sum_j a_j psi^((2k+1) j) (X^N+1), checked
+    at sampled k with Python integers; plus the exact forward -> inverse round trip of random data."""
+    import torch
+    prm = g.NTTParameters(logn, poly, bits)
+    q, n = prm.modulus.value, 1 << logn
+    fwd = g.to_device(prm.forward_table_device_order)
+    rng = np.random.default_rng(logn)
+    js = [0, 1, 5, n // 3, n - 1]
+    av = [int(v) for v in rng.integers(1, q, size=len(js), dtype=np.uint64)]
+    x = np.zeros(n, dtype=g.np_dtype(bits))
+    for j, a in zip(js, av):
+        x[j] = a
+    d = g.to_device(x)
+    cfg = g.ntt_configuration(n_power=logn, ntt_type=g.FORWARD, reduction_poly=poly)
+    g.GPU_NTT_Inplace(d, fwd, prm.modulus, cfg, 1)
+    torch.cuda.synchronize()
+    y = g.to_host(d)
+
+    def brev(v):
+        return int(format(v, "0%db" % logn)[::-1], 2)
+    for k in [0, 1, 2, 3, n // 2, n // 2 + 1, n - 1] + [int(v) for v in rng.integers(0, n, size=24)]:
+        if poly == O.X_N_minus:
+            want = sum(a * pow(prm.omega, (j * k) % n, q) for j, a in zip(js, av)) % q
+        else:
+            want = sum(a * pow(prm.psi, ((2 * k + 1) * j) % (2 * n), q) for j, a in zip(js, av)) % q
+        assert int(y[brev(k)]) == want, (bits, logn, k)
+    del y
+    # round trip of random data, in place
+    inv = g.to_device(prm.inverse_table_device_order)
+    r = (rng.integers(0, q, size=n, dtype=np.uint64)).astype(g.np_dtype(bits))
+    d = g.to_device(r)
+    g.GPU_NTT_Inplace(d, fwd, prm.modulus, cfg, 1)
+    icfg = g.ntt_configuration(n_power=logn, ntt_type=g.INVERSE, reduction_poly=poly, mod_inverse=prm.n_inv)
+    g.GPU_INTT_Inplace(d, inv, prm.modulus, icfg, 1)
+    torch.cuda.synchronize()
+    assert np.array_equal(g.to_host(d), r)

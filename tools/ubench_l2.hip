@@ -33,8 +33,9 @@ __global__ __launch_bounds__(256) void wr_rd(uint64_t* buf, const uint64_t* stre
         acc += sp[i];
     __syncthreads();
     // read back: thread t reads element (t * 16 + j) -- lines written by other waves of the block
+    // (LOADKIND 4: no read-back at all -- do the stores themselves fetch the lines?)
 #pragma unroll
-    for (int j = 0; j < 16; j++)
+    for (int j = 0; j < (LOADKIND == 4 ? 0 : 16); j++)
     {
         const uint64_t* p = tile + ((t * 16 + j * 17) & 4095);
         if (LOADKIND == 0)
@@ -65,6 +66,7 @@ int main(int argc, char** argv)
         hipLaunchKernelGGL((wr_rd<1>), dim3(blocks), dim3(256), 0, 0, buf, stream, out, pollute);
         hipLaunchKernelGGL((wr_rd<2>), dim3(blocks), dim3(256), 0, 0, buf, stream, out, pollute);
         hipLaunchKernelGGL((wr_rd<3>), dim3(blocks), dim3(256), 0, 0, buf, stream, out, pollute);
+        hipLaunchKernelGGL((wr_rd<4>), dim3(blocks), dim3(256), 0, 0, buf, stream, out, pollute);
     }
     // calibration: the same read-back pattern on a buffer nobody touched in this launch (cold L2)
     uint64_t* cold;
