@@ -169,7 +169,9 @@ namespace gpuntt
             }
             static constexpr int wl_of(int r)
             {
-                int w = INV ? first_pos(r) : (first_pos(r) - R + 1);
+                // the register window is aligned to the TOP stage of the round in both directions (a short
+                // inverse round 8,9 of a 10-stage contiguous pass owns tile bits 6..9, like the forward one)
+                int w = INV ? (first_pos(r) + stages_of(r) - R) : (first_pos(r) - R + 1);
                 const int lo = CONTIG ? 0 : (G::L > TL - R ? TL - R : G::L);
                 return w < lo ? lo : (w > TL - R ? TL - R : w);
             }
@@ -298,8 +300,10 @@ namespace gpuntt
             // every register window) owns sub-block w through all rounds, so no exchange crosses a wave:
             // the block barriers become wave-level ordering points and the four waves run unsynchronised.
             // The final store leaves through the 64-contiguous window (512-byte runs per wave instruction).
-            constexpr bool WAVE_LOCAL = CONTIG && !INV && !FST && !MULTI_POLY && !EXACT && (TL == 12) && (K <= TL - 2) &&
-                                        (K >= 8);
+            // (The inverse's first pass mirrors it: coalesced load through the 64-contiguous window, wave-local
+            // transposition into the 16-contiguous one.)
+            constexpr bool WAVE_LOCAL = CONTIG && !FST && !MULTI_POLY && !EXACT && (TL == 12) && (K <= TL - 2) &&
+                                        (K >= 8) && (!INV || (IN_BOUND == 1 && !LAST));
 
             // PERSIST (persistent single-launch kernel): opaque copy of the thread id, so that nothing derived
             // from it (lane offsets, LDS addresses of either pass) is hoisted out of the polynomial loop and
@@ -511,6 +515,26 @@ namespace gpuntt
                                 v[j] = load_guarded(map.flat(elem_of<WL>(t, j)));
                         }
                     }
+                    else if constexpr (WAVE_LOCAL)
+                    {
+                        // inverse first pass: 512-byte runs per load instruction into the wave's own sub-block,
+                        // transposed to the 16-contiguous register window through the wave's LDS quarter
+                        constexpr int IWL = 6;
+                        const unsigned lane = map.part(elem_of<IWL>(t, 0));
+                        T tmp[EPT];
+#pragma unroll
+                        for (int j = 0; j < EPT; j++)
+                            tmp[j] = ld_in<COH_IN>((src + (map.base + map.part(static_cast<unsigned>(j) << IWL))) + lane);
+                        T* li = lds + lds_pad(elem_of<IWL>(t, 0));
+#pragma unroll
+                        for (int j = 0; j < EPT; j++)
+                            li[lds_joff<IWL>(j)] = tmp[j];
+                        wave_sync();
+                        const T* lw = lds + lds_pad(elem_of<WL>(t, 0));
+#pragma unroll
+                        for (int j = 0; j < EPT; j++)
+                            v[j] = lw[lds_joff<WL>(j)];
+                    }
                     else
                     {
                         if (plain_io)
@@ -597,9 +621,19 @@ namespace gpuntt
                                 unit = (tw.w == 1);
                             // U' = U + T comes out of the product's own multiply-add chain;
                             // V' = U - T + TB q = 2 U + TB q - U'  (mod 2^W; the true value is below LIMIT q)
-                            const T nu = unit ? static_cast<T>(U + v[j1]) : m.template mul_acc<UNIFORM_R>(v[j1], tw, U);
-                            v[j0] = nu;
-                            v[j1] = static_cast<T>((U << 1) + m.kq(M::TB) - nu);
+                            // (32-bit words: the separate product is one instruction shorter)
+                            if constexpr (sizeof(T) == 8)
+                            {
+                                const T nu = unit ? static_cast<T>(U + v[j1]) : m.template mul_acc<UNIFORM_R>(v[j1], tw, U);
+                                v[j0] = nu;
+                                v[j1] = static_cast<T>((U << 1) + m.kq(M::TB) - nu);
+                            }
+                            else
+                            {
+                                const T Tm = unit ? v[j1] : m.template mul<UNIFORM_R>(v[j1], tw);
+                                v[j0] = U + Tm;
+                                v[j1] = U + m.kq(M::TB) - Tm;
+                            }
                         }
                         else
                         {

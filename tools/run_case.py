@@ -13,8 +13,9 @@ from __graft_entry__ import _load_pkg  # noqa: E402
 case = sys.argv[1]
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 g = _load_pkg()
-if os.environ.get("GPUNTT_LIB"):  # experiment builds
+if os.environ.get("GPUNTT_LIB"):  # experiment builds (may be older than the current C ABI)
     g.LIB_PATH = os.environ["GPUNTT_LIB"]
+    g.EXPORTED_SYMBOLS = ["gpuntt_last_error"]
 g.load_library()
 if case == "c2":
     bc.merge_case(g, 64, 16, 1024, g.X_N_minus, iters, "C2")
