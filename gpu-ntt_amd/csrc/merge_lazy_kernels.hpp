@@ -295,16 +295,16 @@ namespace gpuntt
 
             // single-pass transforms of rings smaller than a tile: the tile holds several polynomials
             constexpr bool MULTI_POLY = CONTIG && (K < TL) && (IN_BOUND == 1) && (LAST || FST);
-            // Forward contiguous pass of at most 10 stages on a 4096-coefficient tile: the tile is four
-            // independent 1024-coefficient sub-blocks and wave w (thread bits 7..6 = tile bits 11..10 in
-            // every register window) owns sub-block w through all rounds, so no exchange crosses a wave:
-            // the block barriers become wave-level ordering points and the four waves run unsynchronised.
-            // The final store leaves through the 64-contiguous window (512-byte runs per wave instruction).
-            // (The inverse's first pass mirrors it: coalesced load through the 64-contiguous window, wave-local
-            // transposition into the 16-contiguous one.)
-            constexpr bool WAVE_LOCAL = CONTIG && !FST && !MULTI_POLY && !EXACT && (TL == 12) && (K <= TL - 2) &&
-                                        (K >= 8) && (!INV || (IN_BOUND == 1 && !LAST));
-
+            // Wave-local exchanges.  elem_of<WL> sends thread bit b >= WL to tile bit b + 4, so in every register
+            // window with WL <= 6 the wave index (thread bits >= 6) IS the index of the 1024-coefficient
+            // sub-block (tile bits >= 10) the wave's 16 x 64 coefficients lie in.  An exchange between two such
+            // windows never leaves the wave's own LDS region: the block barrier becomes a wave-level ordering
+            // point (wave_sync) and the waves of a workgroup run unsynchronised -- all of a contiguous pass of
+            // <= 10 stages, the last exchange of every longer one (u64 K = 11, 12; u32 big tiles).  Full-tile
+            // contiguous passes also enter / leave through the 64-contiguous window (512-byte runs per wave
+            // instruction, WIO) with a wave-local transposition instead of the block-wide coalescing pass.
+            constexpr bool WIO_OK = CONTIG && !FST && !MULTI_POLY && !EXACT && (TL >= 10);
+            constexpr int WIO = 6;
             // PERSIST (persistent single-launch kernel): opaque copy of the thread id, so that nothing derived
             // from it (lane offsets, LDS addresses of either pass) is hoisted out of the polynomial loop and
             // kept alive across both passes
@@ -515,11 +515,11 @@ namespace gpuntt
                                 v[j] = load_guarded(map.flat(elem_of<WL>(t, j)));
                         }
                     }
-                    else if constexpr (WAVE_LOCAL)
+                    else if constexpr (WIO_OK && WL <= 6)
                     {
-                        // inverse first pass: 512-byte runs per load instruction into the wave's own sub-block,
-                        // transposed to the 16-contiguous register window through the wave's LDS quarter
-                        constexpr int IWL = 6;
+                        // (inverse first pass) 512-byte runs per load instruction into the wave's own sub-block,
+                        // transposed to the register window through the wave's own LDS region
+                        constexpr int IWL = WIO;
                         const unsigned lane = map.part(elem_of<IWL>(t, 0));
                         T tmp[EPT];
 #pragma unroll
@@ -733,11 +733,11 @@ namespace gpuntt
                             }
                         }
                     }
-                    else if constexpr (WAVE_LOCAL)
+                    else if constexpr (WIO_OK && !DIRECT_IO && WL <= 6)
                     {
                         // registers (16 contiguous coefficients per thread) -> LDS -> the wave's own
                         // 64-contiguous window -> 512-byte runs per store instruction
-                        constexpr int OWL = 6;
+                        constexpr int OWL = WIO;
                         T* lw = lds + lds_pad(elem_of<WL>(t, 0));
 #pragma unroll
                         for (int j = 0; j < EPT; j++)
@@ -868,8 +868,8 @@ namespace gpuntt
 #pragma unroll
                     for (int j = 0; j < EPT; j++)
                         lw[lds_joff<WL>(j)] = v[j];
-                    if constexpr (WAVE_LOCAL)
-                        wave_sync();
+                    if constexpr (!EXACT && WL <= 6 && SCH::wl_of(r + 1 < G::NR ? r + 1 : r) <= 6)
+                        wave_sync(); // both windows inside the wave's sub-block
                     else
                         __syncthreads();
                 }
