@@ -199,6 +199,7 @@ namespace gpuntt
         // two launches it replaces, and its group barriers make it slower (0.55 vs 0.45 ms at 2^16 x 1024).
         // GPUNTT_FUSED_MODE=1 builds groups from consecutive block indices, =2 forces the fence protocol
         // (tests of the placement-independent path).
+        bool lazy_reverse_passes();
         int lazy_fused_env();
         int lazy_fused_mode();
         template <typename T> inline bool lazy_use_fused(int n, int tile_log, bool inverse, unsigned long long polys)
@@ -256,6 +257,10 @@ namespace gpuntt
                     a.flags |= first_in_flags;
                 if (i == pl.count - 1)
                     a.flags |= last_out_flags;
+                // the last pass walks the batch forwards, the one before it backwards, ... (Infinity Cache reuse
+                // of the hand-off; GPUNTT_NO_REVERSE=1 switches it off for A/B timing)
+                if (((pl.count - 1 - i) & 1) != 0 && lazy_reverse_passes())
+                    a.flags |= kern::F_REVERSE;
                 // 64-bit: only the contiguous pass runs on a big tile
                 const int tlp = (sizeof(T) == 8 && !p.contig) ? 12 : tl;
                 // rings from 2^20: the per-lane twiddles of a contiguous pass are tens of MiB per

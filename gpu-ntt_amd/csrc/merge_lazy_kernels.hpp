@@ -898,15 +898,17 @@ namespace gpuntt
             // a.batch > 1: poly-minor block order (block b -> tile b / batch of polynomial b % batch), asked
             // for by the host for big rings so that the polynomials of a batch read each slice of the
             // twiddle table back to back (L2 hits instead of one HBM read per polynomial)
-            long long blk = -1;
+            // F_REVERSE: consecutive passes of one transform walk the batch in opposite directions, so a pass
+            // starts on the data its predecessor wrote last -- the part still in the 256 MiB Infinity Cache
+            const unsigned bx = (a.flags & F_REVERSE) ? (gridDim.x - 1u - blockIdx.x) : blockIdx.x;
+            long long blk = static_cast<long long>(bx);
             if (a.batch > 1)
                 blk = static_cast<long long>(
-                    (static_cast<unsigned long long>(blockIdx.x % static_cast<unsigned>(a.batch)) << (a.n - TLOG)) |
-                    (blockIdx.x / static_cast<unsigned>(a.batch)));
+                    (static_cast<unsigned long long>(bx % static_cast<unsigned>(a.batch)) << (a.n - TLOG)) |
+                    (bx / static_cast<unsigned>(a.batch)));
             if (a.mods != nullptr)
             {
-                const LTileMap<TLOG, CONTIG, K> map(a.n, a.p_lo, blk >= 0 ? static_cast<unsigned long long>(blk)
-                                                                          : static_cast<unsigned long long>(blockIdx.x));
+                const LTileMap<TLOG, CONTIG, K> map(a.n, a.p_lo, static_cast<unsigned long long>(blk));
                 const unsigned long long poly = map.flat(0) >> a.poly_shift;
                 mi = static_cast<int>(poly % static_cast<unsigned>(a.mod_count));
                 const Modulus<T> md = a.mods[a.mod_order != nullptr ? a.mod_order[mi] : mi];

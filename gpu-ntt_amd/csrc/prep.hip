@@ -373,6 +373,14 @@ namespace gpuntt
             return 12;
         }
 
+        bool lazy_reverse_passes()
+        {
+            static const bool v = [] {
+                const char* e = std::getenv("GPUNTT_NO_REVERSE");
+                return !(e != nullptr && std::atoi(e) != 0);
+            }();
+            return v;
+        }
         int lazy_fused_env()
         {
             static const int v = [] {

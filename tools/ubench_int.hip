@@ -6,6 +6,10 @@
 #include <cstdint>
 #include <vector>
 #include <string>
+#include <thread>
+#include <atomic>
+#include <chrono>
+#include <cstring>
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
@@ -100,8 +104,24 @@ KERNEL(k_lshladd32, REP8(LSHLADD32), 0)
 
 typedef void (*kfn)(uint32_t*, uint32_t);
 
-int main()
+// `ubench_int power`: socket power and shader clock (rocm-smi) while ONE opcode runs back to back on every SIMD
+// for ~4 s: at equal clock the power difference between opcodes is their energy per instruction
+static std::string smi_sample()
 {
+    std::string out;
+    FILE* f = popen("rocm-smi --showpower --showclocks 2>/dev/null | grep -E 'sclk|Socket' | sed 's/.*: //' | tr '\\n' ' '", "r");
+    if (!f)
+        return "n/a";
+    char buf[256];
+    while (fgets(buf, sizeof(buf), f))
+        out += buf;
+    pclose(f);
+    return out;
+}
+
+int main(int argc, char** argv)
+{
+    const bool power_mode = argc > 1 && std::strcmp(argv[1], "power") == 0;
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
     int cus = prop.multiProcessorCount;
@@ -123,6 +143,45 @@ int main()
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
+    if (power_mode)
+    {
+        printf("idle: %s\n", smi_sample().c_str());
+        const int blocks = cus * 4;
+        for (auto& k : ks)
+        {
+            const std::string nm = k.name;
+            if (nm != "v_mul_lo_u32" && nm != "v_mul_hi_u32" && nm != "v_mad_u64_u32" && nm != "v_add_u32" &&
+                nm != "v_lshl_add_u64" && nm != "v_sub_co_u32" && nm != "v_cndmask_b32_e64 sgpr" && nm != "v_mov_b32" &&
+                nm != "v_fma_f64" && nm != "v_add3_u32" && nm != "v_mul_u32_u24")
+                continue;
+            std::atomic<bool> stop{false};
+            std::string s1, s2;
+            std::thread sampler([&] {
+                std::this_thread::sleep_for(std::chrono::milliseconds(1500));
+                s1 = smi_sample();
+                s2 = smi_sample();
+                stop = true;
+            });
+            auto t0 = std::chrono::steady_clock::now();
+            long launches = 0;
+            CHECK(hipEventRecord(e0));
+            while (!stop)
+            {
+                for (int i = 0; i < 16; i++)
+                    hipLaunchKernelGGL(k.fn, dim3(blocks), dim3(256), 0, 0, out, 1u);
+                launches += 16;
+                CHECK(hipDeviceSynchronize());
+            }
+            CHECK(hipEventRecord(e1));
+            CHECK(hipEventSynchronize(e1));
+            sampler.join();
+            const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            const double winstr = double(launches) * double(ITERS) * 32 * 4 * cus * 4; // wave-instructions on the chip
+            printf("%-24s %6.2f G wave-instr/s   clock/power samples: %s | %s\n", k.name, winstr / sec / 1e9, s1.c_str(),
+                   s2.c_str());
+        }
+        return 0;
+    }
     for (int wpsimd : {2, 4})
     {
         printf("--- %d wave(s) per SIMD ---\n", wpsimd);
