@@ -6,8 +6,9 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Default = BASELINE.json's metric configuration (configs[1], "c2"): forward Merge NTT, 64-bit, N = 2^16,
-batch = 1024 per GPU, through the drop-in GPU_NTT call.  One "step" = one library call (all of its kernel
-launches) over one batch of synthetic random polynomials already resident in HBM.
+batch = 1024 per GPU, through the drop-in GPU_NTT call, IN PLACE like the reference's own benchmark
+(benchmark/bench_merge_ntt.cu:62 times GPU_NTT_Inplace; --out-of-place times GPU_NTT(in, out)).  One "step" = one
+library call (all of its kernel launches) over one batch of synthetic random polynomials already resident in HBM.
 
     c2  Merge u64 2^16 x 1024 per GPU, forward, X^N-1                    (weak scaling)
     c3  4-Step u64 2^24 x 64 per GPU, forward + inverse pair              (weak scaling)
@@ -135,7 +136,7 @@ def cpu_baseline(cfg, case, y_gpu_sample):
 
 
 # --------------------------------------------------------------------------- HBM traffic (PMC)
-def measure_traffic(config, api):
+def measure_traffic(config, api, out_of_place=False):
     """HBM bytes per call from the PMC counters, measured in THIS run: two short rocprofv3 --pmc child
     passes of this script (FETCH_SIZE, WRITE_SIZE -- separate passes, MI355X_MICROARCH.md), gfx950 x2
     correction on the fetch side.  Returns (bytes_per_call, detail) or (None, reason)."""
@@ -154,7 +155,7 @@ def measure_traffic(config, api):
             out = os.path.join(tmp, counter)
             cmd = [rocprof, "--pmc", counter, "-d", out, "-o", "pmc", "--", sys.executable,
                    os.path.join(ROOT, "bench.py"), "--config", config, "--api", api, "--steps", str(steps),
-                   "--warmup", "0", "--child"]
+                   "--warmup", "0", "--child"] + (["--out-of-place"] if out_of_place else [])
             r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
             dbs = glob.glob(out + "/**/*.db", recursive=True)
             if r.returncode != 0 or not dbs:
@@ -197,7 +198,7 @@ def quoted_traffic():
 
 
 # ------------------------------------------------------------------------------- workloads
-def build_case(g, cfg, rank, world, dev, api):
+def build_case(g, cfg, rank, world, dev, api, inplace=True):
     """Returns a dict with step(), the shard geometry, a sample for the CPU check and the pieces the
     end-to-end leg needs."""
     import torch
@@ -305,6 +306,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--out-of-place", action="store_true",
+                    help="time GPU_NTT(in, out) instead of the in-place call the reference's own benchmark times")
     ap.add_argument("--cpu-polys", type=int, default=64)
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)  # PMC child pass: calls only
     args = ap.parse_args()
@@ -328,9 +331,10 @@ def main():
     dev = "cuda:%d" % local_rank
     dist, rank, world = dist_mod.init_process_group("nccl", dev)
 
-    case = build_case(g, cfg, rank, world, dev, args.api)
+    inplace = not args.out_of_place and cfg["kind"] != "4step"
+    case = build_case(g, cfg, rank, world, dev, args.api, inplace)
     step = case["step"]
-    step()
+    case.get("first", step)()  # d_in -> d_out once: the output the CPU leg checks
     torch.cuda.synchronize()
     if args.child:
         for _ in range(args.steps):
@@ -406,7 +410,7 @@ def main():
         achieved = alg_bytes / (call_ms * 1e-3) / 1e9
         traffic, traffic_info = None, None
         if world == 1 and not args.no_traffic:
-            traffic, traffic_info = measure_traffic(args.config, args.api)
+            traffic, traffic_info = measure_traffic(args.config, args.api, args.out_of_place)
         quoted = False
         if traffic is None:
             reason = traffic_info
@@ -428,7 +432,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": cfg["workload"], "log2N": logn, "batch_per_gpu": case["batch"],
                        "reduction_poly": "X_N_" + cfg["poly"], "modulus": int(case["modulus"]),
-                       "out_of_place": True, "api": args.api,
+                       "in_place": inplace, "api": args.api,
                        "parallelism": "batch-shard x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_info": traffic_info,
