@@ -45,7 +45,10 @@ namespace gpuntt
         __device__ __forceinline__ uint32_t lo32(uint64_t v) { return static_cast<uint32_t>(v); }
         __device__ __forceinline__ uint32_t hi32(uint64_t v) { return static_cast<uint32_t>(v >> 32); }
 
-        template <typename T> struct Mod;
+        // LIM = 0: the default lazy range of the word size (16 q for 64-bit words, q < 2^60; 4 q for 32-bit words,
+        // q < 2^30); LIM = 8: 64-bit words with 61-bit moduli (8 q < 2^64: one range correction per stage);
+        // LIM = 4: 62-bit moduli (4 q < 2^64: products corrected to [0, 2q), the 32-bit scheme in 64-bit words)
+        template <typename T, int LIM = 0> struct Mod;
 
         // constants of the one-multiply final normalisation (64-bit only): for x < 16 q
         //   k = ((x >> sh) * M) >> (32 + c)  is floor(x / q) or one less, so x - k*q is in [0, 2q)
@@ -57,7 +60,7 @@ namespace gpuntt
         __host__ __device__ inline NormConst make_norm_const(uint64_t q, uint64_t bit)
         {
             NormConst n{0, 0, 0, 0};
-            if (q < 3 || bit < 2 || bit > 60)
+            if (q < 3 || bit < 2 || bit > 61)
                 return n;
             n.sh = bit > 27 ? static_cast<uint32_t>(bit - 27) : 0u;
             const uint64_t qt = (q >> n.sh) + (n.sh > 0 ? 1u : 0u); // exact when nothing is shifted out
@@ -90,12 +93,12 @@ namespace gpuntt
             return d;
         }
 
-        // ---- 64-bit: sloppy-quotient Shoup product in [0, 4q); LIMIT 16 needs q < 2^60 ------
-        template <> struct Mod<uint64_t>
+        // ---- 64-bit: sloppy-quotient Shoup product in [0, 4q); LIMIT 16 needs q < 2^60, LIMIT 8 q < 2^61 ------
+        template <int LIM> struct Mod64
         {
-            static constexpr int TB = 4;      // product bound (units of q)
-            static constexpr int LIMIT = 16;  // lazy values stay below LIMIT * q < 2^64
-            static constexpr int MAX_BIT = 60;
+            static constexpr int TB = (LIM == 4) ? 2 : 4; // product bound (units of q)
+            static constexpr int LIMIT = LIM;              // lazy values stay below LIMIT * q < 2^64
+            static constexpr int MAX_BIT = (LIM == 16) ? 60 : (LIM == 8 ? 61 : 62);
             uint64_t q;
             uint64_t qneg; // 2^64 - q
             NormConst nc;
@@ -124,6 +127,18 @@ namespace gpuntt
             // UNI: the twiddle is wave-uniform (scalar registers).  ZERO: acc = 0.
             template <bool UNI, bool ZERO = false>
             __device__ __forceinline__ uint64_t mul_acc(uint64_t x, const Tw64& t, uint64_t acc) const
+            {
+                if constexpr (LIM == 4)
+                {
+                    // 62-bit moduli: the sloppy product lies in [0, 4q) < 2^64; one correction brings it to [0, 2q)
+                    const uint64_t p = csub<2>(mul_acc_raw<UNI, true>(x, t, 0));
+                    return ZERO ? p : acc + p;
+                }
+                else
+                    return mul_acc_raw<UNI, ZERO>(x, t, acc);
+            }
+            template <bool UNI, bool ZERO>
+            __device__ __forceinline__ uint64_t mul_acc_raw(uint64_t x, const Tw64& t, uint64_t acc) const
             {
                 const uint32_t x0 = lo32(x), x1 = hi32(x);
                 const uint32_t h1 = __umulhi(x1, lo32(t.wp)), h2 = __umulhi(x0, hi32(t.wp));
@@ -161,8 +176,18 @@ namespace gpuntt
             }
         };
 
+        template <> struct Mod<uint64_t, 0> : Mod64<16>
+        {
+        };
+        template <> struct Mod<uint64_t, 8> : Mod64<8>
+        {
+        };
+        template <> struct Mod<uint64_t, 4> : Mod64<4>
+        {
+        };
+
         // ---- 32-bit: exact-quotient Shoup product in [0, 2q); q < 2^30 => LIMIT 4 ------------
-        template <> struct Mod<uint32_t>
+        template <> struct Mod<uint32_t, 0>
         {
             static constexpr int TB = 2;
             static constexpr int LIMIT = 4;
@@ -194,7 +219,7 @@ namespace gpuntt
         };
 
         // [0, B*q) -> [0, q)
-        template <int B, typename T> __device__ __forceinline__ T normalize(const Mod<T>& m, T x)
+        template <int B, typename MM, typename T> __device__ __forceinline__ T normalize(const MM& m, T x)
         {
             if constexpr (sizeof(T) == 8 && B > 4)
                 return m.template csub<1>(m.reduce_2q(x)); // 10 instructions instead of 4 x 4

@@ -228,16 +228,25 @@ namespace gpuntt
         extern template void launch_pass_lazy<uint32_t, true>(const Pass&, int, bool, bool,
                                                               const kern::LazyArgsT<uint32_t>&, hipStream_t);
 
+        template <bool INV, int LIMSEL>
+        void launch_pass_lazy_lim(const Pass& p, bool in_first, bool last, const kern::LazyArgsT<uint64_t>& a,
+                                  hipStream_t stream);
+        extern template void launch_pass_lazy_lim<false, 8>(const Pass&, bool, bool, const kern::LazyArgsT<uint64_t>&, hipStream_t);
+        extern template void launch_pass_lazy_lim<true, 8>(const Pass&, bool, bool, const kern::LazyArgsT<uint64_t>&, hipStream_t);
+        extern template void launch_pass_lazy_lim<false, 4>(const Pass&, bool, bool, const kern::LazyArgsT<uint64_t>&, hipStream_t);
+        extern template void launch_pass_lazy_lim<true, 4>(const Pass&, bool, bool, const kern::LazyArgsT<uint64_t>&, hipStream_t);
+
         // forced_tl: tile size the twiddle table was prepared for (NTTPlan); 0 = choose from the batch
         template <typename T, bool INV>
         inline void run_transform_lazy(kern::LazyArgsT<T> base, unsigned first_in_flags,
                                        unsigned last_out_flags, hipStream_t stream, int forced_tl = 0)
         {
-            const int tl = forced_tl ? forced_tl : lazy_tile_log<T>(base.n, INV, base.total >> base.n);
+            const int tl = base.lim ? 12 : (forced_tl ? forced_tl : lazy_tile_log<T>(base.n, INV, base.total >> base.n));
             const Plan pl = make_plan_tl(base.n, tl, tl == 12 ? lazy_contig_k(base.n) : tl);
             if constexpr (sizeof(T) == 8)
             {
-                if (pl.count == 2 && base.fused_ctl != nullptr && lazy_use_fused<T>(base.n, tl, INV, base.total >> base.n))
+                if (pl.count == 2 && base.fused_ctl != nullptr && !base.lim &&
+                    lazy_use_fused<T>(base.n, tl, INV, base.total >> base.n))
                 {
                     kern::LazyArgsT<T> a = base;
                     a.flags |= first_in_flags | last_out_flags;
@@ -270,7 +279,17 @@ namespace gpuntt
                            (polys << base.n) == base.total)
                               ? static_cast<int>(polys)
                               : 0;
-                launch_pass_lazy<T, INV>(p, tlp, i == 0, i == pl.count - 1, a, stream);
+                if constexpr (sizeof(T) == 8)
+                {
+                    if (base.lim == 8)
+                        launch_pass_lazy_lim<INV, 8>(p, i == 0, i == pl.count - 1, a, stream);
+                    else if (base.lim == 4)
+                        launch_pass_lazy_lim<INV, 4>(p, i == 0, i == pl.count - 1, a, stream);
+                    else
+                        launch_pass_lazy<T, INV>(p, tlp, i == 0, i == pl.count - 1, a, stream);
+                }
+                else
+                    launch_pass_lazy<T, INV>(p, tlp, i == 0, i == pl.count - 1, a, stream);
                 src = base.out;
             }
         }

@@ -7,10 +7,10 @@ namespace gpuntt
 {
     namespace host
     {
-        template <typename T, int TLOG, bool INV, bool CONTIG, int K, int IN_BOUND, bool LAST>
+        template <typename T, int TLOG, bool INV, bool CONTIG, int K, int IN_BOUND, bool LAST, int LIMSEL = 0>
         inline void launch_lazy_one(const kern::LazyArgsT<T>& a, unsigned grid, hipStream_t stream)
         {
-            hipLaunchKernelGGL((kern::merge_pass_lazy<T, TLOG, INV, CONTIG, K, IN_BOUND, LAST>), dim3(grid),
+            hipLaunchKernelGGL((kern::merge_pass_lazy<T, TLOG, INV, CONTIG, K, IN_BOUND, LAST, LIMSEL>), dim3(grid),
                                dim3(kern::LTile<TLOG>::NT), 0, stream, a);
             GPUNTT_HIP_CHECK(hipGetLastError());
         }
@@ -20,11 +20,11 @@ namespace gpuntt
         //   forward, n > TLOG STRIDED K 1..8 (IN 1 | LIMIT, not last) + CONTIG K (IN LIMIT, last)
         //   inverse, n > TLOG CONTIG K (IN 1, not last) + STRIDED K 1..8 (IN LIMIT, last | not last)
         //   with CONTIG K in 8..12 for 4096-coefficient tiles and K = 14 for 16384-coefficient tiles
-        template <typename T, int TLOG, bool INV>
+        template <typename T, int TLOG, bool INV, int LIMSEL = 0>
         void dispatch_tl(const Pass& p, bool in_first, bool last, const kern::LazyArgsT<T>& a,
                          hipStream_t stream)
         {
-            constexpr int LIM = lazy::Mod<T>::LIMIT;
+            constexpr int LIM = lazy::Mod<T, LIMSEL>::LIMIT;
             constexpr int TILE = kern::LTile<TLOG>::TILE;
             const unsigned long long tiles = (a.total + TILE - 1) >> TLOG;
             if (tiles == 0)
@@ -33,7 +33,7 @@ namespace gpuntt
                 throw std::invalid_argument("batch_size * N too large for one launch");
             const unsigned grid = static_cast<unsigned>(tiles);
 #define GPUNTT_ONE(CONTIG_, K_, IN_, LAST_)                                                      \
-    return launch_lazy_one<T, TLOG, INV, CONTIG_, K_, IN_, LAST_>(a, grid, stream)
+    return launch_lazy_one<T, TLOG, INV, CONTIG_, K_, IN_, LAST_, LIMSEL>(a, grid, stream)
             if constexpr (sizeof(T) == 8 && TLOG >= 13)
             {
                 // 64-bit big tiles: contiguous passes over the whole tile only -- the single pass of a
@@ -336,6 +336,14 @@ namespace gpuntt
                 throw std::invalid_argument("internal: unsupported single-sweep plan");
 #undef GPUNTT_FUSED
             GPUNTT_HIP_CHECK(hipGetLastError());
+        }
+
+        // 64-bit words with a 61- / 62-bit modulus: LIMIT = 8 / 4 kernels, 4096-coefficient tiles only
+        template <bool INV, int LIMSEL>
+        void launch_pass_lazy_lim(const Pass& p, bool in_first, bool last, const kern::LazyArgsT<uint64_t>& a,
+                                  hipStream_t stream)
+        {
+            return dispatch_tl<uint64_t, 12, INV, LIMSEL>(p, in_first, last, a, stream);
         }
 
         template <typename T, bool INV>

@@ -1,0 +1,5 @@
+// lazy_u64_inv8.hip -- instantiates the inv fast-path kernels for uint64_t with the LIMIT = 8 lazy range (61-bit moduli).
+#include "lazy_launch_impl.hpp"
+namespace gpuntt { namespace host {
+template void launch_pass_lazy_lim<true, 8>(const Pass&, bool, bool, const kern::LazyArgsT<uint64_t>&, hipStream_t);
+} }

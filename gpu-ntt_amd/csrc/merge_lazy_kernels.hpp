@@ -37,6 +37,7 @@ namespace gpuntt
             const T* mul_in;                 // GPU_PolyMul: canonical operand multiplied into the final forward store, or nullptr
             const lazy::Tw<T>* w_pairs;      // 4-step phase 1: prepared W matrix (N pairs)
             unsigned* fused_ctl;             // single-sweep kernel: zeroed control words (FUSED_CTL_WORDS) or nullptr
+            int lim;                         // 64-bit words: 0, or 8 / 4 = a 61- / 62-bit modulus in the call -> the LIMIT = 8 / 4 kernels (host-side switch)
             int n2_log;                      // 4-step phase 1: log2 n2
             int batch;                       // > 1: polynomials of the call, blocks are ordered poly-minor (4-step phase 1; big-ring passes)
             unsigned long long total;
@@ -280,14 +281,14 @@ namespace gpuntt
         }
 
         template <typename T, int TLOG, bool EXACT, bool INV, bool CONTIG, int K, int IN_BOUND, bool LAST,
-                  int FST = 0, bool WMUL = false, bool COH_IN = false, bool PERSIST = false>
+                  int FST = 0, bool WMUL = false, bool COH_IN = false, bool PERSIST = false, int LIM = 0>
         __device__ __forceinline__ void pass_body(const LazyArgsT<T>& a, T* lds, T q_value, T q_bit, T q_mu,
                                                   int mi, unsigned long long fst_poly = 0,
                                                   unsigned fst_tile = 0, long long blk_override = -1,
                                                   unsigned fst_seg = 0)
         {
             using G = LGeo<TLOG, CONTIG, K>;
-            using M = lazy::Mod<T>;
+            using M = lazy::Mod<T, LIM>;
             using SCH = PassSched<TLOG, INV, CONTIG, K, IN_BOUND, M::LIMIT, M::TB>;
             using TW = lazy::Tw<T>;
             constexpr int TL = TLOG;
@@ -876,11 +877,11 @@ namespace gpuntt
             });
         }
 
-        template <typename T, int TLOG, bool INV, bool CONTIG, int K, int IN_BOUND, bool LAST>
+        template <typename T, int TLOG, bool INV, bool CONTIG, int K, int IN_BOUND, bool LAST, int LIM = 0>
         __global__ __launch_bounds__(LTile<TLOG>::NT, (LOcc<TLOG, T>::WAVES)) void merge_pass_lazy(LazyArgsT<T> a)
         {
             using G = LGeo<TLOG, CONTIG, K>;
-            using M = lazy::Mod<T>;
+            using M = lazy::Mod<T, LIM>;
             using SCH = PassSched<TLOG, INV, CONTIG, K, IN_BOUND, M::LIMIT, M::TB>;
             // single-round passes with coalesced register windows never touch LDS
             constexpr bool NEEDS_LDS = (G::NR > 1) || (SCH::wl_of(0) < 4);
@@ -916,7 +917,8 @@ namespace gpuntt
                 qb = md.bit;
                 qm = md.mu;
             }
-            pass_body<T, TLOG, false, INV, CONTIG, K, IN_BOUND, LAST>(a, lds, qv, qb, qm, mi, 0, 0, blk);
+            pass_body<T, TLOG, false, INV, CONTIG, K, IN_BOUND, LAST, 0, false, false, false, LIM>(a, lds, qv, qb, qm, mi, 0,
+                                                                                                   0, blk);
         }
 
         // ---- single-sweep kernel for rings of 2 .. 64 tiles -----------------------------------

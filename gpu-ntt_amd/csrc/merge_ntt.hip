@@ -106,6 +106,21 @@ namespace gpuntt
                    batch_size >= 2;
         }
 
+        // single-modulus calls and NTTPlan see their moduli on the host: 64-bit words take 61-bit moduli on the
+        // LIMIT = 8 kernels (one range correction per stage) and 62-bit moduli on the LIMIT = 4 kernels (products
+        // corrected to [0, 2q)) -- the whole documented domain of the reference (modular_arith.cuh:66-67)
+        template <typename TU> inline bool fast_modulus(const Modulus<TU>& m)
+        {
+            const TU max_bit = (sizeof(TU) == 8) ? TU(62) : TU(lazy::Mod<TU>::MAX_BIT);
+            return m.value >= 3 && m.bit <= max_bit;
+        }
+        template <typename TU> inline int needs_lim(const Modulus<TU>& m)
+        {
+            if (sizeof(TU) != 8)
+                return 0;
+            return m.bit == TU(62) ? 4 : (m.bit == TU(61) ? 8 : 0);
+        }
+
         // mods == nullptr: single modulus `m`; else device array of mod_count moduli (+ optional
         // device array of n^-1 values whose Shoup pairs are prepared alongside the twiddles)
         template <typename TU>
@@ -117,15 +132,17 @@ namespace gpuntt
         {
             using TW = lazy::Tw<TU>;
             const bool neg = (poly == ReductionPolynomial::X_N_plus);
-            const int tl = host::lazy_tile_log<TU>(n_power, ninv_dev != nullptr || ninv_single != nullptr,
-                                                   static_cast<unsigned long long>(batch_size));
+            const int lim = (mods == nullptr) ? needs_lim<TU>(m) : 0;
+            const int tl = lim ? 12
+                                : host::lazy_tile_log<TU>(n_power, ninv_dev != nullptr || ninv_single != nullptr,
+                                                          static_cast<unsigned long long>(batch_size));
             const int perm_tile_log = (n_power >= tl) ? tl : 0;
             const size_t entries = (static_cast<size_t>(mod_count) << n_power) + mod_count;
             // workspace: twiddle pairs | n^-1 pairs | go-flag | per-modulus normalisation constants |
             // control words of the single-sweep kernel (zeroed by the preparation launch)
             const size_t norm_bytes = (sizeof(lazy::NormConst) * static_cast<size_t>(mod_count) + 15u) & ~size_t(15);
-            const bool fused = host::lazy_use_fused<TU>(n_power, tl, ninv_dev != nullptr || ninv_single != nullptr,
-                                                        static_cast<unsigned long long>(batch_size));
+            const bool fused = !lim && host::lazy_use_fused<TU>(n_power, tl, ninv_dev != nullptr || ninv_single != nullptr,
+                                                                 static_cast<unsigned long long>(batch_size));
             const size_t tail = 16 + norm_bytes + (fused ? sizeof(unsigned) * kern::FUSED_CTL_WORDS : 0);
             auto* ws = static_cast<TW*>(host::lazy_workspace(stream, sizeof(TW) * entries + tail));
             TW* ws_ninv = ws + (static_cast<size_t>(mod_count) << n_power);
@@ -147,6 +164,7 @@ namespace gpuntt
             a.ninv_arr = ninv_dev ? ws_ninv : nullptr;
             a.ninv = TW{0, 0};
             a.go_flag = go_flag;
+            a.lim = lim;
             a.fused_ctl = fused_ctl;
             a.mod_order = mod_order;
             a.poly_order = nullptr;
@@ -255,8 +273,7 @@ namespace gpuntt
             run_percoefficient<TU, false>(a, cfg.n_power, batch_size, in_flags, 0u, cfg.stream);
             return;
         }
-        if (batch_size > 0 && modulus.value >= 3 && modulus.bit <= TU(lazy::Mod<TU>::MAX_BIT) &&
-            lazy_eligible<TU>(cfg.n_power, batch_size, 1))
+        if (batch_size > 0 && fast_modulus<TU>(modulus) && lazy_eligible<TU>(cfg.n_power, batch_size, 1))
         {
             kern::LazyArgsT<TU> la =
                 lazy_args<TU>(device_in, device_out, root_of_unity_table, modulus, nullptr, 1, nullptr,
@@ -292,8 +309,8 @@ namespace gpuntt
             run_percoefficient<TU, true>(a, cfg.n_power, batch_size, 0u, out_flags, cfg.stream);
             return;
         }
-        if (batch_size > 0 && modulus.value >= 3 && modulus.bit <= TU(lazy::Mod<TU>::MAX_BIT) &&
-            lazy_eligible<TU>(cfg.n_power, batch_size, 1) && cfg.mod_inverse < modulus.value)
+        if (batch_size > 0 && fast_modulus<TU>(modulus) && lazy_eligible<TU>(cfg.n_power, batch_size, 1) &&
+            cfg.mod_inverse < modulus.value)
         {
             kern::LazyArgsT<TU> la =
                 lazy_args<TU>(device_in, reinterpret_cast<TU*>(device_out), root_of_unity_table, modulus,
@@ -632,7 +649,7 @@ namespace gpuntt
         const T* table = nullptr;
         std::vector<Modulus<T>> moduli;
         std::vector<T> ninv;
-        int mod_count = 1, n = 0, tile_log = 12;
+        int mod_count = 1, n = 0, tile_log = 12, lim = 0;
         ReductionPolynomial poly = ReductionPolynomial::X_N_minus;
         bool inverse = false, fast = false, owns_ws = false;
         unsigned char* ws = nullptr;
@@ -708,17 +725,20 @@ namespace gpuntt
             p->inverse = inverse;
             if (batch_hint < 1)
                 batch_hint = 1;
-            p->tile_log = host::lazy_tile_log<T>(n_power, inverse, static_cast<unsigned long long>(batch_hint));
             bool fast = lazy_eligible<T>(n_power, batch_hint > 1 ? batch_hint : 2, mod_count);
             for (int i = 0; i < mod_count; i++)
             {
                 const Modulus<T>& m = p->moduli[i];
-                if (m.value < 3 || m.bit > T(lazy::Mod<T>::MAX_BIT))
+                if (!fast_modulus<T>(m))
                     fast = false;
+                const int l = needs_lim<T>(m); // the widest modulus decides the lazy range of the whole stack
+                if (l != 0 && (p->lim == 0 || l < p->lim))
+                    p->lim = l;
                 if (inverse && p->ninv[i] >= m.value)
                     fast = false;
             }
             p->fast = fast;
+            p->tile_log = p->lim ? 12 : host::lazy_tile_log<T>(n_power, inverse, static_cast<unsigned long long>(batch_hint));
             const PlanLayout<T> lay(n_power, mod_count);
             if (workspace_device != nullptr)
                 p->ws = static_cast<unsigned char*>(workspace_device);
@@ -816,6 +836,7 @@ namespace gpuntt
             a.n = p.n;
             a.poly_shift = p.n;
             a.mod_count = p.mod_count;
+            a.lim = p.lim;
             if (p.inverse)
                 host::run_transform_lazy<T, true>(a, in_flags, out_flags, stream, p.tile_log);
             else

@@ -74,7 +74,7 @@ def test_plan_single_modulus(g, bits):
 
 def test_plan_rns_and_wide_moduli(g):
     """RNS plans: 6 primes at 2^16 (config 5's shape) on the fast kernels, and a stack containing a
-    62-bit prime, which the plan classifies at construction and routes to the generic kernels"""
+    62-bit prime, which the plan classifies at construction (LIMIT = 4 kernels for the whole stack)"""
     import torch
     P = O.Port(64)
     logn, batch, mc = 16, 18, 6
@@ -96,7 +96,7 @@ def test_plan_rns_and_wide_moduli(g):
     iplan.execute(d, d, batch)
     torch.cuda.synchronize()
     assert np.array_equal(g.to_host(d), x)
-    # one modulus without lazy headroom -> generic kernels, same results
+    # a 62-bit modulus in the stack -> the whole stack runs on the LIMIT = 4 kernels, same results
     logn = 13
     fl = [find_ntt_factors(58, logn), find_ntt_factors(62, logn), find_ntt_factors(60, logn)]
     cases, fwd, inv, mods, ninv = _rns_setup(g, 64, logn, O.X_N_minus, fl)
@@ -106,7 +106,7 @@ def test_plan_rns_and_wide_moduli(g):
     moduli = [c.prm.modulus for c in cases]
     fplan = g.NTTPlan(fwd, moduli, logn, O.X_N_minus, g.FORWARD)
     iplan = g.NTTPlan(inv, moduli, logn, O.X_N_minus, g.INVERSE, mod_inverse=[c.prm.n_inv for c in cases])
-    assert not fplan.fast_path
+    assert fplan.fast_path and iplan.fast_path
     d = g.to_device(x)
     o = torch.zeros_like(d)
     fplan.execute(d, o, 7)
@@ -358,3 +358,48 @@ def test_largest_rings_sparse_known_answer(g, bits, logn, poly):
     g.GPU_INTT_Inplace(d, inv, prm.modulus, icfg, 1)
     torch.cuda.synchronize()
     assert np.array_equal(g.to_host(d), r)
+
+
+@pytest.mark.parametrize("qbits", [61, 62])
+def test_61_and_62_bit_moduli_on_the_fast_kernels(g, qbits):
+    """61- and 62-bit moduli (the top of the reference's documented domain, modular_arith.cuh:66-67) run on the
+    lazy-residue kernels -- LIMIT = 8 range schedule for 61 bits, LIMIT = 4 with products corrected to [0, 2q) for 62 --
+    instead of dropping to the Barrett kernels: every plan shape, both directions, drop-in calls and NTTPlan (which
+    reports the path), an RNS plan mixing 59/60/61-bit primes"""
+    import torch
+    for logn, batch in ((4, 9), (10, 5), (12, 3), (13, 6), (16, 5), (18, 2), (21, 2)):
+        for poly in (O.X_N_plus, O.X_N_minus):
+            # (skip the primes within 2^-40 of a power of two: the reference's floating-point log2 rounds them up)
+            c = MergeCase(g, 64, logn, poly, find_ntt_factors(qbits, logn, skip=400 if logn < 10 else 0))
+            assert c.prm.modulus.bit == qbits
+            x = c.random(batch, 6100 + logn)
+            want = c.P.merge_ntt(x, c.oprm)
+            assert np.array_equal(c.gpu_forward(x, inplace=bool(logn & 1)), want), ("fwd", logn, poly)
+            assert np.array_equal(c.gpu_inverse(want, inplace=not (logn & 1)), x), ("inv", logn, poly)
+            assert np.array_equal(c.gpu_inverse(x), c.P.merge_ntt(x, c.oprm, inverse=True))
+            fplan = g.NTTPlan(c.fwd_dev, c.prm.modulus, logn, poly, g.FORWARD, batch_hint=batch)
+            assert fplan.fast_path == (logn >= 5)
+            d = g.to_device(x)
+            fplan.execute(d, d, batch)
+            torch.cuda.synchronize()
+            assert np.array_equal(g.to_host(d), want)
+    if qbits == 62:
+        return
+    # RNS plan with one 61-bit prime in the stack
+    logn, batch = 14, 9
+    fl = [find_ntt_factors(59, logn), find_ntt_factors(61, logn), find_ntt_factors(60, logn)]
+    cases, fwd, inv, mods, ninv = _rns_setup(g, 64, logn, O.X_N_plus, fl)
+    n = 1 << logn
+    x = np.concatenate([cases[p % 3].P.splitmix(6600 + p, 0, n, cases[p % 3].q) for p in range(batch)])
+    want = np.concatenate([cases[p % 3].P.merge_ntt(x[p * n:(p + 1) * n], cases[p % 3].oprm) for p in range(batch)])
+    moduli = [c.prm.modulus for c in cases]
+    fplan = g.NTTPlan(fwd, moduli, logn, O.X_N_plus, g.FORWARD, batch_hint=batch)
+    iplan = g.NTTPlan(inv, moduli, logn, O.X_N_plus, g.INVERSE, mod_inverse=[c.prm.n_inv for c in cases], batch_hint=batch)
+    assert fplan.fast_path and iplan.fast_path
+    d = g.to_device(x)
+    fplan.execute(d, d, batch)
+    torch.cuda.synchronize()
+    assert np.array_equal(g.to_host(d), want)
+    iplan.execute(d, d, batch)
+    torch.cuda.synchronize()
+    assert np.array_equal(g.to_host(d), x)
