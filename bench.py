@@ -272,10 +272,18 @@ def build_case(g, cfg, rank, world, dev, api, inplace=True):
         ci = g.ntt4step_configuration(n_power=logn, ntt_type=g.INVERSE, mod_inverse=p4.n_inv)
         d_back = torch.empty_like(d_in)
 
-        def step():
+        def dropin_step():
             g.GPU_4STEP_NTT(d_in, d_mid, *tf, p4.modulus, cf, batch)
             g.GPU_4STEP_NTT(d_mid, d_back, *ti, p4.modulus, ci, batch)
-        case.update(step=step, x=base, d_in=d_in, d_out=d_mid, table=tf[2], modulus=p4.modulus.value,
+
+        def plan_step():
+            if "plan" not in case:
+                case["plan"] = (g.FourStepPlan(*tf, p4.modulus, cf, batch_hint=batch),
+                                g.FourStepPlan(*ti, p4.modulus, ci, batch_hint=batch))
+            case["plan"][0].execute(d_in, d_mid, batch)
+            case["plan"][1].execute(d_mid, d_back, batch)
+        step, other_step = (plan_step, dropin_step) if api == "plan" else (dropin_step, plan_step)
+        case.update(step=step, x=base, other_step=lambda: other_step, d_in=d_in, d_out=d_mid, table=tf[2], modulus=p4.modulus.value,
                     transforms_per_step=2 * batch, p4=p4, natural=(tf, cf), run_shard=None)
     return case
 
@@ -312,8 +320,6 @@ def main():
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)  # PMC child pass: calls only
     args = ap.parse_args()
     cfg = dict(CONFIGS[args.config], name=args.config)
-    if cfg["kind"] == "4step" and args.api == "plan":
-        raise SystemExit("the 4-step entry points have no plan form")
     if args.config == "c3" and args.steps == 200:
         args.steps, args.warmup = 10, 2  # a step is ~25 ms and 16 GiB of traffic
 

@@ -88,7 +88,8 @@ EXPORTED_SYMBOLS = ["gpuntt_last_error", "gpuntt_version"] + [
               "ntt_poly_ordered", "polymul", "polymul_rns", "4step", "4step_rns", "4step_natural", "transpose",
               "merge_params",
               "4step_params", "plan_workspace_bytes", "plan_create", "plan_execute", "plan_fast_path",
-              "plan_destroy", "operator_gpu")
+              "plan_destroy", "operator_gpu", "4step_plan_workspace_bytes", "4step_plan_create",
+              "4step_plan_execute", "4step_plan_fast_path", "4step_plan_destroy")
     for s in ("u32", "u64")] + ["gpuntt_release_workspaces"]
 
 
@@ -462,6 +463,54 @@ class NTTPlan:
     def close(self):
         if self._h:
             getattr(load_library(), "gpuntt_plan_destroy_u%d" % self.bits)(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class FourStepPlan:
+    """Extension FourStepPlan<T> (include/gpuntt/ntt_4step/ntt_4step.cuh): the Shoup pairs of the n1 / n2 / W
+    tables are prepared once; execute() launches the sweeps only.  natural_order False: execute ==
+    GPU_4STEP_NTT (n2 x n1 in, n1 x n2 out); True: == GPU_4STEP_NTT_NaturalOrder (device_in is scratch).
+    `cfg` is an ntt4step_configuration (n_power, ntt_type, mod_inverse, stream of the preparation);
+    `workspace` an optional uint8 device tensor of workspace_bytes() bytes owned by the caller."""
+
+    def __init__(self, n1_root_of_unity_table, n2_root_of_unity_table, W_root_of_unity_table, modulus, cfg,
+                 natural_order=False, batch_hint=1, workspace=None):
+        lib = load_library()
+        _require_gpu(n1_root_of_unity_table, n2_root_of_unity_table, W_root_of_unity_table)
+        self.bits = modulus.bits
+        self.n_power, self.ntt_type, self.natural_order = cfg.n_power, cfg.ntt_type, bool(natural_order)
+        self._keep = (n1_root_of_unity_table, n2_root_of_unity_table, W_root_of_unity_table, workspace)
+        self._h = ctypes.c_void_p()
+        fn = getattr(lib, "gpuntt_4step_plan_create_u%d" % self.bits)
+        _check(fn(ctypes.byref(self._h), _ptr(n1_root_of_unity_table), _ptr(n2_root_of_unity_table),
+                  _ptr(W_root_of_unity_table), modulus.c(), cfg.n_power, cfg.ntt_type,
+                  _ct(self.bits)(cfg.mod_inverse), int(self.natural_order), int(batch_hint), _ptr(workspace),
+                  _stream(cfg.stream)))
+
+    @staticmethod
+    def workspace_bytes(n_power, bits=64):
+        out = ctypes.c_uint64()
+        _check(getattr(load_library(), "gpuntt_4step_plan_workspace_bytes_u%d" % bits)(n_power, ctypes.byref(out)))
+        return int(out.value)
+
+    @property
+    def fast_path(self):
+        return bool(getattr(load_library(), "gpuntt_4step_plan_fast_path_u%d" % self.bits)(self._h))
+
+    def execute(self, device_in, device_out, batch_size, stream=None):
+        _require_gpu(device_in, device_out)
+        fn = getattr(load_library(), "gpuntt_4step_plan_execute_u%d" % self.bits)
+        _check(fn(self._h, _ptr(device_in), _ptr(device_out), int(batch_size), _stream(stream)))
+
+    def close(self):
+        if self._h:
+            getattr(load_library(), "gpuntt_4step_plan_destroy_u%d" % self.bits)(self._h)
             self._h = ctypes.c_void_p()
 
     def __del__(self):

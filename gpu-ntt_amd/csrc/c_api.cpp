@@ -555,6 +555,43 @@ extern "C"
     {                                                                                             \
         return guarded([&] { delete reinterpret_cast<NTTPlan<T>*>(plan); });                      \
     }                                                                                             \
+    int gpuntt_4step_plan_workspace_bytes_##S(int n_power, uint64_t* bytes_host)                  \
+    {                                                                                             \
+        GPUNTT_NEED(bytes_host)                                                                   \
+        return guarded([&] { *bytes_host = FourStepPlan<T>::workspace_bytes(n_power); });          \
+    }                                                                                             \
+    int gpuntt_4step_plan_create_##S(gpuntt_4step_plan** plan_host, const T* n1_table,            \
+                                     const T* n2_table, const T* w_table, CM modulus, int n_power, \
+                                     int ntt_type, T mod_inverse, int natural_order,              \
+                                     int batch_hint, void* workspace_device, void* stream)        \
+    {                                                                                             \
+        GPUNTT_NEED(plan_host, n1_table, n2_table, w_table)                                       \
+        return guarded([&] {                                                                      \
+            ntt4step_configuration<T> cfg = {n_power, static_cast<type>(ntt_type), mod_inverse,   \
+                                             static_cast<hipStream_t>(stream)};                   \
+            *plan_host = reinterpret_cast<gpuntt_4step_plan*>(new FourStepPlan<T>(                \
+                const_cast<T*>(n1_table), const_cast<T*>(n2_table), const_cast<T*>(w_table),      \
+                to_mod<T>(modulus), cfg, natural_order != 0, batch_hint, workspace_device));      \
+        });                                                                                       \
+    }                                                                                             \
+    int gpuntt_4step_plan_execute_##S(const gpuntt_4step_plan* plan, T* in, T* out,               \
+                                      int batch_size, void* stream)                               \
+    {                                                                                             \
+        GPUNTT_NEED(plan, in, out)                                                                \
+        return guarded([&] {                                                                      \
+            reinterpret_cast<const FourStepPlan<T>*>(plan)->execute(in, out, batch_size,          \
+                                                                    static_cast<hipStream_t>(stream)); \
+        });                                                                                       \
+    }                                                                                             \
+    int gpuntt_4step_plan_fast_path_##S(const gpuntt_4step_plan* plan)                            \
+    {                                                                                             \
+        GPUNTT_NEED(plan)                                                                         \
+        return reinterpret_cast<const FourStepPlan<T>*>(plan)->fast_path() ? 1 : 0;               \
+    }                                                                                             \
+    int gpuntt_4step_plan_destroy_##S(gpuntt_4step_plan* plan)                                    \
+    {                                                                                             \
+        return guarded([&] { delete reinterpret_cast<FourStepPlan<T>*>(plan); });                 \
+    }                                                                                             \
     int gpuntt_operator_gpu_##S(int op, const T* a, const T* b, T* out, CM modulus,               \
                                 uint64_t count, void* stream)                                     \
     {                                                                                             \

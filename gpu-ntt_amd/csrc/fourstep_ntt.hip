@@ -147,6 +147,21 @@ namespace gpuntt
             host::run_transform<T, INV>(b, 0u, INV ? kern::F_SCALE : 0u, stream);
         }
 
+        // FourStepPlan splits the fast paths below into their two halves: PLAN_PREPARE runs the table
+        // preparation into the plan's buffer and returns, PLAN_EXECUTE skips it and launches the sweeps
+        enum PlanMode
+        {
+            PLAN_NONE = 0,
+            PLAN_PREPARE = 1,
+            PLAN_EXECUTE = 2
+        };
+        template <typename T> struct PlanUse
+        {
+            PlanMode mode = PLAN_NONE;
+            lazy::Tw<T>* ws = nullptr;
+            int tile_log = 0; // row-pass tile the n2 table was laid out for (reference-layout plans)
+        };
+
         // fast path: single modulus with lazy headroom.  Workspace layout (Shoup pairs):
         //   [0, n1)  n1 table by stage | [n1, n1 + N)  W matrix | [.., + n2)  n2 table by stage
         // mods_dev != nullptr: the RNS overload with ONE modulus (how the reference's own example calls
@@ -158,9 +173,12 @@ namespace gpuntt
         bool fourstep_run_lazy(T* in, T* out, const T* n1_table, const T* n2_table, const T* w_table,
                                const Modulus<T>& mod, T ninv, int n_power, int log_n1, int log_n2,
                                int batch_size, hipStream_t stream, const Modulus<T>* mods_dev = nullptr,
-                               const T* ninv_dev = nullptr, const unsigned** go_flag_out = nullptr)
+                               const T* ninv_dev = nullptr, const unsigned** go_flag_out = nullptr,
+                               const PlanUse<T>& plan = PlanUse<T>())
         {
             using TW = lazy::Tw<T>;
+            if (plan.mode != PLAN_NONE && mods_dev != nullptr)
+                return false;
             if (mods_dev == nullptr &&
                 (mod.bit > T(lazy::Mod<T>::MAX_BIT) || mod.value < 3 || (INV && ninv >= mod.value)))
                 return false;
@@ -172,8 +190,10 @@ namespace gpuntt
             const size_t n1 = size_t(1) << log_n1, n2 = size_t(1) << log_n2, n = size_t(1) << n_power;
             // pairs: n1 table | W | n2 table | n^-1 ; then go-flag (16 B) and the normalisation constants
             const size_t pairs = n1 + n + n2 + 2;
-            auto* ws = static_cast<TW*>(
-                host::lazy_workspace(stream, sizeof(TW) * pairs + 16 + sizeof(lazy::NormConst)));
+            auto* ws = plan.mode != PLAN_NONE
+                           ? plan.ws
+                           : static_cast<TW*>(
+                                 host::lazy_workspace(stream, sizeof(TW) * pairs + 16 + sizeof(lazy::NormConst)));
             TW* ws_n1 = ws;
             TW* ws_w = ws + n1;
             TW* ws_n2 = ws + n1 + n;
@@ -181,13 +201,19 @@ namespace gpuntt
             unsigned char* tail = reinterpret_cast<unsigned char*>(ws + pairs);
             unsigned* go_flag = mods_dev ? reinterpret_cast<unsigned*>(tail) : nullptr;
             auto* norm_arr = mods_dev ? reinterpret_cast<lazy::NormConst*>(tail + 16) : nullptr;
-            const int tl2 = host::lazy_tile_log<T>(log_n2, INV, static_cast<unsigned long long>(batch_size) << log_n1);
+            const int tl2 = plan.mode != PLAN_NONE
+                                ? plan.tile_log
+                                : host::lazy_tile_log<T>(log_n2, INV, static_cast<unsigned long long>(batch_size) << log_n1);
             // one preparation launch; inverse: n^-1 rides on the last row stage (fold = 2)
-            host::launch_prep_fourstep<T>(n1_table, n2_table, w_table, ws_n1, ws_w, ws_n2, log_n1, log_n2,
-                                          (log_n2 >= tl2) ? tl2 : 0, false, INV ? 2 : 0, mod.value, ninv, mods_dev,
-                                          (INV && mods_dev) ? ninv_dev : nullptr, ws_ninv, go_flag, norm_arr, stream);
+            if (plan.mode != PLAN_EXECUTE)
+                host::launch_prep_fourstep<T>(n1_table, n2_table, w_table, ws_n1, ws_w, ws_n2, log_n1, log_n2,
+                                              (log_n2 >= tl2) ? tl2 : 0, false, INV ? 2 : 0, mod.value, ninv, mods_dev,
+                                              (INV && mods_dev) ? ninv_dev : nullptr, ws_ninv, go_flag, norm_arr,
+                                              stream);
             if (go_flag_out != nullptr)
                 *go_flag_out = go_flag;
+            if (plan.mode == PLAN_PREPARE)
+                return true;
 
             kern::LazyArgsT<T> a{};
             a.in = in;
@@ -224,7 +250,7 @@ namespace gpuntt
                 b.ninv = TW{ninv, host::shoup_host(ninv, mod.value)};
             if (INV && mods_dev != nullptr)
                 b.ninv_arr = ws_ninv;
-            host::run_transform_lazy<T, INV>(b, 0u, 0u, stream);
+            host::run_transform_lazy<T, INV>(b, 0u, 0u, stream, plan.mode != PLAN_NONE ? tl2 : 0);
             return true;
         }
 
@@ -238,7 +264,8 @@ namespace gpuntt
         template <typename T>
         bool fourstep_natural_forward_lazy(T* in, T* out, const T* n1_table, const T* n2_table,
                                            const T* w_table, const Modulus<T>& mod, int n_power, int log_n1,
-                                           int log_n2, int batch_size, hipStream_t stream)
+                                           int log_n2, int batch_size, hipStream_t stream,
+                                           const PlanUse<T>& plan = PlanUse<T>())
         {
             using TW = lazy::Tw<T>;
             if (mod.bit > T(lazy::Mod<T>::MAX_BIT) || mod.value < 3)
@@ -247,13 +274,18 @@ namespace gpuntt
                 if (std::strcmp(e, "generic") == 0)
                     return false;
             const size_t n1 = size_t(1) << log_n1, n2 = size_t(1) << log_n2, n = size_t(1) << n_power;
-            auto* ws = static_cast<TW*>(host::lazy_workspace(stream, sizeof(TW) * (n1 + n + n2 + 2)));
+            auto* ws = plan.mode != PLAN_NONE
+                           ? plan.ws
+                           : static_cast<TW*>(host::lazy_workspace(stream, sizeof(TW) * (n1 + n + n2 + 2)));
             TW* ws_n1 = ws;
             TW* ws_w = ws + n1;
             TW* ws_n2 = ws + n1 + n;
             // plain stage layout of the n2 table (no per-tile permutation: the last pass works on row runs)
-            host::launch_prep_fourstep<T>(n1_table, n2_table, w_table, ws_n1, ws_w, ws_n2, log_n1, log_n2, 0, false, 0,
-                                          mod.value, T(0), nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+            if (plan.mode != PLAN_EXECUTE)
+                host::launch_prep_fourstep<T>(n1_table, n2_table, w_table, ws_n1, ws_w, ws_n2, log_n1, log_n2, 0, false,
+                                              0, mod.value, T(0), nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+            if (plan.mode == PLAN_PREPARE)
+                return true;
 
             kern::LazyArgsT<T> a{};
             a.in = in;
@@ -318,7 +350,8 @@ namespace gpuntt
         template <typename T>
         bool fourstep_natural_inverse_lazy(T* in, T* out, const T* n1_table, const T* n2_table,
                                            const T* w_table, const Modulus<T>& mod, T ninv, int n_power,
-                                           int log_n1, int log_n2, int batch_size, hipStream_t stream)
+                                           int log_n1, int log_n2, int batch_size, hipStream_t stream,
+                                           const PlanUse<T>& plan = PlanUse<T>())
         {
             using TW = lazy::Tw<T>;
             if (mod.bit > T(lazy::Mod<T>::MAX_BIT) || mod.value < 3 || ninv >= mod.value)
@@ -327,13 +360,18 @@ namespace gpuntt
                 if (std::strcmp(e, "generic") == 0)
                     return false;
             const size_t n1 = size_t(1) << log_n1, n2 = size_t(1) << log_n2, n = size_t(1) << n_power;
-            auto* ws = static_cast<TW*>(host::lazy_workspace(stream, sizeof(TW) * (n1 + n + n2 + 2)));
+            auto* ws = plan.mode != PLAN_NONE
+                           ? plan.ws
+                           : static_cast<TW*>(host::lazy_workspace(stream, sizeof(TW) * (n1 + n + n2 + 2)));
             TW* ws_n1 = ws;
             TW* ws_w = ws + n1;
             TW* ws_n2 = ws + n1 + n;
             // N^-1 rides on the very last stage (fold = 1: the n1 table); W re-indexed (w_brev)
-            host::launch_prep_fourstep<T>(n1_table, n2_table, w_table, ws_n1, ws_w, ws_n2, log_n1, log_n2, 0, true, 1,
-                                          mod.value, ninv, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+            if (plan.mode != PLAN_EXECUTE)
+                host::launch_prep_fourstep<T>(n1_table, n2_table, w_table, ws_n1, ws_w, ws_n2, log_n1, log_n2, 0, true,
+                                              1, mod.value, ninv, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+            if (plan.mode == PLAN_PREPARE)
+                return true;
 
             kern::LazyArgsT<T> a{};
             a.in = in;
@@ -513,6 +551,147 @@ namespace gpuntt
                              cfg.ntt_type, batch_size, cfg.stream);
         transpose_on<T>(device_in, device_out, n1, n2, cfg.n_power, batch_size, cfg.stream);
     }
+
+    // ------------------------------------------------------------------ FourStepPlan ----
+    template <typename T> struct FourStepPlan<T>::Impl
+    {
+        T *n1_table = nullptr, *n2_table = nullptr, *w_table = nullptr;
+        Modulus<T> mod{};
+        T ninv = 0;
+        int n = 0, l1 = 0, l2 = 0;
+        bool inverse = false, natural = false, fast = false, owns_ws = false;
+        PlanUse<T> use{};
+    };
+
+    template <typename T> size_t FourStepPlan<T>::workspace_bytes(int n_power)
+    {
+        int l1 = 0, l2 = 0;
+        if (!fourstep_shape(n_power, l1, l2))
+            throw std::invalid_argument("Invalid n_power range!");
+        return sizeof(lazy::Tw<T>) * ((size_t(1) << l1) + (size_t(1) << n_power) + (size_t(1) << l2) + 2);
+    }
+
+    template <typename T>
+    FourStepPlan<T>::FourStepPlan(Root<T>* n1_root_of_unity_table, Root<T>* n2_root_of_unity_table,
+                                  Root<T>* W_root_of_unity_table, Modulus<T> modulus, ntt4step_configuration<T> cfg,
+                                  bool natural_order, int batch_hint, void* workspace_device)
+        : p_(nullptr)
+    {
+        int l1 = 0, l2 = 0;
+        if (!fourstep_shape(cfg.n_power, l1, l2))
+            throw std::invalid_argument("Invalid n_power range!");
+        if (cfg.ntt_type != FORWARD && cfg.ntt_type != INVERSE)
+            throw std::invalid_argument("Invalid ntt_type!");
+        if (n1_root_of_unity_table == nullptr || n2_root_of_unity_table == nullptr || W_root_of_unity_table == nullptr)
+            throw std::invalid_argument("null pointer argument");
+        if (batch_hint < 1)
+            batch_hint = 1;
+        Impl* p = new Impl();
+        p_ = p;
+        try
+        {
+            p->n1_table = n1_root_of_unity_table;
+            p->n2_table = n2_root_of_unity_table;
+            p->w_table = W_root_of_unity_table;
+            p->mod = modulus;
+            p->ninv = cfg.mod_inverse;
+            p->n = cfg.n_power;
+            p->l1 = l1;
+            p->l2 = l2;
+            p->inverse = (cfg.ntt_type == INVERSE);
+            p->natural = natural_order;
+            if (workspace_device != nullptr)
+                p->use.ws = static_cast<lazy::Tw<T>*>(workspace_device);
+            else
+            {
+                void* mem = nullptr;
+                GPUNTT_HIP_CHECK(hipMalloc(&mem, workspace_bytes(cfg.n_power)));
+                p->use.ws = static_cast<lazy::Tw<T>*>(mem);
+                p->owns_ws = true;
+            }
+            p->use.mode = PLAN_PREPARE;
+            p->use.tile_log =
+                host::lazy_tile_log<T>(l2, p->inverse, static_cast<unsigned long long>(batch_hint) << l1);
+            // the eligibility checks of the fast paths decide (modulus width, n^-1 canonical, GPUNTT_PATH)
+            if (natural_order)
+                p->fast = p->inverse ? fourstep_natural_inverse_lazy<T>(nullptr, nullptr, p->n1_table, p->n2_table,
+                                                                        p->w_table, p->mod, p->ninv, p->n, l1, l2, 1,
+                                                                        cfg.stream, p->use)
+                                     : fourstep_natural_forward_lazy<T>(nullptr, nullptr, p->n1_table, p->n2_table,
+                                                                        p->w_table, p->mod, p->n, l1, l2, 1, cfg.stream,
+                                                                        p->use);
+            else
+                p->fast = p->inverse ? fourstep_run_lazy<T, true>(nullptr, nullptr, p->n1_table, p->n2_table, p->w_table,
+                                                                  p->mod, p->ninv, p->n, l1, l2, 1, cfg.stream, nullptr,
+                                                                  nullptr, nullptr, p->use)
+                                     : fourstep_run_lazy<T, false>(nullptr, nullptr, p->n1_table, p->n2_table,
+                                                                   p->w_table, p->mod, p->ninv, p->n, l1, l2, 1,
+                                                                   cfg.stream, nullptr, nullptr, nullptr, p->use);
+            p->use.mode = PLAN_EXECUTE;
+        }
+        catch (...)
+        {
+            if (p->owns_ws && p->use.ws != nullptr)
+                (void) hipFree(p->use.ws);
+            delete p;
+            p_ = nullptr;
+            throw;
+        }
+    }
+
+    template <typename T> FourStepPlan<T>::~FourStepPlan()
+    {
+        if (p_ != nullptr)
+        {
+            if (p_->owns_ws && p_->use.ws != nullptr)
+                (void) hipFree(p_->use.ws);
+            delete p_;
+        }
+    }
+
+    template <typename T> bool FourStepPlan<T>::fast_path() const { return p_->fast; }
+
+    template <typename T>
+    void FourStepPlan<T>::execute(T* device_in, T* device_out, int batch_size, stream_t stream) const
+    {
+        const Impl& p = *p_;
+        if (batch_size <= 0)
+            return;
+        if (device_in == nullptr || device_out == nullptr)
+            throw std::invalid_argument("null pointer argument");
+        if (device_in == device_out)
+            throw std::invalid_argument("FourStepPlan::execute needs distinct buffers");
+        if ((static_cast<unsigned long long>(batch_size) << p.n) >> kern::TL > 0x7fffffffull)
+            throw std::invalid_argument("batch_size * N too large for one launch");
+        if (!p.fast)
+        {
+            ntt4step_configuration<T> cfg = {p.n, p.inverse ? INVERSE : FORWARD, p.ninv, stream};
+            if (p.natural)
+                GPU_4STEP_NTT_NaturalOrder<T>(device_in, device_out, p.n1_table, p.n2_table, p.w_table, p.mod, cfg,
+                                              batch_size);
+            else
+                GPU_4STEP_NTT<T>(device_in, device_out, p.n1_table, p.n2_table, p.w_table, p.mod, cfg, batch_size);
+            return;
+        }
+        bool ok;
+        if (p.natural)
+            ok = p.inverse ? fourstep_natural_inverse_lazy<T>(device_in, device_out, nullptr, nullptr, nullptr, p.mod,
+                                                              p.ninv, p.n, p.l1, p.l2, batch_size, stream, p.use)
+                           : fourstep_natural_forward_lazy<T>(device_in, device_out, nullptr, nullptr, nullptr, p.mod,
+                                                              p.n, p.l1, p.l2, batch_size, stream, p.use);
+        else
+            ok = p.inverse ? fourstep_run_lazy<T, true>(device_in, device_out, nullptr, nullptr, nullptr, p.mod, p.ninv,
+                                                        p.n, p.l1, p.l2, batch_size, stream, nullptr, nullptr, nullptr,
+                                                        p.use)
+                           : fourstep_run_lazy<T, false>(device_in, device_out, nullptr, nullptr, nullptr, p.mod, p.ninv,
+                                                         p.n, p.l1, p.l2, batch_size, stream, nullptr, nullptr, nullptr,
+                                                         p.use);
+        if (!ok)
+            throw std::runtime_error("FourStepPlan: prepared path refused (GPUNTT_PATH changed since creation?)");
+    }
+
+    template class FourStepPlan<Data32>;
+    template class FourStepPlan<Data64>;
 
     template __host__ void GPU_4STEP_NTT_NaturalOrder<Data32>(Data32*, Data32*, Root<Data32>*, Root<Data32>*,
                                                               Root<Data32>*, Modulus<Data32>,

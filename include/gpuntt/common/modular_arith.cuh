@@ -9,6 +9,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdint>
 #include <type_traits>
 
@@ -37,8 +38,11 @@ namespace gpuntt_detail
 } // namespace gpuntt_detail
 
 // Layout contract (reference :28-57): three T words {value, bit, mu};
-// bit = floor(log2 q) + 1, mu = floor(2^(2*bit+1) / q).  `bit` is computed with integer
-// arithmetic (the reference's double log2 agrees for every supported modulus).
+// bit = (T)(log2((double) q) + 1), mu = floor(2^(2*bit+1) / q).  `bit` is evaluated in double exactly as
+// the reference does (:44-47): a modulus q >= 2^53 within rounding distance below a power of two (2^60 - 107,
+// say) converts to that power of two and gets bit = 61, not its exact length 60.  Every kernel family accepts
+// the over-stated width (Barrett shifts, lazy ranges and path selection all key on `bit`), and a caller that
+// compares or serialises the three words sees the reference's values.
 template <typename T1> struct Modulus
 {
     T1 value;
@@ -48,9 +52,13 @@ template <typename T1> struct Modulus
     __host__ Modulus(T1 mod) : value(mod), bit(0), mu(0)
     {
         using T2 = typename gpuntt_detail::wide<T1>::type;
-        bit = static_cast<T1>(gpuntt_detail::bit_length(mod));
         if (mod != 0)
-            mu = static_cast<T1>((static_cast<T2>(1) << (2 * bit + 1)) / mod);
+        {
+            bit = static_cast<T1>(std::log2(static_cast<double>(mod)) + 1);
+            const unsigned sh = static_cast<unsigned>(2 * bit + 1);
+            if (sh < sizeof(T2) * 8) // (the reference shifts past the word for bit = 64: undefined; mu stays 0 here)
+                mu = static_cast<T1>((static_cast<T2>(1) << sh) / mod);
+        }
     }
     __host__ __device__ Modulus() : value(0), bit(0), mu(0) {}
 };

@@ -70,4 +70,34 @@ namespace gpuntt
                                              Modulus<T> modulus, ntt4step_configuration<T> cfg,
                                              int batch_size);
 
+    // Prepared 4-step transform (extension; the 4-step counterpart of NTTPlan<T>, ntt_merge/ntt.cuh).
+    // GPU_4STEP_NTT re-derives, on every call, the Shoup pairs of the caller's n1 / n2 / W tables into a
+    // library-owned scratch buffer -- at 2^24 that is 128 MiB read and 256 MiB written before the first
+    // sweep, most of a batch-1 call.  A plan does it once, into memory the caller owns (or the plan
+    // allocates), and execute() launches the sweeps only: no allocation, no synchronisation, no
+    // preparation launch, hipGraph-capturable from the first call.
+    //   natural_order false: execute() == GPU_4STEP_NTT (n2 x n1 in, n1 x n2 out, in != out);
+    //   natural_order true:  execute() == GPU_4STEP_NTT_NaturalOrder (device_in is scratch).
+    // cfg.stream is the stream the preparation runs on; execute() takes its own.  batch_hint: the batch
+    // size the plan will mostly run (decides the row-pass tile the n2 table is laid out for; any batch
+    // size is correct).  The caller's tables must stay alive when fast_path() is false (moduli without
+    // lazy headroom run GPU_4STEP_NTT / _NaturalOrder on them).
+    template <typename T> class FourStepPlan
+    {
+      public:
+        static size_t workspace_bytes(int n_power);
+        FourStepPlan(Root<T>* n1_root_of_unity_table, Root<T>* n2_root_of_unity_table,
+                     Root<T>* W_root_of_unity_table, Modulus<T> modulus, ntt4step_configuration<T> cfg,
+                     bool natural_order, int batch_hint, void* workspace_device = nullptr);
+        ~FourStepPlan();
+        FourStepPlan(const FourStepPlan&) = delete;
+        FourStepPlan& operator=(const FourStepPlan&) = delete;
+        void execute(T* device_in, T* device_out, int batch_size, stream_t stream) const;
+        bool fast_path() const;
+
+      private:
+        struct Impl;
+        Impl* p_;
+    };
+
 } // namespace gpuntt

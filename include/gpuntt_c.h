@@ -223,6 +223,31 @@ extern "C"
     int gpuntt_plan_destroy_u32(gpuntt_plan* plan);
     int gpuntt_plan_destroy_u64(gpuntt_plan* plan);
 
+    /* ---- extension: prepared 4-step transforms (FourStepPlan<T>, include/gpuntt/ntt_4step/ntt_4step.cuh) ----
+     * The Shoup pairs of the n1 / n2 / W tables are derived once, at creation, into workspace_device
+     * (gpuntt_4step_plan_workspace_bytes_*() bytes owned by the caller) or a buffer the plan allocates (NULL).
+     * natural_order 0: execute == gpuntt_4step_* (n2 x n1 in, n1 x n2 out); 1: == gpuntt_4step_natural_* (`in` is
+     * scratch).  in != out.  Creation runs on `stream`; execute allocates nothing and never synchronises. */
+    typedef struct gpuntt_4step_plan gpuntt_4step_plan;
+    int gpuntt_4step_plan_workspace_bytes_u32(int n_power, uint64_t* bytes_host);
+    int gpuntt_4step_plan_workspace_bytes_u64(int n_power, uint64_t* bytes_host);
+    int gpuntt_4step_plan_create_u32(gpuntt_4step_plan** plan_host, const uint32_t* n1_table, const uint32_t* n2_table,
+                                     const uint32_t* w_table, gpuntt_modulus32 modulus, int n_power, int ntt_type,
+                                     uint32_t mod_inverse, int natural_order, int batch_hint, void* workspace_device,
+                                     void* stream);
+    int gpuntt_4step_plan_create_u64(gpuntt_4step_plan** plan_host, const uint64_t* n1_table, const uint64_t* n2_table,
+                                     const uint64_t* w_table, gpuntt_modulus64 modulus, int n_power, int ntt_type,
+                                     uint64_t mod_inverse, int natural_order, int batch_hint, void* workspace_device,
+                                     void* stream);
+    int gpuntt_4step_plan_execute_u32(const gpuntt_4step_plan* plan, uint32_t* in, uint32_t* out, int batch_size,
+                                      void* stream);
+    int gpuntt_4step_plan_execute_u64(const gpuntt_4step_plan* plan, uint64_t* in, uint64_t* out, int batch_size,
+                                      void* stream);
+    int gpuntt_4step_plan_fast_path_u32(const gpuntt_4step_plan* plan); /* 1 / 0, negative on error */
+    int gpuntt_4step_plan_fast_path_u64(const gpuntt_4step_plan* plan);
+    int gpuntt_4step_plan_destroy_u32(gpuntt_4step_plan* plan);
+    int gpuntt_4step_plan_destroy_u64(gpuntt_4step_plan* plan);
+
     /* frees the library-owned scratch buffers of the drop-in entry points (synchronises the device) */
     int gpuntt_release_workspaces(void);
 

@@ -101,6 +101,8 @@ def find_ntt_factors(bits, logn, skip=0):
     q = ((1 << bits) - 1) // step * step + 1
     found = 0
     while True:
+        if q.bit_length() < bits:
+            raise ValueError("no %d-bit prime = 1 mod 2^%d left (skip=%d)" % (bits, logn + 1, skip))
         if q.bit_length() == bits and _is_probable_prime(q):
             if found == skip:
                 break

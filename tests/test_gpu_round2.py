@@ -239,11 +239,12 @@ def test_operator_gpu_device_class(g, bits):
     T = np.uint32 if bits == 32 else np.uint64
     widths = (2, 3, 14, 20, 29, 30) if bits == 32 else (2, 3, 20, 31, 32, 33, 50, 59, 60, 61, 62)
     for wbits in widths:
-        q = (1 << wbits) - 1
-        while q % 2 == 0 or q < 3:
-            q -= 1
+        # widest odd value of that width; from 50 bits on, one that the reference's double log2 does not round up to
+        # the next width (2^61 - 1 would get bit = 62 and a mu past the word: outside the reference's own domain)
+        q = (1 << wbits) - 1 if wbits < 50 else (1 << wbits) - (1 << (wbits - 30)) - 1
         if wbits == 2:
             q = 3
+        assert q % 2 == 1 and q.bit_length() == wbits
         m = g.Modulus(q, bits=bits)
         cnt = 4096
         a = rng.integers(0, q, size=cnt, dtype=np.uint64).astype(T)
@@ -403,3 +404,196 @@ def test_61_and_62_bit_moduli_on_the_fast_kernels(g, qbits):
     iplan.execute(d, d, batch)
     torch.cuda.synchronize()
     assert np.array_equal(g.to_host(d), x)
+
+
+# ------------------------------------------------------------------ FourStepPlan (prepared 4-step transforms)
+@pytest.mark.parametrize("bits", [32, 64])
+def test_fourstep_plan_vs_oracle(g, bits):
+    """FourStepPlan.execute == the oracle's 4-step, every n1 x n2 shape class, both layouts (reference
+    n2 x n1 -> n1 x n2 and natural order), both directions, batch sizes other than the hint, plan reused
+    across calls, preparation in a caller-owned workspace; no scratch of the drop-in calls is touched."""
+    import torch
+    P = O.Port(bits)
+    for logn in (12, 13, 15, 16, 17, 19, 20):
+        p4 = g.NTTParameters4Step(logn, bits)
+        oprm = P.fourstep_params(logn)
+        tf = [g.to_device(t) for t in p4.tables["fwd"]]
+        ti = [g.to_device(t) for t in p4.tables["inv"]]
+        cf = g.ntt4step_configuration(n_power=logn, ntt_type=g.FORWARD)
+        ci = g.ntt4step_configuration(n_power=logn, ntt_type=g.INVERSE, mod_inverse=p4.n_inv)
+        ws = torch.zeros(g.FourStepPlan.workspace_bytes(logn, bits), dtype=torch.uint8, device="cuda")
+        g.release_workspaces()
+        hint = 8 if logn == 19 else 2
+        pf = g.FourStepPlan(*tf, p4.modulus, cf, natural_order=False, batch_hint=hint, workspace=ws)
+        pi = g.FourStepPlan(*ti, p4.modulus, ci, natural_order=False, batch_hint=hint)
+        nf = g.FourStepPlan(*tf, p4.modulus, cf, natural_order=True, batch_hint=hint)
+        ni = g.FourStepPlan(*ti, p4.modulus, ci, natural_order=True, batch_hint=hint)
+        assert pf.fast_path and pi.fast_path and nf.fast_path and ni.fast_path
+        for batch in ((hint, 1, 3) if logn <= 17 else (hint,)):
+            x = P.splitmix(900 + logn + batch, 0, batch * p4.n, p4.modulus.value)
+            want = np.concatenate([P.fourstep_ntt(x[i * p4.n:(i + 1) * p4.n], oprm) for i in range(batch)])
+            # reference layout: transposed input, transposed output
+            xt = x.reshape(batch, p4.n1, p4.n2).transpose(0, 2, 1).reshape(-1).copy()
+            d_in = g.to_device(xt)
+            d_out = torch.zeros_like(d_in)
+            pf.execute(d_in, d_out, batch)
+            torch.cuda.synchronize()
+            got = g.to_host(d_out).reshape(batch, p4.n1, p4.n2).transpose(0, 2, 1).reshape(-1)
+            assert np.array_equal(got, want), ("plan fwd", bits, logn, batch)
+            xin = np.concatenate([P.fourstep_intt_first_transpose(want[i * p4.n:(i + 1) * p4.n], oprm)
+                                  for i in range(batch)])
+            d_in = g.to_device(xin)
+            d_out = torch.zeros_like(d_in)
+            pi.execute(d_in, d_out, batch)
+            torch.cuda.synchronize()
+            back = g.to_host(d_out).reshape(batch, p4.n1, p4.n2).transpose(0, 2, 1).reshape(-1)
+            assert np.array_equal(back, x), ("plan inv", bits, logn, batch)
+            # natural order
+            d_in = g.to_device(x)
+            d_out = torch.zeros_like(d_in)
+            nf.execute(d_in, d_out, batch)
+            torch.cuda.synchronize()
+            assert np.array_equal(g.to_host(d_out), want), ("plan natural fwd", bits, logn, batch)
+            d_back = torch.zeros_like(d_out)
+            ni.execute(d_out, d_back, batch)
+            torch.cuda.synchronize()
+            assert np.array_equal(g.to_host(d_back), x), ("plan natural inv", bits, logn, batch)
+        for p in (pf, pi, nf, ni):
+            p.close()
+
+
+def test_fourstep_plan_golden_2_24(g):
+    """C3's ring through a plan: the forward 2^24 result equals the reference build's digest
+    (tests/golden/digests.json, three-call pipeline) and the natural-order plan's result"""
+    import json
+    import torch
+    from gpu_utils import sha
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "digests.json")))
+    rec = [r for r in gold["fourstep"] if r["logn"] == 24 and r["bits"] == 64][0]
+    P = O.Port(64)
+    p4 = g.NTTParameters4Step(24, 64)
+    tf = [g.to_device(t) for t in p4.tables["fwd"]]
+    cf = g.ntt4step_configuration(n_power=24, ntt_type=g.FORWARD)
+    x = P.splitmix(rec["seed"], 0, p4.n, rec["q"])
+    assert sha(x) == rec["sha_in"]
+    nf = g.FourStepPlan(*tf, p4.modulus, cf, natural_order=True, batch_hint=1)
+    pf = g.FourStepPlan(*tf, p4.modulus, cf, natural_order=False, batch_hint=1)
+    d_in = g.to_device(x)
+    d_t = torch.zeros_like(d_in)
+    d_out = torch.zeros_like(d_in)
+    g.GPU_Transpose(d_in, d_t, p4.n1, p4.n2, 24, 1)
+    torch.cuda.synchronize()
+    pf.execute(d_t, d_out, 1)
+    torch.cuda.synchronize()
+    g.GPU_Transpose(d_out, d_t, p4.n1, p4.n2, 24, 1)
+    torch.cuda.synchronize()
+    assert sha(g.to_host(d_t)) == rec["sha_fwd"]
+    nf.execute(d_in, d_out, 1)
+    torch.cuda.synchronize()
+    assert sha(g.to_host(d_out)) == rec["sha_fwd"]
+
+
+def test_fourstep_plan_slow_modulus_and_errors(g):
+    """a 62-bit modulus has no fast 4-step kernels: the plan reports it and execute() runs the generic
+    path with the same result as GPU_4STEP_NTT; argument errors throw like the drop-in calls"""
+    import torch
+    P = O.Port(64)
+    logn = 13
+    p4 = g.NTTParameters4Step(logn, 64)
+    with pytest.raises(ValueError):
+        g.FourStepPlan.workspace_bytes(11, 64)
+    with pytest.raises(ValueError):
+        g.FourStepPlan.workspace_bytes(25, 64)
+    tf = [g.to_device(t) for t in p4.tables["fwd"]]
+    cf = g.ntt4step_configuration(n_power=logn, ntt_type=g.FORWARD)
+    pf = g.FourStepPlan(*tf, p4.modulus, cf)
+    d = g.to_device(np.zeros(p4.n, dtype=np.uint64))
+    with pytest.raises(ValueError):
+        pf.execute(d, d, 1)  # in place is not supported by the 4-step
+    pf.execute(d, torch.zeros_like(d), 0)  # empty batch: no-op
+    # generic path under GPUNTT_PATH=generic: plan creation sees it and falls back
+    os.environ["GPUNTT_PATH"] = "generic"
+    try:
+        ps = g.FourStepPlan(*tf, p4.modulus, cf)
+        assert not ps.fast_path
+        x = P.splitmix(77, 0, 2 * p4.n, p4.modulus.value)
+        d_in = g.to_device(x)
+        d_a = torch.zeros_like(d_in)
+        d_b = torch.zeros_like(d_in)
+        ps.execute(d_in, d_a, 2)
+        g.GPU_4STEP_NTT(d_in, d_b, *tf, p4.modulus, cf, 2)
+        torch.cuda.synchronize()
+        assert np.array_equal(g.to_host(d_a), g.to_host(d_b))
+    finally:
+        del os.environ["GPUNTT_PATH"]
+    pf.execute(d, torch.zeros_like(d), 1)  # the fast plan made before still runs its prepared path
+    torch.cuda.synchronize()
+
+
+# ------------------------------------------------------------------ seeded random sweep of the Merge entry points
+def test_random_merge_cases_vs_oracle(g):
+    """70 seeded random (word size, modulus width, ring, batch, reduction polynomial, call form) cases: forward
+    result and raw-input inverse result equal the oracle's bit for bit.  Moduli are searched primes of the drawn
+    width (not the reference's pools), so odd widths hit every lazy range (16q / 8q / 4q) and the Barrett kernels."""
+    import torch
+    rng = np.random.default_rng(20260929)
+    for case_no in range(70):
+        bits = int(rng.choice([32, 64]))
+        logn = int(rng.choice([1, 2, 3, 5, 7, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18]))
+        qbits = int(rng.choice([20, 27, 29] if bits == 32 else [24, 33, 47, 55, 59, 60, 61, 62]))
+        if qbits < logn + 12:  # enough candidates k * 2^(logn+1) + 1 of that width
+            qbits = logn + 12 if bits == 64 else 29
+        poly = O.X_N_plus if rng.integers(2) else O.X_N_minus
+        n = 1 << logn
+        batch = int(rng.integers(1, max(2, min(70, (1 << 19) // n) + 1)))
+        form = int(rng.integers(3))  # 0 out of place, 1 in place, 2 plan
+        # (62-bit primes a few hundred below 2^62 get bit = 63 from the reference's double log2: outside its domain)
+        fac = find_ntt_factors(qbits, logn, skip=400 if (qbits == 62 and logn < 10) else int(rng.integers(3)))
+        c = MergeCase(g, bits, logn, poly, fac)
+        tag = (case_no, bits, qbits, logn, batch, poly, form)
+        x = c.random(batch, 7000 + case_no)
+        want = c.P.merge_ntt(x, c.oprm)
+        y = c.random(batch, 8000 + case_no)  # raw input of the inverse (not a forward result)
+        want_inv = c.P.merge_ntt(y, c.oprm, inverse=True)
+        if form == 2:
+            fp = g.NTTPlan(c.fwd_dev, c.prm.modulus, logn, poly, g.FORWARD, batch_hint=int(rng.integers(1, 2000)))
+            ip = g.NTTPlan(c.inv_dev, c.prm.modulus, logn, poly, g.INVERSE, mod_inverse=c.prm.n_inv,
+                           batch_hint=batch)
+            d = g.to_device(x)
+            o = torch.zeros_like(d)
+            fp.execute(d, o, batch)
+            e = g.to_device(y)
+            ip.execute(e, e, batch)
+            torch.cuda.synchronize()
+            got, got_inv = g.to_host(o), g.to_host(e)
+            fp.close()
+            ip.close()
+        else:
+            got = c.gpu_forward(x, inplace=(form == 1))
+            got_inv = c.gpu_inverse(y, inplace=(form == 1))
+        assert np.array_equal(got, want), ("forward",) + tag
+        assert np.array_equal(got_inv, want_inv), ("inverse",) + tag
+
+
+def test_moduli_just_below_a_power_of_two(g):
+    """Modulus<T>::bit is (T)(log2((double) q) + 1) as in the reference (modular_arith.cuh:44-47): a prime within
+    ~2^-48 of a power of two gets its width over-stated by one (2^60 - 107 -> bit 61).  The three words equal the
+    oracle's, and every kernel family computes the right transform with them (the over-stated width selects the
+    next lazy range: 60-bit -> 8q kernels).  A 61-bit prime that close to 2^61 gets bit = 62 and a mu that no longer
+    fits the word (2^125 / q >= 2^64): the reference's own Barrett product is wrong for it, so only the three words
+    are compared there."""
+    fac = find_ntt_factors(61, 3)
+    m = g.Modulus(fac[0], bits=64)
+    assert tuple(m.words()) == O.Port(64).merge_params(3, O.X_N_plus, fac)["mod"] and m.bit == 62
+    seen = set()
+    for qbits in (54, 57, 59, 60):
+        for logn in (1, 3, 5, 12, 13):
+            fac = find_ntt_factors(qbits, logn if logn < 12 else 5)  # the same near-2^k primes serve the big rings
+            fac = fac if logn < 12 else find_ntt_factors(qbits, logn)
+            c = MergeCase(g, 64, logn, O.X_N_plus, fac)  # asserts {value, bit, mu} == oracle's
+            seen.add((qbits, int(c.prm.modulus.bit)))
+            x = c.random(5, 9100 + logn + qbits)
+            want = c.P.merge_ntt(x, c.oprm)
+            assert np.array_equal(c.gpu_forward(x, inplace=bool(logn & 2)), want), (qbits, logn)
+            assert np.array_equal(c.gpu_inverse(want, inplace=not (logn & 2)), x), (qbits, logn)
+    assert (60, 61) in seen and (59, 60) in seen and (57, 58) in seen  # the over-stated widths were exercised

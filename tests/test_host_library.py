@@ -41,6 +41,11 @@ def test_modulus_struct_matches_reference_contract(g):
     for q in (576460756061519873, 576460752303415297, 288230377292562433, 12289, 469762049):
         m = g.Modulus(q)
         assert (m.value, m.bit, m.mu) == P.modulus(q)
+    # just below a power of two the reference's double log2 over-states the width by one (modular_arith.cuh:44-47)
+    for q, bit in ((2**60 - 107, 61), (2**60 - 2559, 61), (2**59 - 55, 60), (2**57 - 111, 58), (2**61 - 31, 62),
+                   (2**54 - 131, 54), (2**60 - 2**20 + 1, 60)):
+        m = g.Modulus(q)
+        assert (m.value, m.bit, m.mu) == P.modulus(q) and m.bit == bit
     P32 = O.Port(32)
     for q in (469762049, 268460033, 12289):
         m = g.Modulus(q, bits=32)

@@ -27,8 +27,11 @@ for bits in (() if os.environ.get('SKIP_MERGE') else (64, 32)):
         cfg = g.ntt_configuration(n_power=logn, reduction_poly=g.X_N_minus)
         fn = lambda: g.GPU_NTT_Inplace(d, tab, prm.modulus, cfg, 1)  # noqa: E731
         ms = time_ms(fn, 200 if logn < 20 else 50, warm=10)
+        plan = g.NTTPlan(tab, prm.modulus, logn, g.X_N_minus, g.FORWARD, batch_hint=1)
+        msp = time_ms(lambda: plan.execute(d, d, 1), 200 if logn < 20 else 50, warm=10)
+        plan.close()
         print(json.dumps({"path": os.environ.get("GPUNTT_PATH", "auto"), "dtype": "u%d" % bits, "log2N": logn,
-                          "batch": 1, "us": round(ms * 1e3, 2)}), flush=True)
+                          "batch": 1, "us": round(ms * 1e3, 2), "plan_us": round(msp * 1e3, 2)}), flush=True)
 
 # 4-step, single polynomial (benchmark/bench_4step_ntt.cu:96-100 sweeps the same axis), pre-transposed input
 for logn in range(12, 25):
@@ -42,6 +45,13 @@ for logn in range(12, 25):
     ms = time_ms(fn, 200 if logn < 20 else 50, warm=10)
     fn2 = lambda: g.GPU_4STEP_NTT_NaturalOrder(a, b, *tf, p4.modulus, cf, 1)  # noqa: E731
     ms2 = time_ms(fn2, 200 if logn < 20 else 50, warm=10)
+    pl = g.FourStepPlan(*tf, p4.modulus, cf, natural_order=False, batch_hint=1)
+    ms3 = time_ms(lambda: pl.execute(a, b, 1), 200 if logn < 20 else 50, warm=10)
+    pl.close()
+    pl = g.FourStepPlan(*tf, p4.modulus, cf, natural_order=True, batch_hint=1)
+    ms4 = time_ms(lambda: pl.execute(a, b, 1), 200 if logn < 20 else 50, warm=10)
+    pl.close()
     print(json.dumps({"path": os.environ.get("GPUNTT_PATH", "auto"), "dtype": "u64", "log2N": logn, "batch": 1,
-                      "algo": "4step-fwd", "us": round(ms * 1e3, 2), "natural_order_us": round(ms2 * 1e3, 2)}),
+                      "algo": "4step-fwd", "us": round(ms * 1e3, 2), "natural_order_us": round(ms2 * 1e3, 2),
+                      "plan_us": round(ms3 * 1e3, 2), "plan_natural_order_us": round(ms4 * 1e3, 2)}),
           flush=True)
