@@ -89,7 +89,8 @@ EXPORTED_SYMBOLS = ["gpuntt_last_error", "gpuntt_version"] + [
               "merge_params",
               "4step_params", "plan_workspace_bytes", "plan_create", "plan_execute", "plan_fast_path",
               "plan_destroy", "operator_gpu", "4step_plan_workspace_bytes", "4step_plan_create",
-              "4step_plan_execute", "4step_plan_fast_path", "4step_plan_destroy")
+              "4step_plan_execute", "4step_plan_fast_path", "4step_plan_destroy",
+              "generate_power_table", "generate_4step_w")
     for s in ("u32", "u64")] + ["gpuntt_release_workspaces"]
 
 
@@ -518,6 +519,23 @@ class FourStepPlan:
             self.close()
         except Exception:
             pass
+
+
+def GPU_GeneratePowerTable(device_out, base, modulus, log_count, bit_reversed=True, stream=None):
+    """Extension: device_out[k] = base^(bitreverse(k, log_count) if bit_reversed else k), k < 2^log_count -- the
+    device-order root tables of GPU_NTT / GPU_INTT / the 4-step n1, n2 slots, built on the device."""
+    _require_gpu(device_out)
+    fn = getattr(load_library(), "gpuntt_generate_power_table_u%d" % modulus.bits)
+    _check(fn(_ptr(device_out), _ct(modulus.bits)(base), modulus.c(), int(log_count), int(bool(bit_reversed)),
+              _stream(stream)))
+
+
+def GPU_Generate4StepW(device_W, root, modulus, n_power, ntt_type=FORWARD, stream=None):
+    """Extension: the 4-step W matrix on the device: FORWARD W[i*n2+j] = root^(bitreverse(i)*j) (root_of_unity),
+    INVERSE W[i*n2+j] = root^(bitreverse(j)*i) (inverse_root_of_unity)."""
+    _require_gpu(device_W)
+    fn = getattr(load_library(), "gpuntt_generate_4step_w_u%d" % modulus.bits)
+    _check(fn(_ptr(device_W), _ct(modulus.bits)(root), modulus.c(), int(n_power), int(ntt_type), _stream(stream)))
 
 
 def release_workspaces():

@@ -592,6 +592,24 @@ extern "C"
     {                                                                                             \
         return guarded([&] { delete reinterpret_cast<FourStepPlan<T>*>(plan); });                 \
     }                                                                                             \
+    int gpuntt_generate_power_table_##S(T* out, T base, CM modulus, int log_count,                \
+                                        int bit_reversed, void* stream)                           \
+    {                                                                                             \
+        GPUNTT_NEED(out)                                                                          \
+        return guarded([&] {                                                                      \
+            GPU_GeneratePowerTable<T>(out, base, to_mod<T>(modulus), log_count, bit_reversed != 0, \
+                                      static_cast<hipStream_t>(stream));                          \
+        });                                                                                       \
+    }                                                                                             \
+    int gpuntt_generate_4step_w_##S(T* out, T root, CM modulus, int n_power, int ntt_type,        \
+                                    void* stream)                                                 \
+    {                                                                                             \
+        GPUNTT_NEED(out)                                                                          \
+        return guarded([&] {                                                                      \
+            GPU_Generate4StepW<T>(out, root, to_mod<T>(modulus), n_power,                         \
+                                  static_cast<type>(ntt_type), static_cast<hipStream_t>(stream)); \
+        });                                                                                       \
+    }                                                                                             \
     int gpuntt_operator_gpu_##S(int op, const T* a, const T* b, T* out, CM modulus,               \
                                 uint64_t count, void* stream)                                     \
     {                                                                                             \

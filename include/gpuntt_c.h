@@ -248,6 +248,21 @@ extern "C"
     int gpuntt_4step_plan_destroy_u32(gpuntt_4step_plan* plan);
     int gpuntt_4step_plan_destroy_u64(gpuntt_4step_plan* plan);
 
+    /* ---- extension: root-of-unity tables built on the device (include/gpuntt/common/parameter_sets.hpp) ----
+     * power table: out[k] = base^(bit_reversed ? bitreverse(k, log_count) : k), k < 2^log_count (log_count <= 28) --
+     * with bit_reversed = 1 the device-order table GPU_NTT / GPU_INTT / the 4-step n1, n2 slots take;
+     * 4-step W:  GPUNTT_FORWARD W[i*n2+j] = root^(bitreverse(i, log n1) * j), GPUNTT_INVERSE root^(bitreverse(j, log n2) * i)
+     * (pass the inverse root), N = 2^n_power entries, 12 <= n_power <= 24.  Replaces the host loops of the
+     * reference's src/lib/common/nttparameters.cu:356-444 and the upload. */
+    int gpuntt_generate_power_table_u32(uint32_t* out, uint32_t base, gpuntt_modulus32 modulus, int log_count,
+                                        int bit_reversed, void* stream);
+    int gpuntt_generate_power_table_u64(uint64_t* out, uint64_t base, gpuntt_modulus64 modulus, int log_count,
+                                        int bit_reversed, void* stream);
+    int gpuntt_generate_4step_w_u32(uint32_t* out, uint32_t root, gpuntt_modulus32 modulus, int n_power, int ntt_type,
+                                    void* stream);
+    int gpuntt_generate_4step_w_u64(uint64_t* out, uint64_t root, gpuntt_modulus64 modulus, int n_power, int ntt_type,
+                                    void* stream);
+
     /* frees the library-owned scratch buffers of the drop-in entry points (synchronises the device) */
     int gpuntt_release_workspaces(void);
 

@@ -597,3 +597,82 @@ def test_moduli_just_below_a_power_of_two(g):
             assert np.array_equal(c.gpu_forward(x, inplace=bool(logn & 2)), want), (qbits, logn)
             assert np.array_equal(c.gpu_inverse(want, inplace=not (logn & 2)), x), (qbits, logn)
     assert (60, 61) in seen and (59, 60) in seen and (57, 58) in seen  # the over-stated widths were exercised
+
+
+# ------------------------------------------------------------------ tables built on the device
+@pytest.mark.parametrize("bits", [32, 64])
+def test_device_generated_tables_equal_host_tables(g, bits):
+    """GPU_GeneratePowerTable / GPU_Generate4StepW write the very words NTTParameters<T> / NTTParameters4Step<T>
+    build on the host (pinned to the reference build through tests/golden): Merge forward and inverse device-order
+    tables for both reduction polynomials, the 4-step n1 / n2 tables and both W matrices for every n1 x n2 shape."""
+    import torch
+    dt = torch.int32 if bits == 32 else torch.int64
+    for logn in (1, 2, 5, 11, 12, 16, 20):
+        for poly in (O.X_N_plus, O.X_N_minus):
+            prm = g.NTTParameters(logn, poly, bits)
+            q = prm.modulus.value
+            root = prm.psi if poly == O.X_N_plus else prm.omega
+            lg = logn if poly == O.X_N_plus else logn - 1
+            assert prm.root_of_unity_size == 1 << lg
+            for base, host in ((root, prm.forward_table_device_order), (pow(root, -1, q), prm.inverse_table_device_order)):
+                d = torch.zeros(1 << lg, dtype=dt, device="cuda")
+                g.GPU_GeneratePowerTable(d, base, prm.modulus, lg, True)
+                torch.cuda.synchronize()
+                assert np.array_equal(g.to_host(d).view(g.np_dtype(bits)), host), (bits, logn, poly)
+    for logn in range(12, 23):
+        p4 = g.NTTParameters4Step(logn, bits)
+        q = p4.modulus.value
+        root = p4.omega  # cyclic: root_of_unity = omega
+        for tag, r, kind in (("fwd", root, g.FORWARD), ("inv", pow(root, -1, q), g.INVERSE)):
+            t1, t2, w = p4.tables[tag]
+            d = torch.zeros(p4.n, dtype=dt, device="cuda")
+            g.GPU_Generate4StepW(d, r, p4.modulus, logn, kind)
+            d1 = torch.zeros(p4.n1 >> 1, dtype=dt, device="cuda")
+            d2 = torch.zeros(p4.n2 >> 1, dtype=dt, device="cuda")
+            g.GPU_GeneratePowerTable(d1, pow(r, p4.n // p4.n1, q), p4.modulus, int(np.log2(p4.n1)) - 1, True)
+            g.GPU_GeneratePowerTable(d2, pow(r, p4.n // p4.n2, q), p4.modulus, int(np.log2(p4.n2)) - 1, True)
+            torch.cuda.synchronize()
+            assert np.array_equal(g.to_host(d).view(g.np_dtype(bits)), w), (bits, logn, tag, "W")
+            assert np.array_equal(g.to_host(d1).view(g.np_dtype(bits)), t1), (bits, logn, tag, "n1")
+            assert np.array_equal(g.to_host(d2).view(g.np_dtype(bits)), t2), (bits, logn, tag, "n2")
+    # natural (not bit-reversed) order and argument errors
+    prm = g.NTTParameters(8, O.X_N_minus, bits)
+    d = torch.zeros(64, dtype=dt, device="cuda")
+    g.GPU_GeneratePowerTable(d, prm.omega, prm.modulus, 6, False)
+    torch.cuda.synchronize()
+    assert [int(v) for v in g.to_host(d).view(g.np_dtype(bits))] == [pow(prm.omega, k, prm.modulus.value) for k in range(64)]
+    with pytest.raises(ValueError):
+        g.GPU_GeneratePowerTable(d, prm.modulus.value, prm.modulus, 6, True)  # base not reduced
+    with pytest.raises(ValueError):
+        g.GPU_Generate4StepW(d, prm.omega, prm.modulus, 11, g.FORWARD)
+
+
+def test_fourstep_2_24_from_device_generated_tables(g):
+    """C3's ring with no host-built table at all: W and the n1 / n2 tables generated on the device (digest of W equals
+    the reference build's), a FourStepPlan prepared from them, forward result equal to the reference digest"""
+    import json
+    import torch
+    from gpu_utils import sha
+    rec = [r for r in json.load(open(os.path.join(os.path.dirname(__file__), "golden", "digests.json")))["fourstep"]
+           if r["logn"] == 24 and r["bits"] == 64][0]
+    q, root = rec["q"], rec["omega"]
+    m = g.Modulus(q, bits=64)
+    n1, n2, n = 256, 65536, 1 << 24
+    w = torch.zeros(n, dtype=torch.int64, device="cuda")
+    t1 = torch.zeros(n1 >> 1, dtype=torch.int64, device="cuda")
+    t2 = torch.zeros(n2 >> 1, dtype=torch.int64, device="cuda")
+    g.GPU_Generate4StepW(w, root, m, 24, g.FORWARD)
+    g.GPU_GeneratePowerTable(t1, pow(root, n // n1, q), m, 7, True)
+    g.GPU_GeneratePowerTable(t2, pow(root, n // n2, q), m, 15, True)
+    torch.cuda.synchronize()
+    assert sha(g.to_host(w).view(np.uint64)) == rec["sha_W_fwd"]
+    assert sha(g.to_host(t2).view(np.uint64)) == rec["sha_n2_fwd_gpu"]
+    plan = g.FourStepPlan(t1, t2, w, m, g.ntt4step_configuration(n_power=24, ntt_type=g.FORWARD), natural_order=True)
+    torch.cuda.synchronize()
+    del w  # the prepared pairs are all the plan needs
+    x = O.Port(64).splitmix(rec["seed"], 0, n, q)
+    d_in = g.to_device(x)
+    d_out = torch.zeros_like(d_in)
+    plan.execute(d_in, d_out, 1)
+    torch.cuda.synchronize()
+    assert sha(g.to_host(d_out)) == rec["sha_fwd"]
