@@ -236,6 +236,15 @@ namespace gpuntt
         extern template void launch_pass_lazy_lim<false, 4>(const Pass&, bool, bool, const kern::LazyArgsT<uint64_t>&, hipStream_t);
         extern template void launch_pass_lazy_lim<true, 4>(const Pass&, bool, bool, const kern::LazyArgsT<uint64_t>&, hipStream_t);
 
+        // persistent, software-pipelined form of the 10-stage contiguous pass (merge_pipe_kernels.hpp; 64-bit rings
+        // 2^13 .. 2^16 on 4096-coefficient tiles): launches it and returns true if the call qualifies
+        // -- opt-in through GPUNTT_PIPE=1 | 2, measured slower than the default kernels (lazy_u64_pipe.hip)
+        template <bool INV>
+        bool launch_contig_pipe(const Pass& p, bool in_first, bool last, const kern::LazyArgsT<uint64_t>& a,
+                                hipStream_t stream);
+        extern template bool launch_contig_pipe<false>(const Pass&, bool, bool, const kern::LazyArgsT<uint64_t>&, hipStream_t);
+        extern template bool launch_contig_pipe<true>(const Pass&, bool, bool, const kern::LazyArgsT<uint64_t>&, hipStream_t);
+
         // forced_tl: tile size the twiddle table was prepared for (NTTPlan); 0 = choose from the batch
         template <typename T, bool INV>
         inline void run_transform_lazy(kern::LazyArgsT<T> base, unsigned first_in_flags,
@@ -285,7 +294,7 @@ namespace gpuntt
                         launch_pass_lazy_lim<INV, 8>(p, i == 0, i == pl.count - 1, a, stream);
                     else if (base.lim == 4)
                         launch_pass_lazy_lim<INV, 4>(p, i == 0, i == pl.count - 1, a, stream);
-                    else
+                    else if (tlp != 12 || pl.count < 2 || !launch_contig_pipe<INV>(p, i == 0, i == pl.count - 1, a, stream))
                         launch_pass_lazy<T, INV>(p, tlp, i == 0, i == pl.count - 1, a, stream);
                 }
                 else

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Run ONE configuration a few times (for `rocprofv3 --pmc ...` / `--kernel-trace` passes):
-    python tools/run_case.py c2|c2i|c3|c4|c4full|c5 [iters]"""
+    python tools/run_case.py c2|c2i|c3|c4|c4full|c5|merge:BITS:LOGN:BATCH[:inv] [iters]"""
 import os
 import sys
 
@@ -29,5 +29,8 @@ elif case == "c4full":
     bc.merge_case(g, 32, 14, 8192, g.X_N_minus, iters, "C4full")
 elif case == "c5":
     bc.rns_case(g, 16, 512, iters, "C5", os.path.join(ROOT, "tests", "golden"))
+elif case.startswith("merge:"):  # merge:BITS:LOGN:BATCH[:inv]
+    f = case.split(":")
+    bc.merge_case(g, int(f[1]), int(f[2]), int(f[3]), g.X_N_minus, iters, case, inverse=len(f) > 4)
 else:
     raise SystemExit("unknown case " + case)
