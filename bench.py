@@ -187,6 +187,59 @@ def measure_traffic(config, api, out_of_place=False):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def measure_power(step, seconds=3.0):
+    """Socket power and shader clock (rocm-smi) sampled while the step loops for `seconds` -- after the timed
+    region, never part of `value`.  DESIGN.md section 3.4: these transforms run at the part's socket power cap, so the
+    energy per call, not the HBM rate, sets their time; this puts the evidence next to the number.
+    Returns None if rocm-smi is unavailable."""
+    import re
+    import shutil
+    import subprocess
+    import threading
+    import torch
+    smi = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(smi):
+        return None
+    samples = []
+
+    def sampler():
+        time.sleep(0.8)  # let the clocks settle under the load first
+        for _ in range(3):
+            try:
+                out = subprocess.run([smi, "-d", os.environ.get("LOCAL_RANK", "0"), "--showpower", "--showclocks",
+                                      "--showmaxpower"], capture_output=True, text=True, timeout=20).stdout
+            except Exception:
+                return
+            w = re.search(r"Socket (?:Graphics )?Package Power \(W\):\s*([0-9.]+)", out) or \
+                re.search(r"Average Graphics Package Power \(W\):\s*([0-9.]+)", out)
+            c = re.search(r"sclk clock level:.*?\((\d+)Mhz\)", out)
+            m = re.search(r"Max Graphics Package Power \(W\):\s*([0-9.]+)", out)
+            samples.append((float(w.group(1)) if w else None, int(c.group(1)) if c else None,
+                            float(m.group(1)) if m else None))
+
+    th = threading.Thread(target=sampler)
+    th.start()
+    t0 = time.perf_counter()
+    calls = 0
+    while th.is_alive() and time.perf_counter() - t0 < max(seconds, 1.0) + 60.0:
+        for _ in range(16):
+            step()
+        calls += 16
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    th.join()
+    ws = [x[0] for x in samples if x[0] is not None]
+    if not ws:
+        return None
+    caps = [x[2] for x in samples if x[2] is not None]
+    ms = dt / calls * 1e3
+    return {"socket_w": ws, "sclk_mhz": [x[1] for x in samples if x[1] is not None],
+            "cap_w": caps[0] if caps else None, "ms_per_step_while_sampling": ms,
+            "energy_per_step_j": sum(ws) / len(ws) * ms * 1e-3,
+            "note": "rocm-smi samples while the step loops after the timed region; at the cap the energy per "
+                    "step bounds the time (DESIGN.md 3.4)"}
+
+
 def quoted_traffic():
     try:
         pm = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles")) if p.endswith("_pmc_traffic.json"))
@@ -314,6 +367,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--no-power", action="store_true")
     ap.add_argument("--out-of-place", action="store_true",
                     help="time GPU_NTT(in, out) instead of the in-place call the reference's own benchmark times")
     ap.add_argument("--cpu-polys", type=int, default=64)
@@ -400,6 +454,13 @@ def main():
         except Exception as e:  # informational only
             other = "failed: %r" % (e,)
 
+    power = None
+    if world == 1 and not args.no_power:
+        try:
+            power = measure_power(step)
+        except Exception as e:  # informational only
+            power = {"error": repr(e)}
+
     e2e = None
     if dist is not None and not args.no_e2e and case.get("run_shard") is not None:
         try:
@@ -449,6 +510,8 @@ def main():
         }
         if isinstance(other, float):
             line["other_api_ms_per_call"] = {"api": "plan" if args.api == "dropin" else "dropin", "ms": other}
+        if power is not None:
+            line["power"] = power
         if e2e is not None:
             line["end_to_end"] = e2e
         if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only

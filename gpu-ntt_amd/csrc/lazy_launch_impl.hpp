@@ -18,7 +18,7 @@ namespace gpuntt
         // Instantiated pass shapes (everything run_transform_lazy can ask for):
         //   single pass       CONTIG K = n <= TLOG              (IN 1, last)   [TLOG 14: K = 13, 14 only]
         //   forward, n > TLOG STRIDED K 1..8 (IN 1 | LIMIT, not last) + CONTIG K (IN LIMIT, last)
-        //   inverse, n > TLOG CONTIG K (IN 1, not last) + STRIDED K 1..8 (IN LIMIT, last | not last)
+        //   inverse, n > TLOG CONTIG K (IN 1, not last) + STRIDED K 1..8 (IN LIMIT / 2, last | not last)
         //   with CONTIG K in 8..12 for 4096-coefficient tiles and K = 14 for 16384-coefficient tiles
         template <typename T, int TLOG, bool INV, int LIMSEL = 0>
         void dispatch_tl(const Pass& p, bool in_first, bool last, const kern::LazyArgsT<T>& a,
@@ -160,9 +160,10 @@ namespace gpuntt
                     if (!in_first)
                         switch (p.k * 2 + (last ? 1 : 0))
                         {
+                    // an inverse pass hands over values below LIMIT / 2 (lazy.hpp: gs_plan corrects the sums)
 #define GPUNTT_CASE(KK)                                                                          \
-    case KK * 2 + 1: GPUNTT_ONE(false, KK, LIM, true);                                           \
-    case KK * 2: GPUNTT_ONE(false, KK, LIM, false);
+    case KK * 2 + 1: GPUNTT_ONE(false, KK, LIM / 2, true);                                       \
+    case KK * 2: GPUNTT_ONE(false, KK, LIM / 2, false);
                             GPUNTT_CASE(1)
                             GPUNTT_CASE(2)
                             GPUNTT_CASE(3)

@@ -147,6 +147,7 @@ namespace gpuntt
                 int ku[NR][R][EPT / 2];
                 int kv[NR][R][EPT / 2];
                 int c[NR][R][EPT / 2];
+                int ko[NR][R][EPT / 2];
                 int bout[NR][EPT];
                 int bin[NR];
                 int final_bound;
@@ -206,6 +207,7 @@ namespace gpuntt
                                 d.ku[r][s][h] = pl.ku;
                                 d.kv[r][s][h] = pl.kv;
                                 d.c[r][s][h] = pl.c;
+                                d.ko[r][s][h] = pl.ko;
                                 b[j0] = pl.out_u;
                                 b[j1] = TB;
                             }
@@ -661,11 +663,18 @@ namespace gpuntt
                             if constexpr (kv != 0)
                                 V = m.template csub<kv>(V);
                             // final stage of an inverse transform: its twiddle was prepared as
-                            // w * n^-1, so scaling the sum as well finishes the n^-1 product
+                            // w * n^-1, so scaling the sum as well finishes the n^-1 product (the product
+                            // takes any 64-bit value: no range correction of the sum there)
                             if constexpr (LAST && r == G::NR - 1 && s == STAGES - 1)
                                 v[j0] = m.template mul<true>(U + V, ninv);
                             else
-                                v[j0] = U + V;
+                            {
+                                constexpr int ko = SCH::d.ko[r][s][h];
+                                T S = U + V;
+                                if constexpr (ko != 0)
+                                    S = m.template csub<ko>(S);
+                                v[j0] = S;
+                            }
                             v[j1] = m.template mul<UNIFORM_R>(U + m.kq(c) - V, tw);
                         }
                     });

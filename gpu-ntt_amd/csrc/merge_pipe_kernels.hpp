@@ -219,7 +219,11 @@ namespace gpuntt
                                     U = m.template csub<ku>(U);
                                 if constexpr (kv != 0)
                                     V = m.template csub<kv>(V);
-                                v[j0] = U + V;
+                                constexpr int ko = SCH::d.ko[r][s][h];
+                                T S = U + V;
+                                if constexpr (ko != 0)
+                                    S = m.template csub<ko>(S);
+                                v[j0] = S;
                                 v[j1] = m.template mul<UNIFORM_R>(U + m.kq(c) - V, tw);
                             }
                             // the eight butterflies of a stage are independent; scheduled all at once their
