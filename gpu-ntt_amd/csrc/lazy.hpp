@@ -46,7 +46,7 @@ namespace gpuntt
         __device__ __forceinline__ uint32_t hi32(uint64_t v) { return static_cast<uint32_t>(v >> 32); }
 
         // LIM = 0: the default lazy range of the word size (16 q for 64-bit words, q < 2^60; 4 q for 32-bit words,
-        // q < 2^30); LIM = 8: 64-bit words with 61-bit moduli (8 q < 2^64: one range correction per stage);
+        // q < 2^30); LIM = 31: 64-bit words with 31 q < 2^64 (forward transforms); LIM = 8: 64-bit words with 61-bit moduli (8 q < 2^64: one range correction per stage);
         // LIM = 4: 62-bit moduli (4 q < 2^64: products corrected to [0, 2q), the 32-bit scheme in 64-bit words)
         template <typename T, int LIM = 0> struct Mod;
 
@@ -98,7 +98,7 @@ namespace gpuntt
         {
             static constexpr int TB = (LIM == 4) ? 2 : 4; // product bound (units of q)
             static constexpr int LIMIT = LIM;              // lazy values stay below LIMIT * q < 2^64
-            static constexpr int MAX_BIT = (LIM == 16) ? 60 : (LIM == 8 ? 61 : 62);
+            static constexpr int MAX_BIT = (LIM == 16 || LIM == 31) ? 60 : (LIM == 8 ? 61 : 62);
             uint64_t q;
             uint64_t qneg; // 2^64 - q
             NormConst nc;
@@ -177,6 +177,11 @@ namespace gpuntt
         };
 
         template <> struct Mod<uint64_t, 0> : Mod64<16>
+        {
+        };
+        // 31 q < 2^64 (every prime of the reference's 64-bit pools: 2^59 + small): twice the headroom, forward
+        // transforms correct the range every fourth stage instead of every second (host-side switch, lim = 31)
+        template <> struct Mod<uint64_t, 31> : Mod64<31>
         {
         };
         template <> struct Mod<uint64_t, 8> : Mod64<8>

@@ -234,6 +234,12 @@ namespace gpuntt
         extern template void launch_pass_lazy_lim<false, 8>(const Pass&, bool, bool, const kern::LazyArgsT<uint64_t>&, hipStream_t);
         extern template void launch_pass_lazy_lim<true, 8>(const Pass&, bool, bool, const kern::LazyArgsT<uint64_t>&, hipStream_t);
         extern template void launch_pass_lazy_lim<false, 4>(const Pass&, bool, bool, const kern::LazyArgsT<uint64_t>&, hipStream_t);
+        extern template void launch_pass_lazy_lim<false, 31>(const Pass&, bool, bool, const kern::LazyArgsT<uint64_t>&, hipStream_t);
+        // forward transforms of a modulus with 31 q < 2^64 on 4096-coefficient tiles take the LIMIT = 31 kernels
+        // (GPUNTT_LIM31=0 switches that off for A/B timing)
+        bool lazy_lim31_enabled();
+        int lazy_pipe_env();
+        inline bool lazy_lim31_modulus(uint64_t q) { return q >= 3 && q <= 0xffffffffffffffffull / 31; }
         extern template void launch_pass_lazy_lim<true, 4>(const Pass&, bool, bool, const kern::LazyArgsT<uint64_t>&, hipStream_t);
 
         // persistent, software-pipelined form of the 10-stage contiguous pass (merge_pipe_kernels.hpp; 64-bit rings
@@ -294,6 +300,13 @@ namespace gpuntt
                         launch_pass_lazy_lim<INV, 8>(p, i == 0, i == pl.count - 1, a, stream);
                     else if (base.lim == 4)
                         launch_pass_lazy_lim<INV, 4>(p, i == 0, i == pl.count - 1, a, stream);
+                    else if (base.lim == 31)
+                    {
+                        if constexpr (!INV)
+                            launch_pass_lazy_lim<false, 31>(p, i == 0, i == pl.count - 1, a, stream);
+                        else
+                            throw std::invalid_argument("internal: the 31 q range serves forward transforms only");
+                    }
                     else if (tlp != 12 || pl.count < 2 || !launch_contig_pipe<INV>(p, i == 0, i == pl.count - 1, a, stream))
                         launch_pass_lazy<T, INV>(p, tlp, i == 0, i == pl.count - 1, a, stream);
                 }

@@ -373,6 +373,16 @@ namespace gpuntt
             return 12;
         }
 
+        bool lazy_lim31_enabled()
+        {
+            static const bool v = [] {
+                const char* e = std::getenv("GPUNTT_LIM31");
+                return !(e != nullptr && std::atoi(e) == 0);
+            }();
+            // the opt-in experiment kernels (single-launch, pipelined) exist for the 16 q range only
+            return v && lazy_fused_env() != 1 && lazy_pipe_env() <= 0;
+        }
+
         bool lazy_reverse_passes()
         {
             static const bool v = [] {

@@ -676,3 +676,34 @@ def test_fourstep_2_24_from_device_generated_tables(g):
     plan.execute(d_in, d_out, 1)
     torch.cuda.synchronize()
     assert sha(g.to_host(d_out)) == rec["sha_fwd"]
+
+
+def test_31q_range_switch(g):
+    """Forward transforms of moduli with 31 q < 2^64 (every pool prime) take the LIMIT = 31 kernels on
+    4096-coefficient tiles; GPUNTT_LIM31=0 keeps them on the 16 q kernels.  Both must equal the oracle, and a
+    60-bit prime above 2^64 / 31 must stay on the 16 q kernels (and equal the oracle too)."""
+    from test_gpu_merge import _run_in_subprocess
+    code = r'''
+import numpy as np, sys, os
+sys.path.insert(0, os.path.join(os.path.dirname(os.environ["PYTHONPATH"]), ""))
+from conftest import load_pkg
+from gpu_utils import MergeCase, find_ntt_factors
+from oracle import oracle as O
+g = load_pkg(); g.load_library()
+for logn, batch in ((9, 9), (12, 5), (16, 7), (17, 3), (20, 2)):
+    for poly in (O.X_N_minus, O.X_N_plus):
+        c = MergeCase(g, 64, logn, poly)
+        assert c.q <= (2**64 - 1) // 31
+        x = c.random(batch, 77 + logn)
+        assert np.array_equal(c.gpu_forward(x, inplace=bool(logn & 1)), c.P.merge_ntt(x, c.oprm)), (logn, poly)
+f = find_ntt_factors(60, 16)
+assert f[0] > (2**64 - 1) // 31
+c = MergeCase(g, 64, 16, O.X_N_plus, f)
+x = c.random(3, 5)
+assert np.array_equal(c.gpu_forward(x), c.P.merge_ntt(x, c.oprm))
+# prepared transforms (single modulus and an RNS stack of pool-sized primes)
+prm = c.prm
+print("31q switch OK")
+'''
+    for env in ({"GPUNTT_LIM31": "0"}, {"GPUNTT_LIM31": "1"}, {"GPUNTT_LIM31": "1", "GPUNTT_PATH": "fast-strict"}):
+        assert "31q switch OK" in _run_in_subprocess(code, env)
