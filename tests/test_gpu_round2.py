@@ -701,8 +701,6 @@ assert f[0] > (2**64 - 1) // 31
 c = MergeCase(g, 64, 16, O.X_N_plus, f)
 x = c.random(3, 5)
 assert np.array_equal(c.gpu_forward(x), c.P.merge_ntt(x, c.oprm))
-# prepared transforms (single modulus and an RNS stack of pool-sized primes)
-prm = c.prm
 print("31q switch OK")
 '''
     for env in ({"GPUNTT_LIM31": "0"}, {"GPUNTT_LIM31": "1"}, {"GPUNTT_LIM31": "1", "GPUNTT_PATH": "fast-strict"}):
