@@ -900,6 +900,28 @@ namespace gpuntt
             });
         }
 
+        // Poly-minor block order (the polynomials of a batch that share a slice of the twiddle / W table run back
+        // to back), XCD-aware: the dispatcher sends workgroup b to XCD b % 8 and every XCD has its own L2, so a
+        // slice shared by consecutive block indices is fetched from the fabric once per XCD -- up to 8 times
+        // (PMC, C3 phase 1: 2.15 GB of W fetched for a 256 MiB table).  With 8 | tiles the tile index takes its
+        // low three bits from b % 8, so all polynomials of a tile position run on ONE XCD and its slice crosses the
+        // fabric once.  Falls back to the plain order for rings of fewer than 8 tiles.
+        __device__ __forceinline__ void poly_minor_order(unsigned bx, unsigned batch, int tiles_log, unsigned& poly,
+                                                         unsigned& tile)
+        {
+            if (tiles_log >= 3)
+            {
+                const unsigned x = bx & 7u, k = bx >> 3;
+                poly = k % batch;
+                tile = ((k / batch) << 3) | x;
+            }
+            else
+            {
+                poly = bx % batch;
+                tile = bx / batch;
+            }
+        }
+
         template <typename T, int TLOG, bool INV, bool CONTIG, int K, int IN_BOUND, bool LAST, int LIM = 0>
         __global__ __launch_bounds__(LTile<TLOG>::NT, (LOcc<TLOG, T>::WAVES)) void merge_pass_lazy(LazyArgsT<T> a)
         {
@@ -927,9 +949,11 @@ namespace gpuntt
             const unsigned bx = (a.flags & F_REVERSE) ? (gridDim.x - 1u - blockIdx.x) : blockIdx.x;
             long long blk = static_cast<long long>(bx);
             if (a.batch > 1)
-                blk = static_cast<long long>(
-                    (static_cast<unsigned long long>(bx % static_cast<unsigned>(a.batch)) << (a.n - TLOG)) |
-                    (bx / static_cast<unsigned>(a.batch)));
+            {
+                unsigned poly, tile;
+                poly_minor_order(bx, static_cast<unsigned>(a.batch), a.n - TLOG, poly, tile);
+                blk = static_cast<long long>((static_cast<unsigned long long>(poly) << (a.n - TLOG)) | tile);
+            }
             if (a.mods != nullptr)
             {
                 const LTileMap<TLOG, CONTIG, K> map(a.n, a.p_lo, static_cast<unsigned long long>(blk));
@@ -1124,9 +1148,9 @@ namespace gpuntt
             using SCH = PassSched<TLOG, false, false, K, 1, M::LIMIT, M::TB>;
             constexpr bool NEEDS_LDS = (G::NR > 1) || (SCH::wl_of(0) < 4);
             __shared__ T lds[NEEDS_LDS ? LTile<TLOG>::LDS_ELEMS : 1];
-            const unsigned long long poly = blockIdx.x % static_cast<unsigned>(a.batch);
-            const unsigned long long tile = blockIdx.x / static_cast<unsigned>(a.batch);
-            const long long blk = static_cast<long long>((poly << (a.n - TLOG)) | tile);
+            unsigned poly, tile;
+            poly_minor_order(blockIdx.x, static_cast<unsigned>(a.batch), a.n - TLOG, poly, tile);
+            const long long blk = static_cast<long long>((static_cast<unsigned long long>(poly) << (a.n - TLOG)) | tile);
             pass_body<T, TLOG, false, false, false, K, 1, false, 0, true>(a, lds, a.q, a.q_bit, a.q_mu, 0, 0, 0, blk);
         }
 
@@ -1173,9 +1197,9 @@ namespace gpuntt
             using SCH = PassSched<TLOG, true, false, K, M::TB, M::LIMIT, M::TB>;
             constexpr bool NEEDS_LDS = (G::NR > 1) || (SCH::wl_of(0) < 4);
             __shared__ T lds[NEEDS_LDS ? LTile<TLOG>::LDS_ELEMS : 1];
-            const unsigned long long poly = blockIdx.x % static_cast<unsigned>(a.batch);
-            const unsigned long long tile = blockIdx.x / static_cast<unsigned>(a.batch);
-            const long long blk = static_cast<long long>((poly << (a.n - TLOG)) | tile);
+            unsigned poly, tile;
+            poly_minor_order(blockIdx.x, static_cast<unsigned>(a.batch), a.n - TLOG, poly, tile);
+            const long long blk = static_cast<long long>((static_cast<unsigned long long>(poly) << (a.n - TLOG)) | tile);
             pass_body<T, TLOG, false, true, false, K, M::TB, true, 0, true>(a, lds, a.q, a.q_bit, a.q_mu, 0, 0, 0, blk);
         }
 
@@ -1195,8 +1219,8 @@ namespace gpuntt
                 qb = md.bit;
                 qm = md.mu;
             }
-            const unsigned long long poly = blockIdx.x % static_cast<unsigned>(a.batch);
-            const unsigned tile = blockIdx.x / static_cast<unsigned>(a.batch);
+            unsigned poly, tile;
+            poly_minor_order(blockIdx.x, static_cast<unsigned>(a.batch), a.poly_shift - TLOG, poly, tile);
             pass_body<T, TLOG, false, INV, true, K, 1, false, true>(a, lds, qv, qb, qm, 0, poly, tile);
         }
 
