@@ -250,9 +250,9 @@ namespace gpuntt
                 b.ninv = TW{ninv, host::shoup_host(ninv, mod.value)};
             if (INV && mods_dev != nullptr)
                 b.ninv_arr = ws_ninv;
-            // forward row passes of a modulus with 31 q < 2^64 on 4096-coefficient tiles: the LIMIT = 31 kernels
+            // forward row passes of a modulus with 31 q < 2^64: the LIMIT = 31 kernels
             if constexpr (sizeof(T) == 8 && !INV)
-                if (mods_dev == nullptr && tl2 == 12 && host::lazy_lim31_enabled() &&
+                if (mods_dev == nullptr && host::lazy_lim31_enabled() &&
                     host::lazy_lim31_modulus(mod.value))
                     b.lim = 31;
             host::run_transform_lazy<T, INV>(b, 0u, 0u, stream, plan.mode != PLAN_NONE ? tl2 : 0);

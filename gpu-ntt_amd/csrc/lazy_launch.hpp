@@ -234,8 +234,10 @@ namespace gpuntt
         extern template void launch_pass_lazy_lim<false, 8>(const Pass&, bool, bool, const kern::LazyArgsT<uint64_t>&, hipStream_t);
         extern template void launch_pass_lazy_lim<true, 8>(const Pass&, bool, bool, const kern::LazyArgsT<uint64_t>&, hipStream_t);
         extern template void launch_pass_lazy_lim<false, 4>(const Pass&, bool, bool, const kern::LazyArgsT<uint64_t>&, hipStream_t);
-        extern template void launch_pass_lazy_lim<false, 31>(const Pass&, bool, bool, const kern::LazyArgsT<uint64_t>&, hipStream_t);
-        // forward transforms of a modulus with 31 q < 2^64 on 4096-coefficient tiles take the LIMIT = 31 kernels
+        // LIMIT = 31 forward kernels on any 64-bit tile size (4096 / 8192 / 16384 coefficients)
+        void launch_pass_lazy31(const Pass& p, int tile_log, bool in_first, bool last, const kern::LazyArgsT<uint64_t>& a,
+                                hipStream_t stream);
+        // forward transforms of a modulus with 31 q < 2^64 take the LIMIT = 31 kernels
         // (GPUNTT_LIM31=0 switches that off for A/B timing)
         bool lazy_lim31_enabled();
         int lazy_pipe_env();
@@ -256,7 +258,9 @@ namespace gpuntt
         inline void run_transform_lazy(kern::LazyArgsT<T> base, unsigned first_in_flags,
                                        unsigned last_out_flags, hipStream_t stream, int forced_tl = 0)
         {
-            const int tl = base.lim ? 12 : (forced_tl ? forced_tl : lazy_tile_log<T>(base.n, INV, base.total >> base.n));
+            const int tl = (base.lim && base.lim != 31)
+                               ? 12
+                               : (forced_tl ? forced_tl : lazy_tile_log<T>(base.n, INV, base.total >> base.n));
             const Plan pl = make_plan_tl(base.n, tl, tl == 12 ? lazy_contig_k(base.n) : tl);
             if constexpr (sizeof(T) == 8)
             {
@@ -303,7 +307,7 @@ namespace gpuntt
                     else if (base.lim == 31)
                     {
                         if constexpr (!INV)
-                            launch_pass_lazy_lim<false, 31>(p, i == 0, i == pl.count - 1, a, stream);
+                            launch_pass_lazy31(p, tlp, i == 0, i == pl.count - 1, a, stream);
                         else
                             throw std::invalid_argument("internal: the 31 q range serves forward transforms only");
                     }

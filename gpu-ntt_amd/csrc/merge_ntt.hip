@@ -135,9 +135,9 @@ namespace gpuntt
             int lim = (mods == nullptr) ? needs_lim<TU>(m) : 0;
             const bool inverse = ninv_dev != nullptr || ninv_single != nullptr;
             const int tl = lim ? 12 : host::lazy_tile_log<TU>(n_power, inverse, static_cast<unsigned long long>(batch_size));
-            // forward, host-side modulus with 31 q < 2^64, 4096-coefficient tiles: the LIMIT = 31 kernels
+            // forward, host-side modulus with 31 q < 2^64: the LIMIT = 31 kernels
             if constexpr (sizeof(TU) == 8)
-                if (lim == 0 && mods == nullptr && !inverse && tl == 12 && host::lazy_lim31_enabled() &&
+                if (lim == 0 && mods == nullptr && !inverse && host::lazy_lim31_enabled() &&
                     host::lazy_lim31_modulus(m.value))
                     lim = 31;
             const int perm_tile_log = (n_power >= tl) ? tl : 0;
@@ -745,8 +745,8 @@ namespace gpuntt
             p->tile_log = p->lim ? 12 : host::lazy_tile_log<T>(n_power, inverse, static_cast<unsigned long long>(batch_hint));
             if constexpr (sizeof(T) == 8)
             {
-                // forward plans whose every modulus has 31 q < 2^64: the LIMIT = 31 kernels (4096-coefficient tiles)
-                bool wide = fast && p->lim == 0 && !inverse && p->tile_log == 12 && host::lazy_lim31_enabled();
+                // forward plans whose every modulus has 31 q < 2^64: the LIMIT = 31 kernels
+                bool wide = fast && p->lim == 0 && !inverse && host::lazy_lim31_enabled();
                 for (int i = 0; wide && i < mod_count; i++)
                     wide = host::lazy_lim31_modulus(p->moduli[i].value);
                 if (wide)
