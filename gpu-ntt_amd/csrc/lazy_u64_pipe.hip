@@ -34,7 +34,8 @@ namespace gpuntt
             const unsigned long long polys = a.total >> a.n;
             if ((polys << a.n) != a.total || polys > 0x7fffffffull)
                 return 0;
-            unsigned stride = static_cast<unsigned>(2 * device_cu_count()) >> (a.n - 12);
+            // GPUNTT_PIPE=3: the variant without prefetch, three resident workgroups per CU
+            unsigned stride = static_cast<unsigned>((env == 3 ? 3 : 2) * device_cu_count()) >> (a.n - 12);
             const unsigned mc = a.mods != nullptr ? static_cast<unsigned>(a.mod_count) : 1u;
             stride -= stride % mc;
             if (stride == 0)
@@ -60,12 +61,25 @@ namespace gpuntt
             if (stride == 0)
                 return false;
             const unsigned grid = stride << (a.n - 12);
+            const bool prefetch = lazy_pipe_env() != 3;
             if constexpr (!INV)
-                hipLaunchKernelGGL((kern::merge_contig_pipe<uint64_t, false, 10, lazy::Mod<uint64_t>::LIMIT, true>),
-                                   dim3(grid), dim3(256), 0, stream, a);
+            {
+                if (prefetch)
+                    hipLaunchKernelGGL((kern::merge_contig_pipe<uint64_t, false, 10, lazy::Mod<uint64_t>::LIMIT, true, true>),
+                                       dim3(grid), dim3(256), 0, stream, a);
+                else
+                    hipLaunchKernelGGL((kern::merge_contig_pipe<uint64_t, false, 10, lazy::Mod<uint64_t>::LIMIT, true, false>),
+                                       dim3(grid), dim3(256), 0, stream, a);
+            }
             else
-                hipLaunchKernelGGL((kern::merge_contig_pipe<uint64_t, true, 10, 1, false>), dim3(grid), dim3(256), 0,
-                                   stream, a);
+            {
+                if (prefetch)
+                    hipLaunchKernelGGL((kern::merge_contig_pipe<uint64_t, true, 10, 1, false, true>), dim3(grid), dim3(256),
+                                       0, stream, a);
+                else
+                    hipLaunchKernelGGL((kern::merge_contig_pipe<uint64_t, true, 10, 1, false, false>), dim3(grid),
+                                       dim3(256), 0, stream, a);
+            }
             GPUNTT_HIP_CHECK(hipGetLastError());
             return true;
         }

@@ -35,8 +35,10 @@ namespace gpuntt
 {
     namespace kern
     {
-        template <typename T, bool INV, int K, int IN_BOUND, bool LAST>
-        __global__ __launch_bounds__(256, 2) void merge_contig_pipe(LazyArgsT<T> a)
+        // PREFETCH: request the next polynomial's coefficients before the current butterflies (32 more VGPRs: two
+        // waves per SIMD); without it the kernel fits three waves per SIMD and only keeps the twiddles resident
+        template <typename T, bool INV, int K, int IN_BOUND, bool LAST, bool PREFETCH = true>
+        __global__ __launch_bounds__(256, (PREFETCH ? 2 : 3)) void merge_contig_pipe(LazyArgsT<T> a)
         {
 #if defined(__HIP_DEVICE_COMPILE__)
             constexpr int TLOG = 12;
@@ -144,6 +146,7 @@ namespace gpuntt
                 return (static_cast<unsigned long long>(p) << a.n) + tb + io_lane;
             };
             T nxt[EPT];
+            if constexpr (PREFETCH)
             {
                 const T* g = src + tile_base(0);
 #pragma unroll
@@ -153,16 +156,26 @@ namespace gpuntt
             for (unsigned i = 0; i < count; i++)
             {
                 T v[EPT];
-#pragma unroll
-                for (int j = 0; j < EPT; j++)
-                    v[j] = nxt[j];
                 const unsigned long long out_base = tile_base(i);
-                if (i + 1u < count)
+                if constexpr (PREFETCH)
                 {
-                    const T* g = src + tile_base(i + 1u);
 #pragma unroll
                     for (int j = 0; j < EPT; j++)
-                        nxt[j] = ld_stream<(IN_BOUND == 1), false>(g + (j << IOW));
+                        v[j] = nxt[j];
+                    if (i + 1u < count)
+                    {
+                        const T* g = src + tile_base(i + 1u);
+#pragma unroll
+                        for (int j = 0; j < EPT; j++)
+                            nxt[j] = ld_stream<(IN_BOUND == 1), false>(g + (j << IOW));
+                    }
+                }
+                else
+                {
+                    const T* g = src + out_base;
+#pragma unroll
+                    for (int j = 0; j < EPT; j++)
+                        v[j] = ld_stream<(IN_BOUND == 1), false>(g + (j << IOW));
                 }
                 static_for<NR>([&](auto r_) {
                     constexpr int r = decltype(r_)::value;

@@ -45,3 +45,14 @@ def test_gpu_4step_example(logn, batch):
     out = _run("example_4step_ntt", logn, batch)
     assert "All Correct." in out and "All Correct (inverse)." in out
     assert "All Correct (natural order, one call)." in out
+
+
+@pytest.mark.gpu
+def test_native_benchmark_program_runs():
+    """tests/cpp/bench_ntt.cpp (the reference benchmark's axes timed from C++: drop-in call, plan, plan replayed
+    from a hipGraph) -- a short run of each algorithm; one JSON object per ring size"""
+    import json
+    for algo, dt, first, last in (("merge", "u64", 12, 14), ("merge", "u32", 16, 16), ("4step", "u64", 12, 13)):
+        lines = [json.loads(l) for l in _run("bench_ntt", algo, dt, first, last, 1, 32).splitlines() if l.startswith("{")]
+        assert [d["log2N"] for d in lines] == list(range(first, last + 1))
+        assert all(d["us"] > 0 and d["plan_us"] > 0 and d["graph_us"] > 0 for d in lines)
