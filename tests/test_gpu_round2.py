@@ -705,3 +705,39 @@ print("31q switch OK")
 '''
     for env in ({"GPUNTT_LIM31": "0"}, {"GPUNTT_LIM31": "1"}, {"GPUNTT_LIM31": "1", "GPUNTT_PATH": "fast-strict"}):
         assert "31q switch OK" in _run_in_subprocess(code, env)
+
+
+def test_31q_range_at_its_boundary(g):
+    """The largest NTT primes at or below (2^64 - 1) / 31 leave the LIMIT = 31 kernels no slack (31 q is within
+    2^17 * 31 of 2^64), the next ones above take the 16 q kernels: worst-case inputs (all q - 1, alternating 0 / q - 1)
+    and random ones against the oracle, single pass, two passes and the big tiles."""
+    from gpu_utils import _is_probable_prime
+    bound = (2**64 - 1) // 31
+
+    def factors(logn, below):
+        step = 1 << (logn + 1)
+        q = bound // step * step + 1
+        while (q > bound) if below else (q <= bound):
+            q += -step if below else step
+        while not _is_probable_prime(q):
+            q += -step if below else step
+        assert (q <= bound) == below
+        gen = 2
+        while True:
+            psi = pow(gen, (q - 1) >> (logn + 1), q)
+            if pow(psi, 1 << logn, q) == q - 1:
+                return q, psi * psi % q, psi
+            gen += 1
+
+    for logn in (12, 13, 16):
+        for below in (True, False):
+            f = factors(logn, below)
+            for poly in (O.X_N_minus, O.X_N_plus):
+                c = MergeCase(g, 64, logn, poly, f)
+                n, q = c.n, c.q
+                worst = [np.full(n, q - 1, dtype=object), np.array([0, q - 1] * (n // 2), dtype=object),
+                         np.array([q - 1, 0] * (n // 2), dtype=object)]
+                x = np.concatenate([np.concatenate(worst).astype(c.P.T), c.random(2, 3 + logn)])
+                want = c.P.merge_ntt(x, c.oprm)
+                assert np.array_equal(c.gpu_forward(x), want), (logn, below, poly)
+                assert np.array_equal(c.gpu_inverse(want, inplace=True), x), (logn, below, poly)
