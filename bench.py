@@ -511,6 +511,19 @@ def main():
         if isinstance(other, float):
             line["other_api_ms_per_call"] = {"api": "plan" if args.api == "dropin" else "dropin", "ms": other}
         if power is not None:
+            if bits == 64 and isinstance(power.get("cap_w"), float) and traffic:
+                # what the measured bytes and the butterflies of one step cost by the per-byte / per-butterfly energies
+                # measured on this part (profiles/r02_power.txt: device copy 0.12 nJ per byte through L2 / fabric / HBM;
+                # profiles/ubench_bfly_r02.txt: register-only 64-bit lazy butterflies 29 nJ per wave of 64; idle 261 W)
+                wave_bfly = per_step * (n // 2) * logn / 64.0
+                dyn_j = float(traffic) * 0.12e-9 + wave_bfly * 29e-9
+                power["energy_model"] = {
+                    "dynamic_j_per_step": dyn_j,
+                    "ms_per_step_at_cap": dyn_j / (power["cap_w"] - 261.0) * 1e3,
+                    "inputs": {"hbm_bytes": float(traffic), "nj_per_byte": 0.12, "wave_butterflies": wave_bfly,
+                               "nj_per_wave_butterfly": 29.0, "idle_w": 261.0},
+                    "note": "time the dynamic energy of one step takes at the socket cap: the bound these "
+                            "transforms run into (sustained loop: ms_per_step_while_sampling)"}
             line["power"] = power
         if e2e is not None:
             line["end_to_end"] = e2e
