@@ -255,6 +255,9 @@ namespace gpuntt
                 if (mods_dev == nullptr && host::lazy_lim31_enabled() &&
                     host::lazy_lim31_modulus(mod.value))
                     b.lim = 31;
+            if constexpr (sizeof(T) == 4)
+                if (mods_dev == nullptr && host::lazy_lim31_enabled() && host::lazy_wide_modulus32(mod.value))
+                    b.lim = 8;
             host::run_transform_lazy<T, INV>(b, 0u, 0u, stream, plan.mode != PLAN_NONE ? tl2 : 0);
             return true;
         }

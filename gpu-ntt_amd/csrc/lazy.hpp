@@ -191,12 +191,12 @@ namespace gpuntt
         {
         };
 
-        // ---- 32-bit: exact-quotient Shoup product in [0, 2q); q < 2^30 => LIMIT 4 ------------
-        template <> struct Mod<uint32_t, 0>
+        // ---- 32-bit: exact-quotient Shoup product in [0, 2q); q < 2^30 => LIMIT 4, q < 2^29 => LIMIT 8 --------
+        template <int LIM> struct Mod32
         {
             static constexpr int TB = 2;
-            static constexpr int LIMIT = 4;
-            static constexpr int MAX_BIT = 30;
+            static constexpr int LIMIT = LIM;
+            static constexpr int MAX_BIT = (LIM == 8) ? 29 : 30;
             uint32_t q;
 
             __device__ __forceinline__ void set(uint32_t modulus, const NormConst&) { q = modulus; }
@@ -221,6 +221,14 @@ namespace gpuntt
                 const uint32_t d = x - kq(K);
                 return d < x ? d : x;
             }
+        };
+        template <> struct Mod<uint32_t, 0> : Mod32<4>
+        {
+        };
+        // moduli below 2^29 (the reference's 32-bit pools: 469762049, ...): twice the headroom, a range correction
+        // every third forward stage instead of every stage (host-side switch, lim = 8; both directions)
+        template <> struct Mod<uint32_t, 8> : Mod32<8>
+        {
         };
 
         // [0, B*q) -> [0, q)

@@ -240,6 +240,16 @@ namespace gpuntt
         // forward transforms of a modulus with 31 q < 2^64 take the LIMIT = 31 kernels
         // (GPUNTT_LIM31=0 switches that off for A/B timing)
         bool lazy_lim31_enabled();
+        // 32-bit words, every modulus of the call below 2^29: the LIMIT = 8 kernels (both directions, both tiles);
+        // switched together with the 31 q range (GPUNTT_LIM31=0)
+        template <bool INV>
+        void launch_pass_lazy_u32w(const Pass& p, int tile_log, bool in_first, bool last,
+                                   const kern::LazyArgsT<uint32_t>& a, hipStream_t stream);
+        template <>
+        void launch_pass_lazy_u32w<false>(const Pass&, int, bool, bool, const kern::LazyArgsT<uint32_t>&, hipStream_t);
+        template <>
+        void launch_pass_lazy_u32w<true>(const Pass&, int, bool, bool, const kern::LazyArgsT<uint32_t>&, hipStream_t);
+        inline bool lazy_wide_modulus32(uint32_t q) { return q >= 3 && q < (1u << 29); }
         int lazy_pipe_env();
         inline bool lazy_lim31_modulus(uint64_t q) { return q >= 3 && q <= 0xffffffffffffffffull / 31; }
         extern template void launch_pass_lazy_lim<true, 4>(const Pass&, bool, bool, const kern::LazyArgsT<uint64_t>&, hipStream_t);
@@ -258,7 +268,7 @@ namespace gpuntt
         inline void run_transform_lazy(kern::LazyArgsT<T> base, unsigned first_in_flags,
                                        unsigned last_out_flags, hipStream_t stream, int forced_tl = 0)
         {
-            const int tl = (base.lim && base.lim != 31)
+            const int tl = (sizeof(T) == 8 && base.lim && base.lim != 31)
                                ? 12
                                : (forced_tl ? forced_tl : lazy_tile_log<T>(base.n, INV, base.total >> base.n));
             const Plan pl = make_plan_tl(base.n, tl, tl == 12 ? lazy_contig_k(base.n) : tl);
@@ -315,7 +325,12 @@ namespace gpuntt
                         launch_pass_lazy<T, INV>(p, tlp, i == 0, i == pl.count - 1, a, stream);
                 }
                 else
-                    launch_pass_lazy<T, INV>(p, tlp, i == 0, i == pl.count - 1, a, stream);
+                {
+                    if (base.lim == 8)
+                        launch_pass_lazy_u32w<INV>(p, tlp, i == 0, i == pl.count - 1, a, stream);
+                    else
+                        launch_pass_lazy<T, INV>(p, tlp, i == 0, i == pl.count - 1, a, stream);
+                }
                 src = base.out;
             }
         }

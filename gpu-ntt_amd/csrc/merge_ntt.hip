@@ -140,6 +140,10 @@ namespace gpuntt
                 if (lim == 0 && mods == nullptr && !inverse && host::lazy_lim31_enabled() &&
                     host::lazy_lim31_modulus(m.value))
                     lim = 31;
+            // 32-bit words, host-side modulus below 2^29: the LIMIT = 8 kernels (both directions)
+            if constexpr (sizeof(TU) == 4)
+                if (mods == nullptr && host::lazy_lim31_enabled() && host::lazy_wide_modulus32(m.value))
+                    lim = 8;
             const int perm_tile_log = (n_power >= tl) ? tl : 0;
             const size_t entries = (static_cast<size_t>(mod_count) << n_power) + mod_count;
             // workspace: twiddle pairs | n^-1 pairs | go-flag | per-modulus normalisation constants |
@@ -751,6 +755,14 @@ namespace gpuntt
                     wide = host::lazy_lim31_modulus(p->moduli[i].value);
                 if (wide)
                     p->lim = 31;
+            }
+            else
+            {
+                bool wide = fast && host::lazy_lim31_enabled();
+                for (int i = 0; wide && i < mod_count; i++)
+                    wide = host::lazy_wide_modulus32(p->moduli[i].value);
+                if (wide)
+                    p->lim = 8;
             }
             const PlanLayout<T> lay(n_power, mod_count);
             if (workspace_device != nullptr)

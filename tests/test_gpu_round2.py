@@ -679,9 +679,10 @@ def test_fourstep_2_24_from_device_generated_tables(g):
 
 
 def test_31q_range_switch(g):
-    """Forward transforms of moduli with 31 q < 2^64 (every pool prime) take the LIMIT = 31 kernels on
-    4096-coefficient tiles; GPUNTT_LIM31=0 keeps them on the 16 q kernels.  Both must equal the oracle, and a
-    60-bit prime above 2^64 / 31 must stay on the 16 q kernels (and equal the oracle too)."""
+    """Forward transforms of 64-bit moduli with 31 q < 2^64 (every pool prime) take the LIMIT = 31 kernels, 32-bit
+    moduli below 2^29 the LIMIT = 8 kernels (both directions); GPUNTT_LIM31=0 keeps both on the default ranges.
+    All must equal the oracle, and a 60-bit prime above 2^64 / 31 / a 30-bit prime must stay on the default
+    kernels (and equal the oracle too)."""
     from test_gpu_merge import _run_in_subprocess
     code = r'''
 import numpy as np, sys, os
@@ -696,6 +697,21 @@ for logn, batch in ((9, 9), (12, 5), (16, 7), (17, 3), (20, 2)):
         assert c.q <= (2**64 - 1) // 31
         x = c.random(batch, 77 + logn)
         assert np.array_equal(c.gpu_forward(x, inplace=bool(logn & 1)), c.P.merge_ntt(x, c.oprm)), (logn, poly)
+# 32-bit words: pool prime below 2^29 (LIMIT = 8 kernels when switched on), 4096- and 16384-coefficient tiles
+for logn, batch in ((9, 9), (12, 5), (14, 6), (16, 4), (20, 2)):
+    for poly in (O.X_N_minus, O.X_N_plus):
+        c = MergeCase(g, 32, logn, poly)
+        assert c.q < 2**29
+        x = c.random(batch, 177 + logn)
+        want = c.P.merge_ntt(x, c.oprm)
+        assert np.array_equal(c.gpu_forward(x, inplace=bool(logn & 1)), want), (32, logn, poly)
+        assert np.array_equal(c.gpu_inverse(want, inplace=not (logn & 1)), x), (32, logn, poly)
+        assert np.array_equal(c.gpu_inverse(x), c.P.merge_ntt(x, c.oprm, inverse=True)), (32, logn, poly)
+f32 = find_ntt_factors(30, 14)  # a 30-bit prime keeps the 4 q kernels
+c = MergeCase(g, 32, 14, O.X_N_plus, f32)
+x = c.random(3, 6)
+assert np.array_equal(c.gpu_forward(x), c.P.merge_ntt(x, c.oprm))
+assert np.array_equal(c.gpu_inverse(x), c.P.merge_ntt(x, c.oprm, inverse=True))
 f = find_ntt_factors(60, 16)
 assert f[0] > (2**64 - 1) // 31
 c = MergeCase(g, 64, 16, O.X_N_plus, f)
