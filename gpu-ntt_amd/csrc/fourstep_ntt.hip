@@ -236,7 +236,7 @@ namespace gpuntt
             a.poly_shift = n_power;
             a.mod_count = 1;
             a.p_lo = 0;
-            a.flags = 0u;
+            a.flags = host::lazy_order_flags();
             host::launch_fourstep_phase1_lazy<T, INV>(log_n1, a, stream);
 
             // phase 2: n2-point transforms of the batch * n1 rows of `out`, in place
@@ -316,7 +316,7 @@ namespace gpuntt
             a.poly_shift = n_power;
             a.mod_count = 1;
             a.p_lo = log_n2;
-            a.flags = 0u;
+            a.flags = host::lazy_order_flags();
             host::launch_fourstep_nat_p1_lazy<T>(log_n1, a, stream);
 
             // rows of length n2
@@ -402,7 +402,7 @@ namespace gpuntt
             a.poly_shift = n_power;
             a.mod_count = 1;
             a.p_lo = 0;
-            a.flags = 0u;
+            a.flags = host::lazy_order_flags();
             const int k_first = (log_n2 > 9) ? 8 : log_n2;
             host::launch_fourstep_nat_first_inv_lazy<T>(k_first, a, stream);
 

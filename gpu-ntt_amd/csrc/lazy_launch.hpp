@@ -240,6 +240,7 @@ namespace gpuntt
         // forward transforms of a modulus with 31 q < 2^64 take the LIMIT = 31 kernels
         // (GPUNTT_LIM31=0 switches that off for A/B timing)
         bool lazy_lim31_enabled();
+        unsigned lazy_order_flags(); // F_PLAIN_ORDER if GPUNTT_XCD_ORDER=0
         // 32-bit words, every modulus of the call below 2^29: the LIMIT = 8 kernels (both directions, both tiles);
         // switched together with the 31 q range (GPUNTT_LIM31=0)
         template <bool INV>
@@ -291,6 +292,7 @@ namespace gpuntt
                 kern::LazyArgsT<T> a = base;
                 a.in = src;
                 a.p_lo = p.p_lo;
+                a.flags |= lazy_order_flags();
                 if (i == 0)
                     a.flags |= first_in_flags;
                 if (i == pl.count - 1)

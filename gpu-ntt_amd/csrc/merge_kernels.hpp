@@ -50,7 +50,8 @@ namespace gpuntt
             F_FOURSTEP_T = 16u, // 4-step phase 1: transposed store with W multiply
             F_MULTI = 32u, // a tile may span polynomials with different moduli (RNS, N < tile)
             F_REVERSE = 128u, // fast kernels: walk the tiles from the last to the first (see run_transform_lazy)
-            F_COLMOD = 64u // PerCoefficient RNS: the modulus follows the COLUMN (flat & (2^n2_log - 1)) % mod_count
+            F_COLMOD = 64u, // PerCoefficient RNS: the modulus follows the COLUMN (flat & (2^n2_log - 1)) % mod_count
+            F_PLAIN_ORDER = 256u // fast kernels: poly-minor block order without the XCD grouping (GPUNTT_XCD_ORDER=0, A/B timing)
         };
 
         template <typename T> struct PassArgs

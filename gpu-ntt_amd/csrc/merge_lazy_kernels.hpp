@@ -904,16 +904,19 @@ namespace gpuntt
         // to back), XCD-aware: the dispatcher sends workgroup b to XCD b % 8 and every XCD has its own L2, so a
         // slice shared by consecutive block indices is fetched from the fabric once per XCD -- up to 8 times
         // (PMC, C3 phase 1: 2.15 GB of W fetched for a 256 MiB table).  With 8 | tiles the tile index takes its
-        // low three bits from b % 8, so all polynomials of a tile position run on ONE XCD and its slice crosses the
-        // fabric once.  Falls back to the plain order for rings of fewer than 8 tiles.
+        // TOP three bits from b % 8, so all polynomials of a tile position run on ONE XCD and its slice crosses the
+        // fabric once, and the eight tiles in flight at a time lie an eighth of the ring apart (in the low bits
+        // they would be neighbouring 512-byte runs of the same rows in a strided pass -- one HBM channel for all
+        // eight XCDs: the natural-order forward 4-step ran 9 % slower that way).  Falls back to the plain order
+        // for rings of fewer than 8 tiles.
         __device__ __forceinline__ void poly_minor_order(unsigned bx, unsigned batch, int tiles_log, unsigned& poly,
-                                                         unsigned& tile)
+                                                         unsigned& tile, unsigned flags = 0u)
         {
-            if (tiles_log >= 3)
+            if (tiles_log >= 3 && (flags & F_PLAIN_ORDER) == 0u)
             {
                 const unsigned x = bx & 7u, k = bx >> 3;
                 poly = k % batch;
-                tile = ((k / batch) << 3) | x;
+                tile = (x << (tiles_log - 3)) | (k / batch);
             }
             else
             {
@@ -951,7 +954,7 @@ namespace gpuntt
             if (a.batch > 1)
             {
                 unsigned poly, tile;
-                poly_minor_order(bx, static_cast<unsigned>(a.batch), a.n - TLOG, poly, tile);
+                poly_minor_order(bx, static_cast<unsigned>(a.batch), a.n - TLOG, poly, tile, a.flags);
                 blk = static_cast<long long>((static_cast<unsigned long long>(poly) << (a.n - TLOG)) | tile);
             }
             if (a.mods != nullptr)
@@ -1149,7 +1152,9 @@ namespace gpuntt
             constexpr bool NEEDS_LDS = (G::NR > 1) || (SCH::wl_of(0) < 4);
             __shared__ T lds[NEEDS_LDS ? LTile<TLOG>::LDS_ELEMS : 1];
             unsigned poly, tile;
-            poly_minor_order(blockIdx.x, static_cast<unsigned>(a.batch), a.n - TLOG, poly, tile);
+            // plain order here: with the XCD grouping this strided column pass measured 8 % slower at batch 64 (12.58 ->
+            // 13.64 ms for the whole natural-order forward transform, A/B GPUNTT_XCD_ORDER on one box)
+            poly_minor_order(blockIdx.x, static_cast<unsigned>(a.batch), a.n - TLOG, poly, tile, a.flags | F_PLAIN_ORDER);
             const long long blk = static_cast<long long>((static_cast<unsigned long long>(poly) << (a.n - TLOG)) | tile);
             pass_body<T, TLOG, false, false, false, K, 1, false, 0, true>(a, lds, a.q, a.q_bit, a.q_mu, 0, 0, 0, blk);
         }
@@ -1198,7 +1203,7 @@ namespace gpuntt
             constexpr bool NEEDS_LDS = (G::NR > 1) || (SCH::wl_of(0) < 4);
             __shared__ T lds[NEEDS_LDS ? LTile<TLOG>::LDS_ELEMS : 1];
             unsigned poly, tile;
-            poly_minor_order(blockIdx.x, static_cast<unsigned>(a.batch), a.n - TLOG, poly, tile);
+            poly_minor_order(blockIdx.x, static_cast<unsigned>(a.batch), a.n - TLOG, poly, tile, a.flags);
             const long long blk = static_cast<long long>((static_cast<unsigned long long>(poly) << (a.n - TLOG)) | tile);
             pass_body<T, TLOG, false, true, false, K, M::TB, true, 0, true>(a, lds, a.q, a.q_bit, a.q_mu, 0, 0, 0, blk);
         }
@@ -1220,7 +1225,7 @@ namespace gpuntt
                 qm = md.mu;
             }
             unsigned poly, tile;
-            poly_minor_order(blockIdx.x, static_cast<unsigned>(a.batch), a.poly_shift - TLOG, poly, tile);
+            poly_minor_order(blockIdx.x, static_cast<unsigned>(a.batch), a.poly_shift - TLOG, poly, tile, a.flags);
             pass_body<T, TLOG, false, INV, true, K, 1, false, true>(a, lds, qv, qb, qm, 0, poly, tile);
         }
 

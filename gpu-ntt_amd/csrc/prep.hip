@@ -373,6 +373,15 @@ namespace gpuntt
             return 12;
         }
 
+        unsigned lazy_order_flags()
+        {
+            static const unsigned v = [] {
+                const char* e = std::getenv("GPUNTT_XCD_ORDER");
+                return (e != nullptr && std::atoi(e) == 0) ? static_cast<unsigned>(kern::F_PLAIN_ORDER) : 0u;
+            }();
+            return v;
+        }
+
         bool lazy_lim31_enabled()
         {
             static const bool v = [] {
