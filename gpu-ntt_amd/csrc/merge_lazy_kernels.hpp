@@ -226,6 +226,8 @@ namespace gpuntt
             }
             static constexpr Data d = make();
             static_assert(d.final_bound <= LIMIT, "lazy bound exceeds the headroom");
+            // inverse passes are instantiated with IN_BOUND = LIMIT / 2 behind another inverse pass (lazy_launch_impl.hpp)
+            static_assert(!INV || d.final_bound <= LIMIT / 2, "an inverse pass must hand over values below LIMIT / 2");
         };
 
         // waves per SIMD requested from the register allocator: four 256-thread tiles per CU
