@@ -22,6 +22,7 @@ namespace gpuntt
             bool contig;
             int k;    // stages
             int p_lo; // STRIDED: lowest global stage position
+            int in_b = 0; // fast path, forward: range bound (units of q) of the values this pass reads, 0 = not tracked
         };
 
         struct Plan

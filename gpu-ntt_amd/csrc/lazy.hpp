@@ -53,16 +53,20 @@ namespace gpuntt
         // constants of the one-multiply final normalisation (64-bit only): for x < 16 q
         //   k = ((x >> sh) * M) >> (32 + c)  is floor(x / q) or one less, so x - k*q is in [0, 2q)
         // with sh = max(bit - 27, 0), qt = (q >> sh) + [sh > 0], c = bit - 1 - sh, M = floor(2^(32+c) / qt)
+        // Moduli of 48 bits and more take the estimate from the HIGH WORD of x alone (sh = 32: no 64-bit shift;
+        // qt = (q >> 32) + 1 still has >= 15 bits, so k * 2^-15 < 1 for k < 32 and the estimate stays
+        // floor(x / q) or one less): `hi` = 1, same formulas.
         struct NormConst
         {
-            uint32_t sh, c, M, pad;
+            uint32_t sh, c, M, hi;
         };
         __host__ __device__ inline NormConst make_norm_const(uint64_t q, uint64_t bit)
         {
             NormConst n{0, 0, 0, 0};
             if (q < 3 || bit < 2 || bit > 61)
                 return n;
-            n.sh = bit > 27 ? static_cast<uint32_t>(bit - 27) : 0u;
+            n.hi = bit >= 48 ? 1u : 0u;
+            n.sh = n.hi ? 32u : (bit > 27 ? static_cast<uint32_t>(bit - 27) : 0u);
             const uint64_t qt = (q >> n.sh) + (n.sh > 0 ? 1u : 0u); // exact when nothing is shifted out
             n.c = static_cast<uint32_t>(bit - 1 - n.sh);
             const uint64_t m = (1ull << (32 + n.c)) / qt;
@@ -102,22 +106,27 @@ namespace gpuntt
             uint64_t q;
             uint64_t qneg; // 2^64 - q
             NormConst nc;
+            uint32_t zero; // 0, pinned to v127 where the quotient chain needs a zero high word (mul_acc_raw)
 
             __device__ __forceinline__ void set(uint64_t modulus, const NormConst& n)
             {
                 q = modulus;
                 qneg = 0 - modulus;
                 nc = n;
+                // opaque to the optimiser: a constant 0 would be re-materialised (one v_mov per use)
+                asm("v_mov_b32 %0, 0" : "=v"(zero));
             }
-            // x < 16 q  ->  [0, 2q): quotient estimate from the top bits, one 32 x 64 multiply-subtract
-            __device__ __forceinline__ uint64_t reduce_2q(uint64_t x) const
+            // x < 32 q  ->  [0, 2q): quotient estimate from the top bits, one 32 x 64 multiply-subtract.
+            // HI: the modulus has >= 48 bits (nc.hi), the top bits are the high word as it stands
+            template <bool HI = false> __device__ __forceinline__ uint64_t reduce_2q(uint64_t x) const
             {
-                const uint32_t xt = static_cast<uint32_t>(x >> nc.sh);
+                const uint32_t xt = HI ? hi32(x) : static_cast<uint32_t>(x >> nc.sh);
                 const uint32_t k = __umulhi(xt, nc.M) >> nc.c;
                 const uint64_t r = static_cast<uint64_t>(k) * lo32(qneg) + x; // v_mad_u64_u32
                 return r + (static_cast<uint64_t>(k * hi32(qneg)) << 32);
             }
             __device__ __forceinline__ uint64_t kq(int k) const { return q * static_cast<uint64_t>(k); }
+            __device__ __forceinline__ bool hi_norm() const { return nc.hi != 0u; } // wave-uniform
 
             // acc + x * w - qh * q  (mod 2^64)  =  acc + T  with  T = x * w (mod q) + {0..3} q  in [0, 4q),
             // for any x < 2^64: 11 instructions, the 64-bit add of the butterfly included --
@@ -141,21 +150,45 @@ namespace gpuntt
             __device__ __forceinline__ uint64_t mul_acc_raw(uint64_t x, const Tw64& t, uint64_t acc) const
             {
                 const uint32_t x0 = lo32(x), x1 = hi32(x);
-                const uint32_t h1 = __umulhi(x1, lo32(t.wp)), h2 = __umulhi(x0, hi32(t.wp));
-                uint64_t qh = static_cast<uint64_t>(x1) * hi32(t.wp) + h1;
+                const uint32_t h2 = __umulhi(x0, hi32(t.wp));
+                // qh = x1 * wp1 + hi32(x1 * wp0): the 64-bit addend {h1, 0} is the fixed pair v[126:127] whose
+                // high half holds `zero` for the whole kernel (the "{v127}" operand), so the zero extension of
+                // h1 costs nothing -- the compiler's own form re-creates the pair with a v_mov per butterfly
+                // (80 of 1640 VALU instructions per wave in the 10-stage pass).  Every 64-bit kernel is built
+                // for 4 waves per SIMD = a 128-VGPR budget, so v126 / v127 exist.
+                uint64_t qh, carry;
+                if constexpr (UNI)
+                    asm("v_mul_hi_u32 v126, %2, %3\n\tv_mad_u64_u32 %0, %1, %2, %4, v[126:127]"
+                        : "=v"(qh), "=s"(carry)
+                        : "v"(x1), "s"(lo32(t.wp)), "s"(hi32(t.wp)), "{v127}"(zero)
+                        : "v126");
+                else
+                    asm("v_mul_hi_u32 v126, %2, %3\n\tv_mad_u64_u32 %0, %1, %2, %4, v[126:127]"
+                        : "=v"(qh), "=s"(carry)
+                        : "v"(x1), "v"(lo32(t.wp)), "v"(hi32(t.wp)), "{v127}"(zero)
+                        : "v126");
                 // + h2 as a multiply-add by 1: adding a 32-bit value to a 64-bit one otherwise
                 // costs a zero-extending move plus a 64-bit add
-                uint64_t carry;
                 asm("v_mad_u64_u32 %0, %1, %2, 1, %3" : "=v"(qh), "=s"(carry) : "v"(h2), "v"(qh));
                 uint64_t c = mad32z<UNI>(x0, hi32(t.w));
                 c = mad32<UNI>(x1, lo32(t.w), c);
                 c = mad32<true>(lo32(qh), hi32(qneg), c);
                 c = mad32<true>(hi32(qh), lo32(qneg), c);
                 uint64_t a = ZERO ? mad32z<UNI>(x0, lo32(t.w)) : mad32<UNI>(x0, lo32(t.w), acc);
-                a = mad32<true>(lo32(qh), lo32(qneg), a);
+                // the cross sum goes into the accumulator's high word BEFORE the last multiply-add, so the result
+                // leaves the chain as one 64-bit register pair (with the add last, the compiler started the
+                // butterfly's 64-bit subtraction on the halves: a third instruction in a third of the butterflies)
                 uint32_t ah;
                 asm("v_add_u32 %0, %1, %2" : "=v"(ah) : "v"(hi32(a)), "v"(lo32(c)));
-                return (static_cast<uint64_t>(ah) << 32) | lo32(a);
+                a = (static_cast<uint64_t>(ah) << 32) | lo32(a);
+                return mad32<true>(lo32(qh), lo32(qneg), a);
+            }
+            // 2 x + k (k wave-uniform): one v_lshl_add_u64
+            __device__ __forceinline__ uint64_t shl1_add(uint64_t x, uint64_t k) const
+            {
+                uint64_t d;
+                asm("v_lshl_add_u64 %0, %1, 1, %2" : "=v"(d) : "v"(x), "s"(k));
+                return d;
             }
             // x * w  (mod q), any x < 2^64, result in [0, 4q)
             template <bool UNI = false> __device__ __forceinline__ uint64_t mul(uint64_t x, const Tw64& t) const
@@ -202,6 +235,7 @@ namespace gpuntt
             __device__ __forceinline__ void set(uint32_t modulus, const NormConst&) { q = modulus; }
             __device__ __forceinline__ uint32_t reduce_2q(uint32_t x) const { return csub<2>(x); }
             __device__ __forceinline__ uint32_t kq(int k) const { return q * static_cast<uint32_t>(k); }
+            __device__ __forceinline__ bool hi_norm() const { return false; }
 
             template <bool UNI = false> __device__ __forceinline__ uint32_t mul(uint32_t x, const Tw32& t) const
             {
@@ -232,10 +266,11 @@ namespace gpuntt
         };
 
         // [0, B*q) -> [0, q)
-        template <int B, typename MM, typename T> __device__ __forceinline__ T normalize(const MM& m, T x)
+        // HI (64-bit words): the caller found nc.hi set (wave-uniform) -- reduce_2q reads the high word only
+        template <int B, bool HI = false, typename MM, typename T> __device__ __forceinline__ T normalize(const MM& m, T x)
         {
             if constexpr (sizeof(T) == 8 && B > 4)
-                return m.template csub<1>(m.reduce_2q(x)); // 10 instructions instead of 4 x 4
+                return m.template csub<1>(m.template reduce_2q<HI>(x)); // 9-10 instructions instead of 4 x 4
             if constexpr (B > 8)
                 x = m.template csub<8>(x);
             if constexpr (B > 4)

@@ -264,6 +264,17 @@ namespace gpuntt
         extern template bool launch_contig_pipe<false>(const Pass&, bool, bool, const kern::LazyArgsT<uint64_t>&, hipStream_t);
         extern template bool launch_contig_pipe<true>(const Pass&, bool, bool, const kern::LazyArgsT<uint64_t>&, hipStream_t);
 
+        // Range bound (units of q) a forward pass of k stages hands over when it reads values below `bound` -- the
+        // run-time twin of kern::PassSched for Cooley-Tukey passes (every register carries the same bound there).
+        // The last contiguous pass of a two-pass plan is instantiated for the bound it really receives (25 q behind
+        // six strided stages, not the range limit): one round of range corrections less.
+        inline int fwd_bound_after(int bound, int k, int limit, int tb)
+        {
+            for (int s = 0; s < k; s++)
+                bound = lazy::ct_plan(bound, limit, tb).out;
+            return bound;
+        }
+
         // forced_tl: tile size the twiddle table was prepared for (NTTPlan); 0 = choose from the batch
         template <typename T, bool INV>
         inline void run_transform_lazy(kern::LazyArgsT<T> base, unsigned first_in_flags,
@@ -286,9 +297,15 @@ namespace gpuntt
                 }
             }
             const void* src = base.in;
+            int fwd_bound = 1; // range bound of the values in flight (forward, 31 q range: see fwd_bound_after)
             for (int i = 0; i < pl.count; i++)
             {
-                const Pass& p = INV ? pl.pass[pl.count - 1 - i] : pl.pass[i];
+                Pass p = INV ? pl.pass[pl.count - 1 - i] : pl.pass[i];
+                if (!INV && sizeof(T) == 8 && base.lim == 31)
+                {
+                    p.in_b = fwd_bound;
+                    fwd_bound = fwd_bound_after(fwd_bound, p.k, 31, 4);
+                }
                 kern::LazyArgsT<T> a = base;
                 a.in = src;
                 a.p_lo = p.p_lo;

@@ -101,7 +101,13 @@ namespace gpuntt
                             {
                                 case 8: GPUNTT_ONE(true, 8, LIM, true);
                                 case 9: GPUNTT_ONE(true, 9, LIM, true);
-                                case 10: GPUNTT_ONE(true, 10, LIM, true);
+                                case 10:
+                                    // 31 q range behind a strided pass that hands over <= 27 q (two-pass plans
+                                    // of 2^14 .. 2^16: 17 / 21 / 25 q): three rounds of range corrections, not four
+                                    if constexpr (LIM == 31)
+                                        if (p.in_b > 0 && p.in_b <= 27)
+                                            GPUNTT_ONE(true, 10, 27, true);
+                                    GPUNTT_ONE(true, 10, LIM, true);
                                 case 11: GPUNTT_ONE(true, 11, LIM, true);
                                 case 12: GPUNTT_ONE(true, 12, LIM, true);
                                 default: break;

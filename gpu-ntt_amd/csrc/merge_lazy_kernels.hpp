@@ -298,6 +298,17 @@ namespace gpuntt
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
 
+        // Block-uniform values that went through a division or a select end up in vector registers, and so does
+        // every address derived from them (64-bit VALU adds + v_readfirstlane per access).  Reading them back
+        // through v_readfirstlane tells the compiler they are scalar: tile bases, twiddle bases and the modulus
+        // index stay in SGPRs and the address arithmetic moves to the scalar unit.
+        __device__ __forceinline__ unsigned uniform32(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
+        __device__ __forceinline__ unsigned long long uniform64(unsigned long long v)
+        {
+            return (static_cast<unsigned long long>(uniform32(static_cast<unsigned>(v >> 32))) << 32) |
+                   uniform32(static_cast<unsigned>(v));
+        }
+
         template <typename T, int TLOG, bool EXACT, bool INV, bool CONTIG, int K, int IN_BOUND, bool LAST,
                   int FST = 0, bool WMUL = false, bool COH_IN = false, bool PERSIST = false, int LIM = 0>
         __device__ __forceinline__ void pass_body(const LazyArgsT<T>& a, T* lds, T q_value, T q_bit, T q_mu,
@@ -435,9 +446,12 @@ namespace gpuntt
             // 8 waves per SIMD cover the latency)
             constexpr bool TW_AHEAD = (LOcc<TLOG, T>::WAVES <= 4);
 
+            // natural-order inverse 4-step, last pass: the W^-1 pairs of the gather are live first -- the round's own
+            // twiddles are requested behind it (with both in flight the kernel spills)
+            constexpr bool TW0_LATE = WMUL && INV;
             T v[EPT];
             TW tw_next[TW_PER_ROUND];
-            if constexpr (TW_AHEAD)
+            if constexpr (TW_AHEAD && !TW0_LATE)
                 load_twiddles(std::integral_constant<int, 0>{}, tw_next);
 
             static_for<G::NR>([&](auto r_) {
@@ -498,20 +512,23 @@ namespace gpuntt
                             // natural-order inverse 4-step, last pass: W^-1[f mod N] on the way in
                             const unsigned lane = map.part(elem_of<WL>(t, 0));
                             const unsigned long long wb = map.base & nmask;
+                            // quarters of 4 bound the live W pairs (16 VGPRs): with halves of 8 the 64-bit kernels
+                            // spilled once v126 / v127 became the quotient chain's fixed pair (lazy.hpp)
+                            constexpr int QW = (sizeof(T) == 8) ? EPT / 4 : EPT / 2;
 #pragma unroll
-                            for (int half = 0; half < 2; half++)
+                            for (int part = 0; part < EPT / QW; part++)
                             {
-                                TW wv[EPT / 2];
+                                TW wv[QW];
 #pragma unroll
-                                for (int jj = 0; jj < EPT / 2; jj++)
+                                for (int jj = 0; jj < QW; jj++)
                                 {
-                                    const int j = half * (EPT / 2) + jj;
+                                    const int j = part * QW + jj;
                                     wv[jj] = (a.w_pairs + (wb + map.part(static_cast<unsigned>(j) << WL)))[lane];
                                     v[j] = (src + (map.base + map.part(static_cast<unsigned>(j) << WL)))[lane];
                                 }
 #pragma unroll
-                                for (int jj = 0; jj < EPT / 2; jj++)
-                                    v[half * (EPT / 2) + jj] = m.mul(v[half * (EPT / 2) + jj], wv[jj]);
+                                for (int jj = 0; jj < QW; jj++)
+                                    v[part * QW + jj] = m.mul(v[part * QW + jj], wv[jj]);
                             }
                         }
                         else if (plain_io)
@@ -596,6 +613,8 @@ namespace gpuntt
                 }
 
                 TW tw_cur[TW_PER_ROUND];
+                if constexpr (TW_AHEAD && TW0_LATE && r == 0)
+                    load_twiddles(r_, tw_next);
                 if constexpr (TW_AHEAD)
                 {
 #pragma unroll
@@ -645,7 +664,9 @@ namespace gpuntt
                             {
                                 const T nu = unit ? static_cast<T>(U + v[j1]) : m.template mul_acc<UNIFORM_R>(v[j1], tw, U);
                                 v[j0] = nu;
-                                v[j1] = static_cast<T>((U << 1) + m.kq(M::TB) - nu);
+                                // 2 U + TB q as ONE v_lshl_add_u64, then one 64-bit subtract: kept opaque so that
+                                // the sum is not re-associated into shift, subtract, add (a fourth instruction)
+                                v[j1] = static_cast<T>(m.shl1_add(U, m.kq(M::TB)) - nu);
                             }
                             else
                             {
@@ -689,7 +710,22 @@ namespace gpuntt
                     constexpr bool PMUL_OK = LAST && !INV && !FST && !WMUL && !EXACT;
                     const T* mul_in = PMUL_OK ? a.mul_in : nullptr;
                     (void) mul_in;
-                    if constexpr (LAST)
+                    if constexpr (LAST && !INV && !EXACT && sizeof(T) == 8)
+                    {
+                        // moduli of >= 48 bits: quotient estimate from the high word (one shift less per coefficient);
+                        // the test is wave-uniform, both forms are straight-line code
+                        if (m.hi_norm())
+                            static_for<EPT>([&](auto j_) {
+                                constexpr int j = decltype(j_)::value;
+                                v[j] = lazy::normalize<SCH::d.bout[r][j], true>(m, v[j]);
+                            });
+                        else
+                            static_for<EPT>([&](auto j_) {
+                                constexpr int j = decltype(j_)::value;
+                                v[j] = lazy::normalize<SCH::d.bout[r][j], false>(m, v[j]);
+                            });
+                    }
+                    else if constexpr (LAST)
                     {
                         static_for<EPT>([&](auto j_) {
                             constexpr int j = decltype(j_)::value;
@@ -957,13 +993,14 @@ namespace gpuntt
             {
                 unsigned poly, tile;
                 poly_minor_order(bx, static_cast<unsigned>(a.batch), a.n - TLOG, poly, tile, a.flags);
-                blk = static_cast<long long>((static_cast<unsigned long long>(poly) << (a.n - TLOG)) | tile);
+                blk = static_cast<long long>(
+                    uniform64((static_cast<unsigned long long>(poly) << (a.n - TLOG)) | tile));
             }
             if (a.mods != nullptr)
             {
                 const LTileMap<TLOG, CONTIG, K> map(a.n, a.p_lo, static_cast<unsigned long long>(blk));
                 const unsigned long long poly = map.flat(0) >> a.poly_shift;
-                mi = static_cast<int>(poly % static_cast<unsigned>(a.mod_count));
+                mi = static_cast<int>(uniform32(static_cast<unsigned>(poly % static_cast<unsigned>(a.mod_count))));
                 const Modulus<T> md = a.mods[a.mod_order != nullptr ? a.mod_order[mi] : mi];
                 qv = md.value;
                 qb = md.bit;
