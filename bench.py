@@ -187,57 +187,111 @@ def measure_traffic(config, api, out_of_place=False):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def measure_power(step, seconds=3.0):
-    """Socket power and shader clock (rocm-smi) sampled while the step loops for `seconds` -- after the timed
-    region, never part of `value`.  DESIGN.md section 3.4: these transforms run at the part's socket power cap, so the
-    energy per call, not the HBM rate, sets their time; this puts the evidence next to the number.
-    Returns None if rocm-smi is unavailable."""
-    import re
-    import shutil
-    import subprocess
-    import threading
+class PowerReader:
+    """Socket power / shader clock / power cap read IN PROCESS (no fork): amdsmi if importable, else the amdgpu hwmon
+    files in sysfs.  read() -> (watts | None, sclk_mhz | None); cap_w is the socket power limit."""
+
+    def __init__(self, index=0):
+        self.kind, self.cap_w = None, None
+        try:
+            import amdsmi
+            amdsmi.amdsmi_init()
+            self._smi = amdsmi
+            self._h = amdsmi.amdsmi_get_processor_handles()[index]
+            info = amdsmi.amdsmi_get_power_info(self._h)
+            cap = info.get("power_limit")
+            if isinstance(cap, (int, float)) and cap > 0:
+                self.cap_w = float(cap) / (1e6 if cap > 100000 else 1.0)
+            self.kind = "amdsmi"
+            if self.read()[0] is None:
+                self.kind = None
+        except Exception:
+            self.kind = None
+        if self.kind is None:
+            import glob
+            for hw in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+                for f in ("power1_input", "power1_average"):
+                    if os.path.exists(os.path.join(hw, f)):
+                        self._pw, self._hw, self.kind = os.path.join(hw, f), hw, "sysfs"
+                        break
+                if self.kind:
+                    try:
+                        self.cap_w = int(open(os.path.join(hw, "power1_cap")).read()) / 1e6
+                    except Exception:
+                        pass
+                    break
+
+    def read(self):
+        try:
+            if self.kind == "amdsmi":
+                info = self._smi.amdsmi_get_power_info(self._h)
+                w = None
+                for k in ("current_socket_power", "average_socket_power", "socket_power"):
+                    v = info.get(k)
+                    if isinstance(v, (int, float)) and v > 0:
+                        w = float(v)
+                        break
+                try:
+                    clk = self._smi.amdsmi_get_clock_info(self._h, self._smi.AmdSmiClkType.GFX).get("clk")
+                    clk = int(clk) if isinstance(clk, (int, float)) else None
+                except Exception:
+                    clk = None
+                return w, clk
+            if self.kind == "sysfs":
+                w = int(open(self._pw).read()) / 1e6
+                clk = None
+                try:
+                    clk = int(open(os.path.join(self._hw, "freq1_input")).read()) // 1000000
+                except Exception:
+                    pass
+                return w, clk
+        except Exception:
+            pass
+        return None, None
+
+
+def measure_power(step, ms_ref, seconds=3.0):
+    """Socket power and shader clock sampled while the step loops for `seconds` -- after the timed region, never part of
+    `value`.  The launch loop keeps two ~30 ms chunks of calls queued ahead of the GPU and the sensors are read in
+    this process between chunks (no fork, no thread), so the GPU never waits for the host; `ms_per_step_while_sampling`
+    (HIP events around the whole loop) must agree with the timed `ms_per_step` for the samples to describe the same
+    regime -- main() withdraws the energy model otherwise.  Returns None without an in-process sensor."""
     import torch
-    smi = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
-    if not os.path.exists(smi):
+    rd = PowerReader(int(os.environ.get("LOCAL_RANK", "0")))
+    if rd.kind is None:
         return None
-    samples = []
-
-    def sampler():
-        time.sleep(0.8)  # let the clocks settle under the load first
-        for _ in range(3):
-            try:
-                out = subprocess.run([smi, "-d", os.environ.get("LOCAL_RANK", "0"), "--showpower", "--showclocks",
-                                      "--showmaxpower"], capture_output=True, text=True, timeout=20).stdout
-            except Exception:
-                return
-            w = re.search(r"Socket (?:Graphics )?Package Power \(W\):\s*([0-9.]+)", out) or \
-                re.search(r"Average Graphics Package Power \(W\):\s*([0-9.]+)", out)
-            c = re.search(r"sclk clock level:.*?\((\d+)Mhz\)", out)
-            m = re.search(r"Max Graphics Package Power \(W\):\s*([0-9.]+)", out)
-            samples.append((float(w.group(1)) if w else None, int(c.group(1)) if c else None,
-                            float(m.group(1)) if m else None))
-
-    th = threading.Thread(target=sampler)
-    th.start()
+    chunk = max(8, min(4096, int(30.0 / max(ms_ref, 1e-3))))
+    pending, samples, calls = [], [], 0
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    calls = 0
-    while th.is_alive() and time.perf_counter() - t0 < max(seconds, 1.0) + 60.0:
-        for _ in range(16):
+    e0.record()
+    while True:
+        for _ in range(chunk):
             step()
-        calls += 16
-        torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    th.join()
-    ws = [x[0] for x in samples if x[0] is not None]
+        calls += chunk
+        ev = torch.cuda.Event()
+        ev.record()
+        pending.append(ev)
+        if len(pending) > 2:
+            pending.pop(0).synchronize()
+        now = time.perf_counter() - t0
+        if now > 0.8:  # clocks and the power average have settled under the load
+            samples.append(rd.read())
+        if now > seconds:
+            break
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / calls
+    ws = [w for w, _ in samples if w is not None]
     if not ws:
         return None
-    caps = [x[2] for x in samples if x[2] is not None]
-    ms = dt / calls * 1e3
-    return {"socket_w": ws, "sclk_mhz": [x[1] for x in samples if x[1] is not None],
-            "cap_w": caps[0] if caps else None, "ms_per_step_while_sampling": ms,
-            "energy_per_step_j": sum(ws) / len(ws) * ms * 1e-3,
-            "note": "rocm-smi samples while the step loops after the timed region; at the cap the energy per "
-                    "step bounds the time (DESIGN.md 3.4)"}
+    clks = [c for _, c in samples if c is not None]
+    mean_w = sum(ws) / len(ws)
+    return {"sensor": rd.kind, "samples": len(ws), "socket_w_mean": mean_w, "socket_w_min": min(ws), "socket_w_max": max(ws),
+            "sclk_mhz_mean": (sum(clks) / len(clks)) if clks else None, "cap_w": rd.cap_w,
+            "calls": calls, "ms_per_step_while_sampling": ms, "energy_per_step_j": mean_w * ms * 1e-3,
+            "note": "sensors read in-process while the step loops after the timed region (two chunks of calls always "
+                    "queued); at the cap the energy per step bounds the time (DESIGN.md 3.4)"}
 
 
 def quoted_traffic():
@@ -270,18 +324,25 @@ def build_case(g, cfg, rank, world, dev, api, inplace=True):
         d_out = torch.empty_like(d_in)
         table = g.to_device(prm.forward_table_device_order, dev)
         c = g.ntt_configuration(n_power=logn, ntt_type=g.FORWARD, reduction_poly=poly)
+        # the first call goes d_in -> d_out (the output the CPU leg checks); with `inplace` the timed calls are
+        # GPU_NTT_Inplace on d_out (its contents stay residues below q), as the reference's benchmark times it
+        src = d_out if inplace else d_in
         if api == "plan":
             plan = g.NTTPlan(table, prm.modulus, logn, poly, g.FORWARD, batch_hint=batch)
-            case["step"] = lambda: plan.execute(d_in, d_out, batch)
+            case["first"] = lambda: plan.execute(d_in, d_out, batch)
+            case["step"] = lambda: plan.execute(src, d_out, batch)
             case["plan"] = plan
         else:
-            case["step"] = lambda: g.GPU_NTT(d_in, d_out, table, prm.modulus, c, batch)
+            case["first"] = lambda: g.GPU_NTT(d_in, d_out, table, prm.modulus, c, batch)
+            case["step"] = (lambda: g.GPU_NTT_Inplace(d_out, table, prm.modulus, c, batch)) if inplace else \
+                           (lambda: g.GPU_NTT(d_in, d_out, table, prm.modulus, c, batch))
         def other_step():
             if api == "plan":
-                return lambda: g.GPU_NTT(d_in, d_out, table, prm.modulus, c, batch)
+                return (lambda: g.GPU_NTT_Inplace(d_out, table, prm.modulus, c, batch)) if inplace else \
+                       (lambda: g.GPU_NTT(d_in, d_out, table, prm.modulus, c, batch))
             p2 = g.NTTPlan(table, prm.modulus, logn, poly, g.FORWARD, batch_hint=batch)
             case["plan"] = p2
-            return lambda: p2.execute(d_in, d_out, batch)
+            return lambda: p2.execute(src, d_out, batch)
         case.update(x=x, d_in=d_in, d_out=d_out, table=table, modulus=prm.modulus.value, other_step=other_step,
                     run_shard=lambda a, b: g.GPU_NTT(a, b, table, prm.modulus, c, batch))
     elif cfg["kind"] == "rns":
@@ -298,18 +359,23 @@ def build_case(g, cfg, rank, world, dev, api, inplace=True):
         table = g.to_device(tab, dev)
         mods = g.modulus_array_to_device([p.modulus for p in prms], bits, dev)
         c = g.ntt_rns_configuration(n_power=logn, ntt_type=g.FORWARD, reduction_poly=poly)
+        src = d_out if inplace else d_in
         if api == "plan":
             plan = g.NTTPlan(table, [p.modulus for p in prms], logn, poly, g.FORWARD, batch_hint=batch)
-            case["step"] = lambda: plan.execute(d_in, d_out, batch)
+            case["first"] = lambda: plan.execute(d_in, d_out, batch)
+            case["step"] = lambda: plan.execute(src, d_out, batch)
             case["plan"] = plan
         else:
-            case["step"] = lambda: g.GPU_NTT(d_in, d_out, table, mods, c, batch, mc)
+            case["first"] = lambda: g.GPU_NTT(d_in, d_out, table, mods, c, batch, mc)
+            case["step"] = (lambda: g.GPU_NTT_Inplace(d_out, table, mods, c, batch, mc)) if inplace else \
+                           (lambda: g.GPU_NTT(d_in, d_out, table, mods, c, batch, mc))
         def other_step():
             if api == "plan":
-                return lambda: g.GPU_NTT(d_in, d_out, table, mods, c, batch, mc)
+                return (lambda: g.GPU_NTT_Inplace(d_out, table, mods, c, batch, mc)) if inplace else \
+                       (lambda: g.GPU_NTT(d_in, d_out, table, mods, c, batch, mc))
             p2 = g.NTTPlan(table, [p.modulus for p in prms], logn, poly, g.FORWARD, batch_hint=batch)
             case["plan"] = p2
-            return lambda: p2.execute(d_in, d_out, batch)
+            return lambda: p2.execute(src, d_out, batch)
         case.update(x=x, d_in=d_in, d_out=d_out, table=table, factors=factors, modulus=factors[0][0],
                     other_step=other_step,
                     run_shard=lambda a, b: g.GPU_NTT(a, b, table, mods, c, batch, mc))
@@ -356,6 +422,242 @@ def gpu_sample_for_check(g, cfg, case, polys):
     return g.to_host(b)
 
 
+# ------------------------------------------------------------------------------ self-launch
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without torchrun: re-execute this command line under torch.distributed.run with N
+    ranks on this node (127.0.0.1 rendezvous on a free port) and hand its exit code back."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(cfg, args, dist_mod):
+    """No GPU in this process (CPU container): everything around the kernels still runs -- rendezvous (gloo), the
+    shard geometry of every rank, the barrier + MAX-reduced timed region, the JSON line -- with a no-op step.
+    `value` is null and the line says "dry_run": nothing here is a measurement."""
+    dist, rank, world = dist_mod.init_process_group("gloo", None)
+    pkg = sys.modules["gpu_ntt_amd"]
+    total = cfg["batch"] * (1 if cfg["scaling"] == "strong" else world)
+    lo, hi = pkg.shard_range(total, rank, world, cfg.get("mod_count", 1))
+    wall = dist_mod.timed_region(lambda: None, args.steps, dist, None)
+    shards = [(lo, hi)]
+    if dist is not None:
+        shards = [None] * world
+        dist.all_gather_object(shards, (lo, hi))
+    if rank == 0:
+        print(json.dumps({"metric": cfg["metric"], "value": None, "unit": "NTT/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": wall * 1e3 / max(args.steps, 1),
+                          "higher_is_better": True, "scaling": cfg["scaling"], "vs_baseline": None,
+                          "dtype": "u%d" % cfg["bits"], "data": "synthetic", "dry_run": True,
+                          "config": {"workload": cfg["workload"], "log2N": cfg["logn"],
+                                     "parallelism": "batch-shard x%d" % world, "shards": shards},
+                          "note": "no GPU visible: launch, rendezvous (gloo), sharding and timing plumbing only"}),
+              flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------ sweep
+SWEEP_MARK = "FillFunctorIdE"  # the float64 fill kernel that separates two sweep points in a PMC child pass
+
+
+def sweep_points(args):
+    kinds = [k for k in args.sweep_kinds.split(",") if k]
+    pts = []
+    for kind in kinds:
+        for bits in [int(b) for b in args.sweep_bits.split(",")]:
+            for logn in range(args.sweep_min, args.sweep_max + 1):
+                if kind == "4step" and bits == 32 and logn > 24:
+                    continue
+                pts.append((kind, bits, logn, max(1, (1 << args.sweep_log_coeffs) >> logn)))
+    return pts
+
+
+def sweep_case(g, kind, bits, logn, batch, dev, rank):
+    """(first, step, x0, y0-getter) of one sweep point: forward transform of `batch` polynomials of 2^logn, in place
+    for Merge (reference benchmark/bench_merge_ntt.cu:62), in -> out for 4-step (the entry point is out of place)."""
+    import torch
+    n = 1 << logn
+    seed = 0x5EED1000 + logn + 64 * rank
+    if kind == "merge":
+        prm = g.NTTParameters(logn, g.X_N_minus, bits)
+        x = splitmix64_mod(seed, batch * n, prm.modulus.value).astype(g.np_dtype(bits))
+        d_in = g.to_device(x, dev)
+        d_out = torch.empty_like(d_in)
+        table = g.to_device(prm.forward_table_device_order, dev)
+        c = g.ntt_configuration(n_power=logn, ntt_type=g.FORWARD, reduction_poly=g.X_N_minus)
+        first = lambda: g.GPU_NTT(d_in, d_out, table, prm.modulus, c, batch)  # noqa: E731
+        step = lambda: g.GPU_NTT_Inplace(d_out, table, prm.modulus, c, batch)  # noqa: E731
+        return first, step, x[:n], (lambda: g.to_host(d_out)[:n].copy()), [d_in, d_out, table]
+    p4 = g.NTTParameters4Step(logn, bits)
+    distinct = min(batch, 4)
+    base = np.concatenate([splitmix64_mod(seed + 7 * i, n, p4.modulus.value) for i in range(distinct)]).astype(g.np_dtype(bits))
+    d_in = g.to_device(base, dev).repeat(batch // distinct)
+    d_out = torch.empty_like(d_in)
+    tf = [g.to_device(t, dev) for t in p4.tables["fwd"]]
+    cf = g.ntt4step_configuration(n_power=logn, ntt_type=g.FORWARD)
+    step = lambda: g.GPU_4STEP_NTT(d_in, d_out, *tf, p4.modulus, cf, batch)  # noqa: E731
+
+    def natural0():  # natural-order forward of polynomial 0 = NTT_4STEP_CPU::ntt
+        a = g.to_device(base[:n], dev)
+        b = torch.empty_like(a)
+        g.GPU_4STEP_NTT_NaturalOrder(a, b, *tf, p4.modulus, cf, 1)
+        torch.cuda.synchronize()
+        return g.to_host(b)
+    return step, step, base[:n], natural0, [d_in, d_out] + tf
+
+
+def sweep_cpu(kind, bits, logn, x0, y0):
+    """reference CPU transform of ONE polynomial of this ring on one host core (>= 1 transform, ~0.5 s); also the
+    bit-exact check of the GPU's polynomial 0"""
+    from oracle import oracle as O
+    B = O.Ref(bits) if O.have_ref() else O.Port(bits)
+    if kind == "merge":
+        prm = B.merge_params(logn, O.X_N_minus)
+        run = lambda: B.merge_ntt(x0, prm)  # noqa: E731
+    else:
+        prm = B.fourstep_params(logn)
+        run = (lambda: B.fourstep_run(x0, prm, 0)) if O.have_ref() else (lambda: B.fourstep_ntt(x0, prm))
+    t0 = time.perf_counter()
+    y = run()
+    k = 1
+    while time.perf_counter() - t0 < 0.5:
+        run()
+        k += 1
+    dt = (time.perf_counter() - t0) / k
+    return {"value": 1.0 / dt, "unit": "NTT/s", "cores": 1, "kind": "reference" if O.have_ref() else "port",
+            "gpu_output_bit_exact": bool(np.array_equal(y, y0)), "sample": "%d transform(s) of one polynomial" % k}
+
+
+def sweep_traffic(args, points):
+    """HBM bytes per call of every sweep point from two rocprofv3 --pmc child passes of `bench.py --sweep --child`
+    (FETCH_SIZE x2 on gfx950, WRITE_SIZE): the child separates the points with a float64 fill kernel, the dispatches
+    are split at those marks in time order."""
+    import glob
+    import shutil
+    import sqlite3
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None, "rocprofv3 not found"
+    calls = 3
+    tmp = tempfile.mkdtemp(prefix="gpuntt_sweep_pmc_", dir="/tmp")
+    per_point = [0.0] * len(points)
+    try:
+        for counter, corr in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
+            out = os.path.join(tmp, counter)
+            cmd = [rocprof, "--pmc", counter, "-d", out, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
+                   "--sweep", "--child", "--steps", str(calls), "--sweep-kinds", args.sweep_kinds, "--sweep-bits",
+                   args.sweep_bits, "--sweep-min", str(args.sweep_min), "--sweep-max", str(args.sweep_max),
+                   "--sweep-log-coeffs", str(args.sweep_log_coeffs)]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True,
+                               timeout=1500)
+            dbs = glob.glob(out + "/**/*.db", recursive=True)
+            if r.returncode != 0 or not dbs:
+                return None, "rocprofv3 --pmc %s failed: %s" % (counter, (r.stderr or r.stdout)[-300:])
+            c = sqlite3.connect(dbs[0])
+            names = [x[0] for x in c.execute("select name from sqlite_master where type='table'")]
+            t = lambda p: [n for n in names if n.startswith(p)][0]  # noqa: E731
+            q = (f"select s.kernel_name, d.start, sum(p.value) from {t('rocpd_pmc_event')} p "
+                 f"join {t('rocpd_info_pmc')} i on p.pmc_id=i.id "
+                 f"join {t('rocpd_kernel_dispatch')} d on p.event_id=d.event_id "
+                 f"join {t('rocpd_info_kernel_symbol')} s on d.kernel_id=s.id "
+                 f"where i.name='{counter}' group by d.id order by d.start")
+            idx = -1
+            for name, _start, kb in c.execute(q):
+                if SWEEP_MARK in name:
+                    idx += 1
+                elif "gpuntt" in name and 0 <= idx < len(points):
+                    per_point[idx] += kb * 1024.0 * corr / calls
+            if idx != len(points) - 1:
+                return None, "sweep marks in the %s pass: %d, expected %d" % (counter, idx + 1, len(points))
+        return per_point, {"method": "rocprofv3 --pmc, two child passes of the whole sweep, this run",
+                           "fetch_correction": 2.0, "calls_profiled_per_point": calls}
+    except Exception as e:
+        return None, "sweep traffic measurement failed: %r" % (e,)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def run_sweep(g, args, dist_mod, dist, rank, world, dev):
+    """north_star's table: log2N x {Merge, 4-Step}, per ring size NTT/s, achieved algorithmic GB/s and fraction of the
+    8 TB/s peak, PMC HBM bytes per call and the reference CPU transform beside it -- one JSON line per point, at
+    whatever number of ranks the script was started with (weak scaling: every rank transforms its own batch)."""
+    import torch
+    points = sweep_points(args)
+    if args.child:
+        mark = torch.zeros(1, dtype=torch.float64, device=dev)
+        for k, (kind, bits, logn, batch) in enumerate(points):
+            first, step, _, _, keep = sweep_case(g, kind, bits, logn, batch, dev, rank)
+            torch.cuda.synchronize()
+            mark.fill_(float(k))
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            del keep
+        return
+    traffic, tinfo = (None, "disabled / multi-GPU run")
+    if world == 1 and not args.no_traffic:
+        traffic, tinfo = sweep_traffic(args, points)
+    for k, (kind, bits, logn, batch) in enumerate(points):
+        first, step, x0, y0_get, keep = sweep_case(g, kind, bits, logn, batch, dev, rank)
+        first()
+        torch.cuda.synchronize()
+        y0 = y0_get() if rank == 0 else None
+        if kind == "merge":
+            step()  # the in-place form once before timing
+        t0 = time.perf_counter()
+        w = 0
+        while w < 3 or time.perf_counter() - t0 < 0.08:
+            step()
+            w += 1
+            if w % 8 == 0:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        per = max((time.perf_counter() - t0) / w, 1e-6)
+        steps = max(5, min(2000, int(0.15 / per)))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+        def timed():
+            e0.record()
+            for _ in range(steps):
+                step()
+            e1.record()
+        wall = dist_mod.timed_region(timed, 1, dist, dev)
+        dev_ms = e0.elapsed_time(e1)
+        if dist is not None:
+            tt = torch.tensor([dev_ms], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dev_ms = float(tt[0])
+        if rank == 0:
+            n = 1 << logn
+            alg = 2 * n * (bits // 8) * batch
+            call_ms = dev_ms / steps
+            achieved = alg / (call_ms * 1e-3) / 1e9
+            line = {"sweep": True, "algo": kind, "dtype": "u%d" % bits, "log2N": logn, "batch_per_gpu": batch,
+                    "n_gpus": world, "metric": "forward-NTTs/sec + achieved HBM GB/s", "unit": "NTT/s",
+                    "value": world * batch * steps / wall, "steps": steps, "ms_per_step": wall * 1e3 / steps,
+                    "in_place": kind == "merge", "scaling": "weak", "data": "synthetic",
+                    "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_call": alg,
+                                 "call_ms_hip_events": call_ms,
+                                 "traffic": traffic[k] if traffic else None,
+                                 "traffic_over_algorithmic": (traffic[k] / alg) if traffic else None}}
+            if k == 0:
+                line["roofline"]["traffic_info"] = tinfo
+            if not args.no_cpu_baseline and world == 1:
+                line["cpu_baseline"] = sweep_cpu(kind, bits, logn, x0, y0)
+                if not line["cpu_baseline"]["gpu_output_bit_exact"]:
+                    raise SystemExit("bench --sweep: GPU result differs from the CPU reference path at %s 2^%d" % (kind, logn))
+            print(json.dumps(line), flush=True)
+        del keep
+        torch.cuda.empty_cache()
+
+
 # ------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
@@ -372,10 +674,21 @@ def main():
                     help="time GPU_NTT(in, out) instead of the in-place call the reference's own benchmark times")
     ap.add_argument("--cpu-polys", type=int, default=64)
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)  # PMC child pass: calls only
+    ap.add_argument("--sweep", action="store_true",
+                    help="log2N sweep (Merge and 4-Step, forward), one JSON line per ring size with PMC bytes and the CPU column")
+    ap.add_argument("--sweep-kinds", default="merge,4step")
+    ap.add_argument("--sweep-bits", default="64")
+    ap.add_argument("--sweep-min", type=int, default=12)
+    ap.add_argument("--sweep-max", type=int, default=24)
+    ap.add_argument("--sweep-log-coeffs", type=int, default=26, help="log2 of the coefficients per GPU and call")
     args = ap.parse_args()
     cfg = dict(CONFIGS[args.config], name=args.config)
     if args.config == "c3" and args.steps == 200:
         args.steps, args.warmup = 10, 2  # a step is ~25 ms and 16 GiB of traffic
+
+    # `python bench.py --gpus N` on its own: start the N ranks here (the driver's torchrun form sets WORLD_SIZE)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))
 
     import importlib
     import torch
@@ -385,28 +698,33 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    if not torch.cuda.is_available():
+        return dry_run(cfg, args, dist_mod)
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
     dist, rank, world = dist_mod.init_process_group("nccl", dev)
+    if args.sweep:
+        run_sweep(g, args, dist_mod, dist, rank, world, dev)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
     inplace = not args.out_of_place and cfg["kind"] != "4step"
     case = build_case(g, cfg, rank, world, dev, args.api, inplace)
     step = case["step"]
     case.get("first", step)()  # d_in -> d_out once: the output the CPU leg checks
     torch.cuda.synchronize()
+    bits, logn, n = cfg["bits"], cfg["logn"], case["n"]
+    cpu_polys = min(max(args.cpu_polys, os.cpu_count() or 1), case["batch"])  # >= one polynomial per host thread
+    if cfg["kind"] == "rns":
+        cpu_polys = max(cfg["mod_count"], cpu_polys - cpu_polys % cfg["mod_count"])
+    # taken NOW: the in-place timed calls below transform d_out again and again
+    y_first = gpu_sample_for_check(g, cfg, case, cpu_polys) if (rank == 0 and not args.child) else None
     if args.child:
         for _ in range(args.steps):
             step()
         torch.cuda.synchronize()
         return
-
-    bits, logn, n = cfg["bits"], cfg["logn"], case["n"]
-    cpu_polys = min(max(args.cpu_polys, os.cpu_count() or 1), case["batch"])  # >= one polynomial per host thread
-    if cfg["kind"] == "rns":
-        cpu_polys = max(cfg["mod_count"], cpu_polys - cpu_polys % cfg["mod_count"])
-    y_first = gpu_sample_for_check(g, cfg, case, cpu_polys) if rank == 0 else None
 
     # clock settle (untimed, before the W warm-up steps): the part needs ~60 ms of load to leave its
     # idle clocks; without this a short --steps/--warmup run reads 10-15 % slow
@@ -457,7 +775,7 @@ def main():
     power = None
     if world == 1 and not args.no_power:
         try:
-            power = measure_power(step)
+            power = measure_power(step, wall * 1e3 / args.steps)
         except Exception as e:  # informational only
             power = {"error": repr(e)}
 
@@ -510,8 +828,13 @@ def main():
         }
         if isinstance(other, float):
             line["other_api_ms_per_call"] = {"api": "plan" if args.api == "dropin" else "dropin", "ms": other}
+        if power is not None and "ms_per_step_while_sampling" in power:
+            # the samples describe the timed regime only if the sampled loop ran at the timed rate
+            ratio = power["ms_per_step_while_sampling"] / ms_per_step
+            power["sampling_vs_timed_ms_ratio"] = ratio
+            power["same_regime_as_timed_steps"] = bool(0.9 <= ratio <= 1.1)
         if power is not None:
-            if bits == 64 and isinstance(power.get("cap_w"), float) and traffic:
+            if bits == 64 and isinstance(power.get("cap_w"), float) and traffic and power.get("same_regime_as_timed_steps"):
                 # what the measured bytes and the butterflies of one step cost by the per-byte / per-butterfly energies
                 # measured on this part (profiles/r02_power.txt: device copy 0.12 nJ per byte through L2 / fabric / HBM;
                 # profiles/ubench_bfly_r02.txt: register-only 64-bit lazy butterflies 29 nJ per wave of 64; idle 261 W)

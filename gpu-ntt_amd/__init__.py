@@ -78,6 +78,10 @@ def load_library():
     for name in EXPORTED_SYMBOLS:
         getattr(lib, name)  # AttributeError if the ABI is incomplete
     _lib = lib
+    for var, (opt, conv) in ENV_OPTIONS.items():
+        if var in os.environ and "gpuntt_set_option" in EXPORTED_SYMBOLS:
+            val = os.environ[var]
+            set_option(opt, conv(val) if conv else val)
     return lib
 
 
@@ -91,7 +95,19 @@ EXPORTED_SYMBOLS = ["gpuntt_last_error", "gpuntt_version"] + [
               "plan_destroy", "operator_gpu", "4step_plan_workspace_bytes", "4step_plan_create",
               "4step_plan_execute", "4step_plan_fast_path", "4step_plan_destroy",
               "generate_power_table", "generate_4step_w")
-    for s in ("u32", "u64")] + ["gpuntt_release_workspaces"]
+    for s in ("u32", "u64")] + ["gpuntt_release_workspaces", "gpuntt_set_option"]
+
+# GPUNTT_* environment variables of the A/B scripts and tests -> library options.  The C++ library reads no
+# environment variable; this harness forwards them once, when it loads the library.
+ENV_OPTIONS = {"GPUNTT_PATH": ("path", None), "GPUNTT_CONTIG_K": ("contig_k", None),
+               "GPUNTT_XCD_ORDER": ("xcd_order", None), "GPUNTT_LIM31": ("lim31", None),
+               "GPUNTT_NO_REVERSE": ("reverse", lambda v: "0" if v not in ("", "0") else "1"),
+               "GPUNTT_U64_BIG_TILES": ("u64_big_tiles", None), "GPUNTT_U32_TILE": ("u32_tile", None)}
+
+
+def set_option(name, value):
+    """GPU_NTT_SetOption: process-wide tuning / test switch (names in include/gpuntt/ntt_merge/ntt.cuh)."""
+    _check(load_library().gpuntt_set_option(str(name).encode(), str(value).encode()))
 
 
 def _check(rc):

@@ -386,7 +386,14 @@ extern "C"
     {
         return guarded([] { GPU_NTT_ReleaseWorkspaces(); });
     }
-    int gpuntt_version(void) { return 100; }
+    int gpuntt_set_option(const char* name, const char* value)
+    {
+        return guarded([&] {
+            if (!GPU_NTT_SetOption(name, value))
+                throw std::invalid_argument("Unknown option or value!");
+        });
+    }
+    int gpuntt_version(void) { return 101; }
 
     int gpuntt_modulus_u32(uint32_t q, gpuntt_modulus32* out)
     {

@@ -184,16 +184,17 @@ namespace gpuntt
                 return false;
             if (mods_dev != nullptr && INV && ninv_dev == nullptr)
                 return false;
-            if (const char* e = std::getenv("GPUNTT_PATH"))
-                if (std::strcmp(e, "generic") == 0)
-                    return false;
+            if (host::forced_path() == 1)
+                return false;
             const size_t n1 = size_t(1) << log_n1, n2 = size_t(1) << log_n2, n = size_t(1) << n_power;
             // pairs: n1 table | W | n2 table | n^-1 ; then go-flag (16 B) and the normalisation constants
             const size_t pairs = n1 + n + n2 + 2;
             auto* ws = plan.mode != PLAN_NONE
                            ? plan.ws
                            : static_cast<TW*>(
-                                 host::lazy_workspace(stream, sizeof(TW) * pairs + 16 + sizeof(lazy::NormConst)));
+                                 host::lazy_workspace(stream, sizeof(TW) * pairs + 16 + sizeof(lazy::NormConst), true));
+            if (ws == nullptr)
+                return false; // no device memory for the scratch: the generic kernels need none
             TW* ws_n1 = ws;
             TW* ws_w = ws + n1;
             TW* ws_n2 = ws + n1 + n;
@@ -278,13 +279,14 @@ namespace gpuntt
             using TW = lazy::Tw<T>;
             if (mod.bit > T(lazy::Mod<T>::MAX_BIT) || mod.value < 3)
                 return false;
-            if (const char* e = std::getenv("GPUNTT_PATH"))
-                if (std::strcmp(e, "generic") == 0)
-                    return false;
+            if (host::forced_path() == 1)
+                return false;
             const size_t n1 = size_t(1) << log_n1, n2 = size_t(1) << log_n2, n = size_t(1) << n_power;
             auto* ws = plan.mode != PLAN_NONE
                            ? plan.ws
-                           : static_cast<TW*>(host::lazy_workspace(stream, sizeof(TW) * (n1 + n + n2 + 2)));
+                           : static_cast<TW*>(host::lazy_workspace(stream, sizeof(TW) * (n1 + n + n2 + 2), true));
+            if (ws == nullptr)
+                return false; // no device memory for the scratch: the generic kernels need none
             TW* ws_n1 = ws;
             TW* ws_w = ws + n1;
             TW* ws_n2 = ws + n1 + n;
@@ -364,13 +366,14 @@ namespace gpuntt
             using TW = lazy::Tw<T>;
             if (mod.bit > T(lazy::Mod<T>::MAX_BIT) || mod.value < 3 || ninv >= mod.value)
                 return false;
-            if (const char* e = std::getenv("GPUNTT_PATH"))
-                if (std::strcmp(e, "generic") == 0)
-                    return false;
+            if (host::forced_path() == 1)
+                return false;
             const size_t n1 = size_t(1) << log_n1, n2 = size_t(1) << log_n2, n = size_t(1) << n_power;
             auto* ws = plan.mode != PLAN_NONE
                            ? plan.ws
-                           : static_cast<TW*>(host::lazy_workspace(stream, sizeof(TW) * (n1 + n + n2 + 2)));
+                           : static_cast<TW*>(host::lazy_workspace(stream, sizeof(TW) * (n1 + n + n2 + 2), true));
+            if (ws == nullptr)
+                return false; // no device memory for the scratch: the generic kernels need none
             TW* ws_n1 = ws;
             TW* ws_w = ws + n1;
             TW* ws_n2 = ws + n1 + n;
@@ -447,8 +450,7 @@ namespace gpuntt
             if ((static_cast<unsigned long long>(batch_size) << n_power) >> kern::TL > 0x7fffffffull)
                 throw std::invalid_argument("batch_size * N too large for one launch");
             const unsigned* skip_flag = nullptr;
-            const char* path_env = std::getenv("GPUNTT_PATH");
-            if (mods != nullptr && mod_count == 1 && path_env != nullptr && std::strcmp(path_env, "generic-capped") == 0)
+            if (mods != nullptr && mod_count == 1 && host::forced_path() == 4)
             {
                 // test hook: the generic kernels as they run behind a go-flag that says "yours" (what a
                 // 61/62-bit modulus produces) -- capped grid walking the tiles, flag word = 0
@@ -620,7 +622,7 @@ namespace gpuntt
             p->use.mode = PLAN_PREPARE;
             p->use.tile_log =
                 host::lazy_tile_log<T>(l2, p->inverse, static_cast<unsigned long long>(batch_hint) << l1);
-            // the eligibility checks of the fast paths decide (modulus width, n^-1 canonical, GPUNTT_PATH)
+            // the eligibility checks of the fast paths decide (modulus width, n^-1 canonical, option "path")
             if (natural_order)
                 p->fast = p->inverse ? fourstep_natural_inverse_lazy<T>(nullptr, nullptr, p->n1_table, p->n2_table,
                                                                         p->w_table, p->mod, p->ninv, p->n, l1, l2, 1,
@@ -636,6 +638,8 @@ namespace gpuntt
                                                                    p->w_table, p->mod, p->ninv, p->n, l1, l2, 1,
                                                                    cfg.stream, nullptr, nullptr, nullptr, p->use);
             p->use.mode = PLAN_EXECUTE;
+            // complete when the constructor returns: execute() may run on any stream (one host wait per plan)
+            GPUNTT_HIP_CHECK(hipStreamSynchronize(cfg.stream));
         }
         catch (...)
         {
@@ -695,7 +699,7 @@ namespace gpuntt
                                                          p.n, p.l1, p.l2, batch_size, stream, nullptr, nullptr, nullptr,
                                                          p.use);
         if (!ok)
-            throw std::runtime_error("FourStepPlan: prepared path refused (GPUNTT_PATH changed since creation?)");
+            throw std::runtime_error("FourStepPlan: prepared path refused (option path changed since creation?)");
     }
 
     template class FourStepPlan<Data32>;

@@ -66,7 +66,10 @@ namespace gpuntt
         // Inside a WorkspaceScope (every public entry point opens one) the calling thread keeps the
         // buffer's lock until the scope ends, i.e. from the preparation launch to the last kernel launch
         // of the call: two host threads on one stream can no longer interleave A.prep, B.prep, A.kernels.
-        void* lazy_workspace(hipStream_t stream, size_t bytes);
+        // or_null: nullptr instead of a HipException when the device has no memory left for the buffer (the entry
+        // points then run the generic kernels, which need no scratch).  The buffers are retained per (device, stream)
+        // until GPU_NTT_ReleaseWorkspaces().
+        void* lazy_workspace(hipStream_t stream, size_t bytes, bool or_null = false);
         struct WorkspaceScope
         {
             WorkspaceScope();
@@ -86,15 +89,15 @@ namespace gpuntt
                          bool negacyclic, int perm_tile_log, const T* ninv_arr, lazy::Tw<T>* ws_ninv,
                          unsigned* go_flag, lazy::NormConst* norm_arr, hipStream_t stream,
                          const int* mod_order = nullptr, const T* fold_ninv_single = nullptr,
-                         bool fold_ninv_rns = false, unsigned* fused_ctl = nullptr);
+                         bool fold_ninv_rns = false);
         extern template void launch_prep<uint64_t>(const uint64_t*, lazy::Tw64*, const Modulus<uint64_t>*,
                                                    uint64_t, int, int, bool, int, const uint64_t*,
                                                    lazy::Tw64*, unsigned*, lazy::NormConst*, hipStream_t, const int*,
-                                                   const uint64_t*, bool, unsigned*);
+                                                   const uint64_t*, bool);
         extern template void launch_prep<uint32_t>(const uint32_t*, lazy::Tw32*, const Modulus<uint32_t>*,
                                                    uint32_t, int, int, bool, int, const uint32_t*,
                                                    lazy::Tw32*, unsigned*, lazy::NormConst*, hipStream_t, const int*,
-                                                   const uint32_t*, bool, unsigned*);
+                                                   const uint32_t*, bool);
 
         template <typename T>
         void launch_prep_pairs(const T* src, lazy::Tw<T>* dst, unsigned long long count, T q, hipStream_t stream,
@@ -188,32 +191,15 @@ namespace gpuntt
             return pl;
         }
 
-        // stages handled by the contiguous pass of the fast path (GPUNTT_CONTIG_K overrides, 8..12)
+        // process-wide tuning / test options (prep.hip); the library reads no environment variable
+        bool set_option(const char* name, const char* value);
+        // 0 size heuristic, 1 generic kernels, 2 fast, 3 fast-strict (a call the fast kernels cannot take throws),
+        // 4 generic-capped (4-step RNS overload: generic kernels on the capped shadow grid)
+        int forced_path();
+        // stages handled by the contiguous pass of the fast path (option contig_k overrides, 8..12)
         int lazy_contig_k(int n);
 
-        // single-launch kernel (merge_lazy_kernels.hpp: merge_fused_lazy) for two-pass plans on 4096-coefficient
-        // tiles, 64-bit rings 2^14 .. 2^18.  OFF unless GPUNTT_FUSED=1: measured on MI355X (profiles/
-        // r02_fused_single_sweep.md) the XCD's L2 does not keep a line that was just stored (write-around:
-        // a read-back by the same workgroup misses, tools/ubench_l2.hip), so the hand-off between the two
-        // passes goes through the fabric whatever the placement, the launch moves the same 2 x 1 GiB as the
-        // two launches it replaces, and its group barriers make it slower (0.55 vs 0.45 ms at 2^16 x 1024).
-        // GPUNTT_FUSED_MODE=1 builds groups from consecutive block indices, =2 forces the fence protocol
-        // (tests of the placement-independent path).
         bool lazy_reverse_passes();
-        int lazy_fused_env();
-        int lazy_fused_mode();
-        template <typename T> inline bool lazy_use_fused(int n, int tile_log, bool inverse, unsigned long long polys)
-        {
-            (void) inverse;
-            if (sizeof(T) != 8 || tile_log != 12 || polys == 0)
-                return false;
-            return lazy_fused_env() == 1 && n >= 13 && n <= 18;
-        }
-        // one launch for the whole transform; a.fused_ctl must point at zeroed control words
-        template <typename T, bool INV>
-        void launch_fused_lazy(int n, int contig_k, const kern::LazyArgsT<T>& a, hipStream_t stream);
-        extern template void launch_fused_lazy<uint64_t, false>(int, int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
-        extern template void launch_fused_lazy<uint64_t, true>(int, int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
 
         // in_first: the pass reads canonical input (first pass of the transform)
         template <typename T, bool INV>
@@ -251,18 +237,8 @@ namespace gpuntt
         template <>
         void launch_pass_lazy_u32w<true>(const Pass&, int, bool, bool, const kern::LazyArgsT<uint32_t>&, hipStream_t);
         inline bool lazy_wide_modulus32(uint32_t q) { return q >= 3 && q < (1u << 29); }
-        int lazy_pipe_env();
         inline bool lazy_lim31_modulus(uint64_t q) { return q >= 3 && q <= 0xffffffffffffffffull / 31; }
         extern template void launch_pass_lazy_lim<true, 4>(const Pass&, bool, bool, const kern::LazyArgsT<uint64_t>&, hipStream_t);
-
-        // persistent, software-pipelined form of the 10-stage contiguous pass (merge_pipe_kernels.hpp; 64-bit rings
-        // 2^13 .. 2^16 on 4096-coefficient tiles): launches it and returns true if the call qualifies
-        // -- opt-in through GPUNTT_PIPE=1 | 2, measured slower than the default kernels (lazy_u64_pipe.hip)
-        template <bool INV>
-        bool launch_contig_pipe(const Pass& p, bool in_first, bool last, const kern::LazyArgsT<uint64_t>& a,
-                                hipStream_t stream);
-        extern template bool launch_contig_pipe<false>(const Pass&, bool, bool, const kern::LazyArgsT<uint64_t>&, hipStream_t);
-        extern template bool launch_contig_pipe<true>(const Pass&, bool, bool, const kern::LazyArgsT<uint64_t>&, hipStream_t);
 
         // Range bound (units of q) a forward pass of k stages hands over when it reads values below `bound` -- the
         // run-time twin of kern::PassSched for Cooley-Tukey passes (every register carries the same bound there).
@@ -284,18 +260,6 @@ namespace gpuntt
                                ? 12
                                : (forced_tl ? forced_tl : lazy_tile_log<T>(base.n, INV, base.total >> base.n));
             const Plan pl = make_plan_tl(base.n, tl, tl == 12 ? lazy_contig_k(base.n) : tl);
-            if constexpr (sizeof(T) == 8)
-            {
-                if (pl.count == 2 && base.fused_ctl != nullptr && !base.lim &&
-                    lazy_use_fused<T>(base.n, tl, INV, base.total >> base.n))
-                {
-                    kern::LazyArgsT<T> a = base;
-                    a.flags |= first_in_flags | last_out_flags;
-                    a.batch = 0;
-                    launch_fused_lazy<T, INV>(base.n, pl.pass[1].k, a, stream);
-                    return;
-                }
-            }
             const void* src = base.in;
             int fwd_bound = 1; // range bound of the values in flight (forward, 31 q range: see fwd_bound_after)
             for (int i = 0; i < pl.count; i++)
@@ -340,7 +304,7 @@ namespace gpuntt
                         else
                             throw std::invalid_argument("internal: the 31 q range serves forward transforms only");
                     }
-                    else if (tlp != 12 || pl.count < 2 || !launch_contig_pipe<INV>(p, i == 0, i == pl.count - 1, a, stream))
+                    else
                         launch_pass_lazy<T, INV>(p, tlp, i == 0, i == pl.count - 1, a, stream);
                 }
                 else

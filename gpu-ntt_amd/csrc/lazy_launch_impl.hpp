@@ -303,48 +303,6 @@ namespace gpuntt
             GPUNTT_HIP_CHECK(hipGetLastError());
         }
 
-        // grid of the single-sweep kernel: (CUs x 4 resident workgroups) / G groups, never more groups than
-        // polynomials (rounded up to the 8 XCDs), never more than the control block holds
-        int device_cu_count();
-        template <typename T, bool INV>
-        void launch_fused_lazy(int n, int contig_k, const kern::LazyArgsT<T>& a, hipStream_t stream)
-        {
-            constexpr int TLOG = 12;
-            const int gl = n - TLOG;
-            const unsigned long long polys = a.total >> n;
-            unsigned groups = static_cast<unsigned>((device_cu_count() * 4) >> gl);
-            groups &= ~7u;
-            if (groups < 8u)
-                groups = 8u;
-            if (groups > static_cast<unsigned>(kern::FUSED_MAX_GROUPS))
-                groups = kern::FUSED_MAX_GROUPS;
-            const unsigned long long want = (polys + 7ull) & ~7ull;
-            if (want < groups)
-                groups = static_cast<unsigned>(want);
-            const unsigned grid = groups << gl;
-            const int mode = lazy_fused_mode();
-#define GPUNTT_FUSED(KS_, KC_)                                                                                    \
-    hipLaunchKernelGGL((kern::merge_fused_lazy<T, TLOG, INV, KS_, KC_>), dim3(grid), dim3(kern::LTile<TLOG>::NT), \
-                       0, stream, a, a.fused_ctl, mode == 1 ? 1 : 0, mode == 2 ? 1 : 0)
-            const int ks = n - contig_k;
-            if (ks == 3 && contig_k == 10)
-                GPUNTT_FUSED(3, 10);
-            else if (ks == 4 && contig_k == 10)
-                GPUNTT_FUSED(4, 10);
-            else if (ks == 5 && contig_k == 10)
-                GPUNTT_FUSED(5, 10);
-            else if (ks == 6 && contig_k == 10)
-                GPUNTT_FUSED(6, 10);
-            else if (ks == 6 && contig_k == 11)
-                GPUNTT_FUSED(6, 11);
-            else if (ks == 6 && contig_k == 12)
-                GPUNTT_FUSED(6, 12);
-            else
-                throw std::invalid_argument("internal: unsupported single-sweep plan");
-#undef GPUNTT_FUSED
-            GPUNTT_HIP_CHECK(hipGetLastError());
-        }
-
         // 64-bit words with a 61- / 62-bit modulus: LIMIT = 8 / 4 kernels, 4096-coefficient tiles only
         template <bool INV, int LIMSEL>
         void launch_pass_lazy_lim(const Pass& p, bool in_first, bool last, const kern::LazyArgsT<uint64_t>& a,

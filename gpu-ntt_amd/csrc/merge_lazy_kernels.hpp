@@ -36,7 +36,6 @@ namespace gpuntt
             const int* poly_order;           // *_Poly_Ordered: polynomial p lives in slot poly_order[p]
             const T* mul_in;                 // GPU_PolyMul: canonical operand multiplied into the final forward store, or nullptr
             const lazy::Tw<T>* w_pairs;      // 4-step phase 1: prepared W matrix (N pairs)
-            unsigned* fused_ctl;             // single-sweep kernel: zeroed control words (FUSED_CTL_WORDS) or nullptr
             int lim;                         // 64-bit words: 0, or 8 / 4 = a 61- / 62-bit modulus in the call -> the LIMIT = 8 / 4 kernels (host-side switch)
             int n2_log;                      // 4-step phase 1: log2 n2
             int batch;                       // > 1: polynomials of the call, blocks are ordered poly-minor (4-step phase 1; big-ring passes)
@@ -260,26 +259,16 @@ namespace gpuntt
         // WMUL (STRIDED passes): natural-order 4-step, first forward pass: the column transforms run
         // in place on the row-major input, the W product is applied on the way out; blocks are
         // ordered poly-minor (blk_override) so a batch shares each W slice in L2.
-        // COH_IN (fused single-sweep kernel, second phase): the tile was written earlier in this launch
-        // by other workgroups of the same XCD, so it is read past the CU's vector L1 (sc1 loads are
-        // served by the XCD's L2, which those stores went through).
-        template <bool COH, typename T> __device__ __forceinline__ T ld_in(const T* p)
-        {
-            if constexpr (COH)
-                return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else
-                return *p;
-        }
         // streaming forms (global_load / global_store ... nt): the first pass reads input nobody reads again, the
         // last pass writes output nobody reads again -- what should stay in the caches is the hand-off between the
         // passes (C2 0.437 -> 0.422 ms, C5 0.235 -> 0.227 ms, C4 0.310 -> 0.303 ms; nt on the hand-off loads as well
         // changes nothing)
-        template <bool NT_, bool COH, typename T> __device__ __forceinline__ T ld_stream(const T* p)
+        template <bool NT_, typename T> __device__ __forceinline__ T ld_stream(const T* p)
         {
-            if constexpr (NT_ && !COH)
+            if constexpr (NT_)
                 return __builtin_nontemporal_load(p);
             else
-                return ld_in<COH>(p);
+                return *p;
         }
         template <bool NT_, typename T> __device__ __forceinline__ void st_stream(T* p, T v)
         {
@@ -310,7 +299,7 @@ namespace gpuntt
         }
 
         template <typename T, int TLOG, bool EXACT, bool INV, bool CONTIG, int K, int IN_BOUND, bool LAST,
-                  int FST = 0, bool WMUL = false, bool COH_IN = false, bool PERSIST = false, int LIM = 0>
+                  int FST = 0, bool WMUL = false, int LIM = 0>
         __device__ __forceinline__ void pass_body(const LazyArgsT<T>& a, T* lds, T q_value, T q_bit, T q_mu,
                                                   int mi, unsigned long long fst_poly = 0,
                                                   unsigned fst_tile = 0, long long blk_override = -1,
@@ -335,12 +324,7 @@ namespace gpuntt
             // instruction, WIO) with a wave-local transposition instead of the block-wide coalescing pass.
             constexpr bool WIO_OK = CONTIG && !FST && !MULTI_POLY && !EXACT && (TL >= 10);
             constexpr int WIO = 6;
-            // PERSIST (persistent single-launch kernel): opaque copy of the thread id, so that nothing derived
-            // from it (lane offsets, LDS addresses of either pass) is hoisted out of the polynomial loop and
-            // kept alive across both passes
-            int t = threadIdx.x;
-            if constexpr (PERSIST)
-                asm volatile("" : "+v"(t));
+            const int t = threadIdx.x;
             constexpr bool SEG = (FST == 2);
             using Map = LTileMap<TLOG, CONTIG, K, SEG>;
             Map map = SEG   ? Map((fst_poly << a.poly_shift) +
@@ -536,7 +520,7 @@ namespace gpuntt
                             const unsigned lane = map.part(elem_of<WL>(t, 0));
 #pragma unroll
                             for (int j = 0; j < EPT; j++)
-                                v[j] = ld_stream<(IN_BOUND == 1), COH_IN>((src + (map.base + map.part(static_cast<unsigned>(j) << WL))) + lane);
+                                v[j] = ld_stream<(IN_BOUND == 1)>((src + (map.base + map.part(static_cast<unsigned>(j) << WL))) + lane);
                             if (signed_in)
                             {
 #pragma unroll
@@ -560,7 +544,7 @@ namespace gpuntt
                         T tmp[EPT];
 #pragma unroll
                         for (int j = 0; j < EPT; j++)
-                            tmp[j] = ld_stream<(IN_BOUND == 1), COH_IN>((src + (map.base + map.part(static_cast<unsigned>(j) << IWL))) + lane);
+                            tmp[j] = ld_stream<(IN_BOUND == 1)>((src + (map.base + map.part(static_cast<unsigned>(j) << IWL))) + lane);
                         T* li = lds + lds_pad(elem_of<IWL>(t, 0));
 #pragma unroll
                         for (int j = 0; j < EPT; j++)
@@ -579,7 +563,7 @@ namespace gpuntt
                             const unsigned lane = map.part(static_cast<unsigned>(t));
 #pragma unroll
                             for (int j = 0; j < EPT; j++)
-                                tmp[j] = ld_stream<(IN_BOUND == 1), COH_IN>((src + (map.base + map.part(static_cast<unsigned>(NT * j)))) + lane);
+                                tmp[j] = ld_stream<(IN_BOUND == 1)>((src + (map.base + map.part(static_cast<unsigned>(NT * j)))) + lane);
                             if (signed_in)
                             {
 #pragma unroll
@@ -1006,178 +990,8 @@ namespace gpuntt
                 qb = md.bit;
                 qm = md.mu;
             }
-            pass_body<T, TLOG, false, INV, CONTIG, K, IN_BOUND, LAST, 0, false, false, false, LIM>(a, lds, qv, qb, qm, mi, 0,
+            pass_body<T, TLOG, false, INV, CONTIG, K, IN_BOUND, LAST, 0, false, LIM>(a, lds, qv, qb, qm, mi, 0,
                                                                                                    0, blk);
-        }
-
-        // ---- single-sweep kernel for rings of 2 .. 64 tiles -----------------------------------
-        // Replaces the two launches (strided pass, contiguous pass) of a two-pass plan -- reference
-        // src/include/gpuntt/ntt_merge/ntt.cuh:634-636 / src/lib/ntt_merge/ntt.cu:2607-2647 run two
-        // (three) ForwardCore launches per transform, each a full HBM sweep -- by ONE persistent launch
-        // in which HBM sees every coefficient once:
-        //   * the G = N / TILE workgroups of a GROUP own one polynomial at a time; member m runs tile m
-        //     of the first pass, the group meets at an arrival counter, member m runs tile m of the
-        //     second pass (every tile of the second pass needs every tile of the first);
-        //   * a group is made of workgroups that the dispatcher places on ONE XCD (block b -> XCD b % 8,
-        //     MI355X_MICROARCH.md), so the hand-off tile travels through that XCD's 4 MiB L2: plain
-        //     stores (write-through L1 -> L2), s_waitcnt vmcnt(0), arrive; the readers poll the counter,
-        //     then read the tile with sc1 loads (past their own L1).  The second pass stores its result
-        //     over the intermediate lines while they are still dirty in L2, so only the result reaches HBM;
-        //   * placement is a speed assumption, never a correctness one: every workgroup publishes its
-        //     XCC_ID in the group's mask during a registration round, and a group that finds more than
-        //     one XCD in its mask switches to the agent-scope release / acquire fences;
-        //   * groups are index-contiguous, so under in-order dispatch the lowest unfinished groups are
-        //     always resident and finish without waiting for later workgroups (no co-residency
-        //     requirement beyond 8 G workgroups); every spin is bounded and traps instead of hanging.
-        // With several groups per XCD at different phases a CU holds HBM-bound and VALU-bound tiles at the
-        // same time, which the back-to-back launches could not.
-        constexpr int FUSED_MAX_GROUPS = 512;
-        // one 128-byte line per group {arrival counter, XCC mask, ...}: a polled word saturates near 90
-        // accesses per microsecond (MI355X_MICROARCH.md, dequeue row), so a line is shared by the G
-        // pollers of its own group only -- with all counters in two lines the polls of 1024 workgroups
-        // queued for ~10 us each and the kernel ran 2.4x slower than the two launches it replaces
-        constexpr int FUSED_CTL_STRIDE = 32;
-        constexpr int FUSED_CTL_WORDS = FUSED_CTL_STRIDE * (FUSED_MAX_GROUPS + 1); // groups | error word
-        constexpr unsigned FUSED_SPIN_LIMIT = 4u << 20;           // polls (~2 us each) before giving up
-
-        // arrive at the group's counter and wait until `target` arrivals; slow = agent-scope fences
-        __device__ __forceinline__ void group_barrier(unsigned* cnt, unsigned target, bool slow, unsigned* err)
-        {
-            // every wave's stores of the finished pass have reached L2 (write-through L1)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (threadIdx.x == 0)
-            {
-                if (slow)
-                {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // L2 write-back: readers sit on another XCD
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-                __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                unsigned spins = 0;
-                while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target)
-                {
-                    __builtin_amdgcn_s_sleep(16); // ~0.5 us between polls
-                    if (++spins > FUSED_SPIN_LIMIT)
-                    {
-                        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __builtin_trap(); // a member of the group never arrived: fail loudly, never hang
-                    }
-                }
-                if (slow)
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            }
-            __syncthreads();
-        }
-
-        // KS strided + KC contiguous stages, n = KS + KC, G = 2^(n - TLOG).  group_mode 0: XCD-aligned
-        // groups (members b = 8 (G g + m) + x); 1: consecutive block indices (spans all XCDs -- test hook
-        // for the placement check).  force_slow: take the fence protocol regardless (test hook).
-        template <typename T, int TLOG, bool INV, int KS, int KC>
-        __global__ __launch_bounds__(LTile<TLOG>::NT, (LOcc<TLOG, T>::WAVES)) void merge_fused_lazy(LazyArgsT<T> a,
-                                                                                               unsigned* ctl,
-                                                                                               int group_mode,
-                                                                                               int force_slow)
-        {
-#if defined(__HIP_DEVICE_COMPILE__)
-            using M = lazy::Mod<T>;
-            constexpr int GL = KS + KC - TLOG;
-            constexpr unsigned G = 1u << GL;
-            static_assert(GL >= 1 && GL <= 6, "fused kernel: 2 .. 64 tiles per polynomial");
-            __shared__ T lds[LTile<TLOG>::LDS_ELEMS];
-            __shared__ unsigned s_slow;
-            if (a.go_flag != nullptr && *a.go_flag == 0u)
-                return;
-            unsigned m, gid;
-            if (group_mode == 0)
-            {
-                const unsigned x = blockIdx.x & 7u, r = blockIdx.x >> 3;
-                m = r & (G - 1u);
-                gid = ((r >> GL) << 3) | x;
-            }
-            else
-            {
-                m = blockIdx.x & (G - 1u);
-                gid = blockIdx.x >> GL;
-            }
-            const unsigned ngroups = gridDim.x >> GL;
-            const unsigned polys = static_cast<unsigned>(a.total >> a.n);
-            unsigned* cnt = ctl + FUSED_CTL_STRIDE * gid;
-            unsigned* msk = cnt + 1;
-            unsigned* err = ctl + FUSED_CTL_STRIDE * FUSED_MAX_GROUPS;
-
-            // registration round: who shares this group's XCD?
-            if (threadIdx.x == 0)
-            {
-                unsigned xcc;
-                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
-                __hip_atomic_fetch_or(msk, 1u << xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            unsigned target = G;
-            group_barrier(cnt, target, false, err);
-            if (threadIdx.x == 0)
-            {
-                const unsigned mask = __hip_atomic_load(msk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                s_slow = (force_slow != 0 || (mask & (mask - 1u)) != 0u) ? 1u : 0u;
-            }
-            __syncthreads();
-            const bool slow = s_slow != 0u;
-
-            // The argument block is re-read from the kernarg segment at the head of each pass (through a
-            // laundered pointer, or the loads would be merged and ~50 scalar registers pinned across both
-            // passes and the loop: measured 90 SGPR + 87 VGPR spills without this).
-            auto fresh_args = [&]() { return a; };
-            for (unsigned p = gid; p < polys; p += ngroups)
-            {
-                const long long blk = static_cast<long long>((static_cast<unsigned long long>(p) << GL) | m);
-                {
-                    LazyArgsT<T> a1 = fresh_args();
-                    a1.p_lo = KC; // the strided pass covers stage bits [KC, KC + KS)
-                    T qv = a1.q, qb = a1.q_bit, qm = a1.q_mu;
-                    int mi = 0;
-                    if (a1.mods != nullptr)
-                    {
-                        mi = static_cast<int>(p % static_cast<unsigned>(a1.mod_count));
-                        const Modulus<T> md = a1.mods[a1.mod_order != nullptr ? a1.mod_order[mi] : mi];
-                        qv = md.value;
-                        qb = md.bit;
-                        qm = md.mu;
-                    }
-                    // first pass: input -> lazy intermediate in `out`
-                    if constexpr (!INV)
-                        pass_body<T, TLOG, false, false, false, KS, 1, false, 0, false, false, true>(a1, lds, qv, qb, qm, mi, 0, 0, blk);
-                    else
-                        pass_body<T, TLOG, false, true, true, KC, 1, false, 0, false, false, true>(a1, lds, qv, qb, qm, mi, 0, 0, blk);
-                }
-                target += G;
-                group_barrier(cnt, target, slow, err);
-                {
-                    LazyArgsT<T> a2 = fresh_args();
-                    a2.in = a2.out; // second pass: in place on `out`, read past L1
-                    a2.p_lo = KC;
-                    T qv = a2.q, qb = a2.q_bit, qm = a2.q_mu;
-                    int mi = 0;
-                    if (a2.mods != nullptr)
-                    {
-                        mi = static_cast<int>(p % static_cast<unsigned>(a2.mod_count));
-                        const Modulus<T> md = a2.mods[a2.mod_order != nullptr ? a2.mod_order[mi] : mi];
-                        qv = md.value;
-                        qb = md.bit;
-                        qm = md.mu;
-                    }
-                    if constexpr (!INV)
-                        pass_body<T, TLOG, false, false, true, KC, M::LIMIT, true, 0, false, true, true>(a2, lds, qv, qb, qm, mi, 0, 0, blk);
-                    else
-                        pass_body<T, TLOG, false, true, false, KS, M::LIMIT, true, 0, false, true, true>(a2, lds, qv, qb, qm, mi, 0, 0, blk);
-                }
-                __syncthreads(); // the next polynomial's first pass reuses the exchange buffer
-            }
-#else
-            (void) a;
-            (void) ctl;
-            (void) group_mode;
-            (void) force_slow;
-#endif
         }
 
         // natural-order 4-step, forward pass 1: STRIDED column transforms (K = log2 n1 top bits of the

@@ -66,35 +66,21 @@ namespace gpuntt
         //        each returning at once when the flag says the call belongs to the other family.
         // Tiny single-modulus rings (below 2^5 / 2^11), small RNS jobs, rings above 2^24 and RNS
         // stacks of rings below one tile use the generic kernels only.
-        // GPUNTT_PATH=generic | fast overrides the size heuristic (testing / A-B timing);
+        // option path = generic | fast overrides the size heuristic (testing / A-B timing; host::set_option);
         // moduli without the headroom always take the generic kernels.
-        inline int forced_path()
-        {
-            static const int mode = [] {
-                const char* e = std::getenv("GPUNTT_PATH");
-                if (e == nullptr)
-                    return 0;
-                if (std::strcmp(e, "generic") == 0)
-                    return 1;
-                if (std::strcmp(e, "fast") == 0)
-                    return 2;
-                if (std::strcmp(e, "fast-strict") == 0)
-                    return 3; // test hook: like "fast", and a call the fast kernels cannot take throws
-                return 0;
-            }();
-            return mode;
-        }
+        using host::forced_path;
 
         template <typename TU> inline bool lazy_eligible(int n_power, int batch_size, int mod_count)
         {
             const bool can = n_power <= host::LAZY_MAX_N_POWER &&
                              !(mod_count > 1 && n_power < host::lazy_tile_log<TU>(n_power)) && // a tile would mix moduli
                              (static_cast<unsigned long long>(mod_count) << n_power) <= (1ull << 28); // 4 GiB table
-            if (forced_path() == 3 && !can)
-                throw std::invalid_argument("fast path unavailable for this call (GPUNTT_PATH=fast-strict)");
-            if (!can || forced_path() == 1)
+            const int fp = forced_path();
+            if (fp == 3 && !can)
+                throw std::invalid_argument("fast path unavailable for this call (path = fast-strict)");
+            if (!can || fp == 1)
                 return false;
-            if (forced_path() >= 2)
+            if (fp == 2 || fp == 3)
                 return true;
             // Single modulus: measured at batch = 1 (profiles/batch1_r01.txt) the prepared-twiddle
             // kernels win from 2^5 (64-bit) / 2^11 (32-bit) upwards even though they cost one
@@ -104,6 +90,22 @@ namespace gpuntt
             // RNS stacks pay for the dual launch: not worth it for tiny jobs
             return (static_cast<unsigned long long>(batch_size) << n_power) >= (1ull << 15) &&
                    batch_size >= 2;
+        }
+
+        // drop-in calls: eligible AND the per-(device, stream) scratch for the prepared twiddles can be had.  A device
+        // without room for it (several streams, nearly full HBM) gets the generic kernels, which need none.
+        template <typename TU>
+        inline bool lazy_eligible(int n_power, int batch_size, int mod_count, hipStream_t stream)
+        {
+            if (!lazy_eligible<TU>(n_power, batch_size, mod_count))
+                return false;
+            const size_t entries = (static_cast<size_t>(mod_count) << n_power) + mod_count;
+            const size_t norm_bytes = (sizeof(lazy::NormConst) * static_cast<size_t>(mod_count) + 15u) & ~size_t(15);
+            if (host::lazy_workspace(stream, sizeof(lazy::Tw<TU>) * entries + 16 + norm_bytes, true) != nullptr)
+                return true;
+            if (forced_path() == 3)
+                throw std::invalid_argument("fast path unavailable for this call: no device memory for the twiddle scratch");
+            return false;
         }
 
         // single-modulus calls and NTTPlan see their moduli on the host: 64-bit words take 61-bit moduli on the
@@ -146,21 +148,17 @@ namespace gpuntt
                     lim = 8;
             const int perm_tile_log = (n_power >= tl) ? tl : 0;
             const size_t entries = (static_cast<size_t>(mod_count) << n_power) + mod_count;
-            // workspace: twiddle pairs | n^-1 pairs | go-flag | per-modulus normalisation constants |
-            // control words of the single-sweep kernel (zeroed by the preparation launch)
+            // workspace: twiddle pairs | n^-1 pairs | go-flag | per-modulus normalisation constants
             const size_t norm_bytes = (sizeof(lazy::NormConst) * static_cast<size_t>(mod_count) + 15u) & ~size_t(15);
-            const bool fused = !lim && host::lazy_use_fused<TU>(n_power, tl, ninv_dev != nullptr || ninv_single != nullptr,
-                                                                 static_cast<unsigned long long>(batch_size));
-            const size_t tail = 16 + norm_bytes + (fused ? sizeof(unsigned) * kern::FUSED_CTL_WORDS : 0);
+            const size_t tail = 16 + norm_bytes;
             auto* ws = static_cast<TW*>(host::lazy_workspace(stream, sizeof(TW) * entries + tail));
             TW* ws_ninv = ws + (static_cast<size_t>(mod_count) << n_power);
             unsigned char* tail_p = reinterpret_cast<unsigned char*>(ws + entries);
             unsigned* go_flag = mods ? reinterpret_cast<unsigned*>(tail_p) : nullptr;
             auto* norm_arr = mods ? reinterpret_cast<lazy::NormConst*>(tail_p + 16) : nullptr;
-            unsigned* fused_ctl = fused ? reinterpret_cast<unsigned*>(tail_p + 16 + norm_bytes) : nullptr;
             host::launch_prep<TU>(roots, ws, mods, m.value, mod_count, n_power, neg, perm_tile_log, ninv_dev,
                                   ninv_dev ? ws_ninv : nullptr, go_flag, norm_arr, stream, mod_order, ninv_single,
-                                  ninv_dev != nullptr, fused_ctl);
+                                  ninv_dev != nullptr);
             kern::LazyArgsT<TU> a{};
             a.in = in;
             a.out = out;
@@ -173,7 +171,6 @@ namespace gpuntt
             a.ninv = TW{0, 0};
             a.go_flag = go_flag;
             a.lim = lim;
-            a.fused_ctl = fused_ctl;
             a.mod_order = mod_order;
             a.poly_order = nullptr;
             a.norm = lazy::make_norm_const(static_cast<uint64_t>(m.value), static_cast<uint64_t>(m.bit));
@@ -281,7 +278,7 @@ namespace gpuntt
             run_percoefficient<TU, false>(a, cfg.n_power, batch_size, in_flags, 0u, cfg.stream);
             return;
         }
-        if (batch_size > 0 && fast_modulus<TU>(modulus) && lazy_eligible<TU>(cfg.n_power, batch_size, 1))
+        if (batch_size > 0 && fast_modulus<TU>(modulus) && lazy_eligible<TU>(cfg.n_power, batch_size, 1, cfg.stream))
         {
             kern::LazyArgsT<TU> la =
                 lazy_args<TU>(device_in, device_out, root_of_unity_table, modulus, nullptr, 1, nullptr,
@@ -317,7 +314,7 @@ namespace gpuntt
             run_percoefficient<TU, true>(a, cfg.n_power, batch_size, 0u, out_flags, cfg.stream);
             return;
         }
-        if (batch_size > 0 && fast_modulus<TU>(modulus) && lazy_eligible<TU>(cfg.n_power, batch_size, 1) &&
+        if (batch_size > 0 && fast_modulus<TU>(modulus) && lazy_eligible<TU>(cfg.n_power, batch_size, 1, cfg.stream) &&
             cfg.mod_inverse < modulus.value)
         {
             kern::LazyArgsT<TU> la =
@@ -374,7 +371,7 @@ namespace gpuntt
             run_percoefficient<TU, false>(a, cfg.n_power, batch_size, in_flags, 0u, cfg.stream);
             return;
         }
-        if (batch_size > 0 && lazy_eligible<TU>(cfg.n_power, batch_size, mod_count))
+        if (batch_size > 0 && lazy_eligible<TU>(cfg.n_power, batch_size, mod_count, cfg.stream))
         {
             kern::LazyArgsT<TU> la =
                 lazy_args<TU>(device_in, device_out, root_of_unity_table, Modulus<TU>(), modulus, mod_count,
@@ -418,7 +415,7 @@ namespace gpuntt
             return;
         }
         if (batch_size > 0 && cfg.mod_inverse != nullptr &&
-            lazy_eligible<TU>(cfg.n_power, batch_size, mod_count))
+            lazy_eligible<TU>(cfg.n_power, batch_size, mod_count, cfg.stream))
         {
             kern::LazyArgsT<TU> la =
                 lazy_args<TU>(device_in, reinterpret_cast<TU*>(device_out), root_of_unity_table,
@@ -572,7 +569,7 @@ namespace gpuntt
         T* second = (device_out == device_a) ? device_a : device_b; // transformed into device_out
         GPU_NTT<T>(first, first, forward_table, modulus, f, batch_size);
         if (modulus.value >= 3 && modulus.bit <= T(lazy::Mod<T>::MAX_BIT) &&
-            lazy_eligible<T>(cfg.n_power, batch_size, 1))
+            lazy_eligible<T>(cfg.n_power, batch_size, 1, cfg.stream))
         {
             kern::LazyArgsT<T> la = lazy_args<T>(second, device_out, forward_table, modulus, nullptr, 1, nullptr,
                                                  cfg.n_power, cfg.reduction_poly, batch_size, cfg.stream);
@@ -617,7 +614,7 @@ namespace gpuntt
         // moduli live on the device: fast kernels (multiplying on their final store) and generic
         // kernels + pointwise_mul are both enqueued, the go-flag decides which family runs
         const unsigned* skip_flag = nullptr;
-        if (lazy_eligible<T>(cfg.n_power, batch_size, mod_count))
+        if (lazy_eligible<T>(cfg.n_power, batch_size, mod_count, cfg.stream))
         {
             kern::LazyArgsT<T> la = lazy_args<T>(second, device_out, forward_table, Modulus<T>(), modulus, mod_count,
                                                  nullptr, cfg.n_power, cfg.reduction_poly, batch_size, cfg.stream);
@@ -793,13 +790,16 @@ namespace gpuntt
                 if (mod_count == 1)
                     host::launch_prep<T>(table_device, p->tw, nullptr, p->moduli[0].value, 1, n_power, neg,
                                          perm_tile_log, nullptr, nullptr, nullptr, nullptr, stream, nullptr,
-                                         inverse ? &p->ninv[0] : nullptr, false, nullptr);
+                                         inverse ? &p->ninv[0] : nullptr, false);
                 else
                     host::launch_prep<T>(table_device, p->tw, p->mods_dev, T(0), mod_count, n_power, neg,
                                          perm_tile_log, inverse ? p->ninv_dev : nullptr,
                                          inverse ? p->ninv_pairs : nullptr, p->go_flag, p->norm_arr, stream,
-                                         nullptr, nullptr, inverse, nullptr);
+                                         nullptr, nullptr, inverse);
             }
+            // the plan is complete when the constructor returns: execute() may run on ANY stream without an
+            // external dependency on the construction stream (one host wait, once per plan)
+            GPUNTT_HIP_CHECK(hipStreamSynchronize(stream));
         }
         catch (...)
         {
@@ -891,6 +891,7 @@ namespace gpuntt
     template class NTTPlan<Data64>;
 
     void GPU_NTT_ReleaseWorkspaces() { host::release_workspaces(); }
+    bool GPU_NTT_SetOption(const char* name, const char* value) { return host::set_option(name, value); }
 
     // ---------------------------------------------------------------- ordered RNS ----
     namespace
@@ -914,7 +915,7 @@ namespace gpuntt
             const unsigned* skip_flag = nullptr;
             // fast path: whole tiles inside one polynomial
             if (cfg.n_power >= host::lazy_tile_log<T>(cfg.n_power) &&
-                lazy_eligible<T>(cfg.n_power, batch_size, mod_count) && (!inv || cfg.mod_inverse != nullptr))
+                lazy_eligible<T>(cfg.n_power, batch_size, mod_count, cfg.stream) && (!inv || cfg.mod_inverse != nullptr))
             {
                 kern::LazyArgsT<T> la =
                     lazy_args<T>(device_in, device_out, table, Modulus<T>(), modulus, mod_count,

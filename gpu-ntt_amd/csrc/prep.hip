@@ -10,7 +10,9 @@
 // reciprocal itself is a host division for a single modulus, one restoring division per block for
 // an RNS stack).  Nothing is cached between calls, so a caller that rewrites its table in place
 // is always honoured.
+#include <atomic>
 #include <cstdlib>
+#include <string>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -94,15 +96,9 @@ namespace gpuntt
                                                              unsigned* __restrict__ go_flag,
                                                              lazy::NormConst* __restrict__ norm_arr,
                                                              const int* __restrict__ mod_order,
-                                                             T ninv_single, int fold_ninv,
-                                                             unsigned* __restrict__ fused_ctl)
+                                                             T ninv_single, int fold_ninv)
         {
             const unsigned long long gid = blockIdx.x * 256ull + threadIdx.x;
-            // control words of the single-sweep kernel launched behind this one (grid-stride: tiny tables)
-            if (fused_ctl != nullptr)
-                for (unsigned long long i = gid; i < static_cast<unsigned long long>(FUSED_CTL_WORDS);
-                     i += static_cast<unsigned long long>(gridDim.x) * 256ull)
-                    fused_ctl[i] = 0u;
             if (gid == 0 && go_flag != nullptr)
             {
                 // every modulus must leave the lazy kernels their headroom
@@ -331,10 +327,17 @@ namespace gpuntt
 
         void release_workspaces()
         {
-            std::lock_guard<std::mutex> lock(g_ws_mutex);
-            for (auto& kv : g_ws)
+            // lock order: never hold the map's mutex while taking a slot's -- a thread inside an API call holds its
+            // slot and re-enters lazy_workspace() (map mutex) for the next buffer of the same call
+            std::vector<Slot*> slots;
             {
-                Slot& s = kv.second;
+                std::lock_guard<std::mutex> lock(g_ws_mutex);
+                for (auto& kv : g_ws)
+                    slots.push_back(&kv.second); // map nodes never move and are never erased
+            }
+            for (Slot* sp : slots)
+            {
+                Slot& s = *sp;
                 std::lock_guard<std::recursive_mutex> sl(s.mu);
                 if (s.ptr != nullptr)
                 {
@@ -357,12 +360,60 @@ namespace gpuntt
             return static_cast<T>((static_cast<unsigned __int128>(1) << (W - 1 + b)) / q);
         }
 
+        // ---- tuning / test options --------------------------------------------------------------------
+        // The library reads NO environment variable: every switch below is a process-wide option set through
+        // set_option() (C ABI gpuntt_set_option; the Python harness forwards GPUNTT_* variables to it when it
+        // loads the library, which is how the A/B scripts under tools/ and the tests drive them).
+        namespace
+        {
+            struct Options
+            {
+                std::atomic<int> path{0};       // 0 size heuristic, 1 generic, 2 fast, 3 fast-strict, 4 generic-capped
+                std::atomic<int> contig_k{0};   // 8 .. 12: stage split of the 4096-coefficient-tile plans
+                std::atomic<int> xcd_order{1};  // XCD-aware poly-minor block order
+                std::atomic<int> lim31{1};      // wider lazy ranges where the modulus allows them
+                std::atomic<int> reverse{1};    // consecutive passes walk the batch in opposite directions
+                std::atomic<int> big_tiles{14}; // largest 64-bit ring done in one big tile
+                std::atomic<int> u32_tile{0};   // 12 | 14: 32-bit tile above 2^14
+            } g_opt;
+        } // namespace
+
+        bool set_option(const char* name, const char* value)
+        {
+            if (name == nullptr || value == nullptr)
+                return false;
+            const std::string k(name), v(value);
+            const int iv = std::atoi(value);
+            if (k == "path")
+            {
+                const int m = v == "generic" ? 1 : v == "fast" ? 2 : v == "fast-strict" ? 3 : v == "generic-capped" ? 4
+                              : (v == "default" || v.empty()) ? 0 : -1;
+                if (m < 0)
+                    return false;
+                g_opt.path = m;
+            }
+            else if (k == "contig_k")
+                g_opt.contig_k = (iv >= 8 && iv <= 12) ? iv : 0;
+            else if (k == "xcd_order")
+                g_opt.xcd_order = iv != 0;
+            else if (k == "lim31")
+                g_opt.lim31 = iv != 0;
+            else if (k == "reverse")
+                g_opt.reverse = iv != 0;
+            else if (k == "u64_big_tiles")
+                g_opt.big_tiles = iv;
+            else if (k == "u32_tile")
+                g_opt.u32_tile = (iv == 12 || iv == 14) ? iv : 0;
+            else
+                return false;
+            return true;
+        }
+
+        int forced_path() { return g_opt.path.load(std::memory_order_relaxed); }
+
         int lazy_contig_k(int n)
         {
-            static const int forced = [] {
-                const char* e = std::getenv("GPUNTT_CONTIG_K");
-                return e ? std::atoi(e) : 0;
-            }();
+            const int forced = g_opt.contig_k.load(std::memory_order_relaxed);
             if (forced >= 8 && forced <= 12)
                 return forced;
             // The strided pass is HBM-bound with idle VALU slots while the contiguous pass is
@@ -375,86 +426,14 @@ namespace gpuntt
 
         unsigned lazy_order_flags()
         {
-            static const unsigned v = [] {
-                const char* e = std::getenv("GPUNTT_XCD_ORDER");
-                return (e != nullptr && std::atoi(e) == 0) ? static_cast<unsigned>(kern::F_PLAIN_ORDER) : 0u;
-            }();
-            return v;
+            return g_opt.xcd_order.load(std::memory_order_relaxed) ? 0u : static_cast<unsigned>(kern::F_PLAIN_ORDER);
         }
+        bool lazy_lim31_enabled() { return g_opt.lim31.load(std::memory_order_relaxed) != 0; }
+        bool lazy_reverse_passes() { return g_opt.reverse.load(std::memory_order_relaxed) != 0; }
+        int lazy_u64_big_tiles() { return g_opt.big_tiles.load(std::memory_order_relaxed); }
+        int lazy_u32_tile_override() { return g_opt.u32_tile.load(std::memory_order_relaxed); }
 
-        bool lazy_lim31_enabled()
-        {
-            static const bool v = [] {
-                const char* e = std::getenv("GPUNTT_LIM31");
-                return !(e != nullptr && std::atoi(e) == 0);
-            }();
-            // the opt-in experiment kernels (single-launch, pipelined) exist for the 16 q range only
-            return v && lazy_fused_env() != 1 && lazy_pipe_env() <= 0;
-        }
-
-        bool lazy_reverse_passes()
-        {
-            static const bool v = [] {
-                const char* e = std::getenv("GPUNTT_NO_REVERSE");
-                return !(e != nullptr && std::atoi(e) != 0);
-            }();
-            return v;
-        }
-        int lazy_fused_env()
-        {
-            static const int v = [] {
-                const char* e = std::getenv("GPUNTT_FUSED");
-                return e ? std::atoi(e) : -1; // -1: size heuristic
-            }();
-            return v;
-        }
-        int lazy_fused_mode()
-        {
-            static const int v = [] {
-                const char* e = std::getenv("GPUNTT_FUSED_MODE");
-                return e ? std::atoi(e) : 0;
-            }();
-            return v;
-        }
-        int device_cu_count()
-        {
-            // per device, cached: the grid of the persistent kernel is sized from it
-            static std::mutex mu;
-            static std::map<int, int> cache;
-            int dev = 0;
-            GPUNTT_HIP_CHECK(hipGetDevice(&dev));
-            std::lock_guard<std::mutex> lock(mu);
-            auto it = cache.find(dev);
-            if (it != cache.end())
-                return it->second;
-            int cus = 0;
-            GPUNTT_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-            if (cus <= 0)
-                cus = 256;
-            cache[dev] = cus;
-            return cus;
-        }
-
-        int lazy_u64_big_tiles()
-        {
-            static const int v = [] {
-                const char* e = std::getenv("GPUNTT_U64_BIG_TILES");
-                return e ? std::atoi(e) : 14;
-            }();
-            return v;
-        }
-
-        int lazy_u32_tile_override()
-        {
-            static const int forced = [] {
-                const char* e = std::getenv("GPUNTT_U32_TILE");
-                const int v = e ? std::atoi(e) : 0;
-                return (v == 12 || v == 14) ? v : 0;
-            }();
-            return forced;
-        }
-
-        void* lazy_workspace(hipStream_t stream, size_t bytes)
+        void* lazy_workspace(hipStream_t stream, size_t bytes, bool or_null)
         {
             int dev = 0;
             GPUNTT_HIP_CHECK(hipGetDevice(&dev));
@@ -489,7 +468,16 @@ namespace gpuntt
                     s.bytes = 0;
                 }
                 size_t want = bytes < (size_t(1) << 20) ? (size_t(1) << 20) : bytes;
-                GPUNTT_HIP_CHECK(hipMalloc(&s.ptr, want));
+                const hipError_t err = hipMalloc(&s.ptr, want);
+                if (err != hipSuccess)
+                {
+                    // out of device memory: the caller falls back to the kernels that need no scratch
+                    (void) hipGetLastError();
+                    s.ptr = nullptr;
+                    if (or_null)
+                        return nullptr;
+                    GPUNTT_HIP_CHECK(err);
+                }
                 s.bytes = want;
             }
             return s.ptr;
@@ -499,14 +487,14 @@ namespace gpuntt
         void launch_prep(const T* roots, lazy::Tw<T>* ws, const Modulus<T>* mods, T q, int mod_count, int n,
                          bool negacyclic, int perm_tile_log, const T* ninv_arr, lazy::Tw<T>* ws_ninv,
                          unsigned* go_flag, lazy::NormConst* norm_arr, hipStream_t stream, const int* mod_order,
-                         const T* fold_ninv_single, bool fold_ninv_rns, unsigned* fused_ctl)
+                         const T* fold_ninv_single, bool fold_ninv_rns)
         {
             const unsigned long long entries = static_cast<unsigned long long>(mod_count) << n;
             const unsigned grid = static_cast<unsigned>((entries + 255) / 256);
             hipLaunchKernelGGL((kern::prep_twiddles<T>), dim3(grid), dim3(256), 0, stream, roots, ws, mods, q,
                                (mods == nullptr) ? recip_norm_host<T>(q) : static_cast<T>(0), mod_count, n, negacyclic ? 1 : 0, perm_tile_log, ninv_arr, ws_ninv, go_flag, norm_arr, mod_order,
                                fold_ninv_single ? *fold_ninv_single : static_cast<T>(0),
-                               (fold_ninv_single != nullptr || (fold_ninv_rns && ninv_arr != nullptr)) ? 1 : 0, fused_ctl);
+                               (fold_ninv_single != nullptr || (fold_ninv_rns && ninv_arr != nullptr)) ? 1 : 0);
             GPUNTT_HIP_CHECK(hipGetLastError());
         }
         template <typename T>
@@ -559,9 +547,9 @@ namespace gpuntt
 
         template void launch_prep<uint64_t>(const uint64_t*, lazy::Tw64*, const Modulus<uint64_t>*, uint64_t, int,
                                             int, bool, int, const uint64_t*, lazy::Tw64*, unsigned*, lazy::NormConst*, hipStream_t, const int*,
-                                            const uint64_t*, bool, unsigned*);
+                                            const uint64_t*, bool);
         template void launch_prep<uint32_t>(const uint32_t*, lazy::Tw32*, const Modulus<uint32_t>*, uint32_t, int,
                                             int, bool, int, const uint32_t*, lazy::Tw32*, unsigned*, lazy::NormConst*, hipStream_t, const int*,
-                                            const uint32_t*, bool, unsigned*);
+                                            const uint32_t*, bool);
     } // namespace host
 } // namespace gpuntt

@@ -103,18 +103,53 @@ def _timed_collective(fn, dist, device):
     return float(t[0])
 
 
+def _staged(dist, t):
+    """gloo moves host memory only (its scatter / gather have no device form): device tensors are staged through
+    the host around the collective.  RCCL ("nccl") takes them as they are."""
+    return t is not None and t.is_cuda and dist.get_backend() != "nccl"
+
+
+def _scatter(dist, rank, world, full, shard_in):
+    if not _staged(dist, shard_in):
+        dist.scatter(shard_in, list(full.chunk(world)) if rank == 0 else None, src=0)
+        return
+    import torch
+    host = torch.empty(shard_in.shape, dtype=shard_in.dtype)
+    dist.scatter(host, list(full.cpu().chunk(world)) if rank == 0 else None, src=0)
+    shard_in.copy_(host)
+
+
+def _gather(dist, rank, world, shard_out, gathered):
+    if not _staged(dist, shard_out):
+        dist.gather(shard_out, list(gathered.chunk(world)) if rank == 0 else None, dst=0)
+        return
+    import torch
+    host = torch.empty(world * shard_out.numel(), dtype=shard_out.dtype) if rank == 0 else None
+    dist.gather(shard_out.cpu(), list(host.chunk(world)) if rank == 0 else None, dst=0)
+    if rank == 0:
+        gathered.copy_(host)
+
+
+def _broadcast(dist, t, src=0):
+    if not _staged(dist, t):
+        dist.broadcast(t, src=src)
+        return
+    host = t.cpu()
+    dist.broadcast(host, src=src)
+    t.copy_(host)
+
+
 def scatter_transform_gather(dist, rank, world, full, shard_in, shard_out, run_shard, device=None):
     """The batch starts on rank 0 (`full`: world equal shards back to back, None elsewhere): scatter,
     run_shard(shard_in, shard_out) on every rank, gather on rank 0.  Returns (gathered tensor on rank 0 |
-    None, {"scatter_s", "transform_s", "gather_s"}), every part MAX-reduced over the ranks."""
+    None, {"scatter_s", "transform_s", "gather_s"}), every part MAX-reduced over the ranks.  Device tensors go
+    through RCCL directly; under gloo they are staged through the host (same code path otherwise)."""
     import torch
-    scatter_list = list(full.chunk(world)) if rank == 0 else None
-    t_s = _timed_collective(lambda: dist.scatter(shard_in, scatter_list, src=0), dist, device)
+    t_s = _timed_collective(lambda: _scatter(dist, rank, world, full, shard_in), dist, device)
     t_c = _timed_collective(lambda: run_shard(shard_in, shard_out), dist, device)
     gathered = torch.empty(world * shard_out.numel(), dtype=shard_out.dtype, device=shard_out.device) \
         if rank == 0 else None
-    gather_list = list(gathered.chunk(world)) if rank == 0 else None
-    t_g = _timed_collective(lambda: dist.gather(shard_out, gather_list, dst=0), dist, device)
+    t_g = _timed_collective(lambda: _gather(dist, rank, world, shard_out, gathered), dist, device)
     return gathered, {"scatter_s": t_s, "transform_s": t_c, "gather_s": t_g}
 
 
@@ -123,7 +158,7 @@ def end_to_end_leg(dist, rank, world, device, table, d_in, d_out, run_shard, bat
     a batch that lives on rank 0.  The shard contents are this rank's synthetic input replicated (the
     timing does not depend on the values).  Returns a JSON-ready dict."""
     import torch
-    t_b = _timed_collective(lambda: dist.broadcast(table, src=0), dist, device)
+    t_b = _timed_collective(lambda: _broadcast(dist, table, 0), dist, device)
     full = torch.cat([d_in] * world) if rank == 0 else None
     shard = torch.empty_like(d_in)
     _, t = scatter_transform_gather(dist, rank, world, full, shard, d_out, run_shard, device)

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <stdexcept>
 #include <cstdint>
 #include <type_traits>
 
@@ -57,7 +58,15 @@ template <typename T1> struct Modulus
             bit = static_cast<T1>(std::log2(static_cast<double>(mod)) + 1);
             const unsigned sh = static_cast<unsigned>(2 * bit + 1);
             if (sh < sizeof(T2) * 8) // (the reference shifts past the word for bit = 64: undefined; mu stays 0 here)
-                mu = static_cast<T1>((static_cast<T2>(1) << sh) / mod);
+            {
+                const T2 quot = (static_cast<T2>(1) << sh) / mod;
+                // an over-stated width at the top of the domain (a 61-bit prime within double rounding of 2^61 gets
+                // bit = 62) makes 2^(2 bit + 1) / q pass the word: the reference stores the truncated value and its
+                // Barrett product is wrong from then on -- refused here instead of computed with
+                if ((quot >> (sizeof(T1) * 8)) != 0)
+                    throw std::invalid_argument("Invalid modulus! (2^(2*bit+1) / q does not fit the word)");
+                mu = static_cast<T1>(quot);
+            }
         }
     }
     __host__ __device__ Modulus() : value(0), bit(0), mu(0) {}

@@ -78,7 +78,8 @@ namespace gpuntt
     // preparation launch, hipGraph-capturable from the first call.
     //   natural_order false: execute() == GPU_4STEP_NTT (n2 x n1 in, n1 x n2 out, in != out);
     //   natural_order true:  execute() == GPU_4STEP_NTT_NaturalOrder (device_in is scratch).
-    // cfg.stream is the stream the preparation runs on; execute() takes its own.  batch_hint: the batch
+    // cfg.stream is the stream the preparation runs on; the constructor waits for it (one host wait per plan), so
+    // execute() may run on any stream without a dependency on the construction stream.  batch_hint: the batch
     // size the plan will mostly run (decides the row-pass tile the n2 table is laid out for; any batch
     // size is correct).  The caller's tables must stay alive when fast_path() is false (moduli without
     // lazy headroom run GPU_4STEP_NTT / _NaturalOrder on them).

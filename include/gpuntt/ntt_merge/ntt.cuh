@@ -164,7 +164,8 @@ namespace gpuntt
     // caller-owned; nullptr = the plan allocates and owns it).  execute() then launches the transform
     // kernels and nothing else: no allocation, no synchronisation, no preparation launch, no shadow
     // launches for RNS stacks (the moduli are host values here, so the path is known), and it can be
-    // captured into a hipGraph without a warm-up call.
+    // captured into a hipGraph without a warm-up call.  The constructor waits for `stream` before it returns
+    // (one host wait per plan): execute() may run on any stream with no dependency on the construction stream.
     //   table_device       the caller's table exactly as for GPU_NTT / GPU_INTT (slot i at i << n_power);
     //                      it is only read during construction (fast path) -- the generic path keeps
     //                      reading it at execute()
@@ -193,5 +194,17 @@ namespace gpuntt
 
     // frees the per-(device, stream) scratch buffers of the drop-in entry points (synchronises the device)
     void GPU_NTT_ReleaseWorkspaces();
+
+    // Process-wide tuning / test options (extension).  The library reads no environment variable; A/B scripts and
+    // tests set these instead.  name = value:
+    //   path           default | generic | fast | fast-strict | generic-capped   kernel family forced for every call
+    //   contig_k       8..12     stage split of the 4096-coefficient-tile plans (0: built-in choice)
+    //   xcd_order      0 | 1     XCD-aware poly-minor block order (default 1)
+    //   lim31          0 | 1     wider lazy ranges where the modulus allows them (default 1)
+    //   reverse        0 | 1     consecutive passes walk the batch in opposite directions (default 1)
+    //   u64_big_tiles  0|13|14   largest 64-bit ring transformed inside one big tile (default 14)
+    //   u32_tile       0|12|14   32-bit tile size above 2^14 (default 0: built-in choice)
+    // Returns false for an unknown name or value.  Plans keep the choice made when they were created.
+    bool GPU_NTT_SetOption(const char* name, const char* value);
 
 } // namespace gpuntt

@@ -266,6 +266,10 @@ extern "C"
     /* frees the library-owned scratch buffers of the drop-in entry points (synchronises the device) */
     int gpuntt_release_workspaces(void);
 
+    /* process-wide tuning / test option (GPU_NTT_SetOption, include/gpuntt/ntt_merge/ntt.cuh lists the names);
+     * the library itself reads no environment variable */
+    int gpuntt_set_option(const char* name, const char* value);
+
     /* ---- diagnostic: OPERATOR_GPU<T> elementwise on device arrays -----------------------------
      * op: 0 add, 1 sub, 2 mult, 3 reduce (unsigned a), 4 reduce (a read as signed), 5 centered_reduction;
      * b is ignored by ops 3..5 */

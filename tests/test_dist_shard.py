@@ -91,3 +91,24 @@ def test_two_rank_gloo_sharded_equals_unsharded(tmp_path):
     assert digs == want
     e2e = [l for l in r.stdout.splitlines() if l.startswith("E2E")][0].split()[1]
     assert e2e == hashlib.sha256(np.concatenate(full).tobytes()).hexdigest()
+
+
+def test_bench_starts_its_own_ranks_without_torchrun():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment re-executes itself under
+    torch.distributed.run; on a host without a GPU the ranks rendezvous over gloo and print the dry-run line
+    (value null): launch, sharding and timing plumbing are exercised before an 8-GPU lease ever is"""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--config", "c5"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    import torch
+    if torch.cuda.is_available():
+        assert d["n_gpus"] == 2  # a real two-GPU run (or a launch error above)
+        return
+    assert d["dry_run"] is True and d["value"] is None and d["n_gpus"] == 2 and d["steps"] == 3
+    # weak scaling: every rank its own 512 polynomials, shard bounds multiples of the 8 primes
+    assert d["config"]["shards"] == [[0, 512], [512, 1024]]

@@ -126,7 +126,7 @@ def test_fourstep_natural_order_vs_oracle(g, bits):
 def test_fourstep_rns_overload_generic_kernels_on_capped_grid(g):
     """the RNS overload with one device-side modulus enqueues the generic kernels behind the fast
     ones; when they own the call (61/62-bit modulus) they run on a capped grid that walks the tiles.
-    GPUNTT_PATH=generic-capped forces exactly that state for a pool prime."""
+    option path = generic-capped forces exactly that state for a pool prime."""
     import torch
     P = O.Port(64)
     logn, batch = 20, 8  # 2048 tiles > 1024 blocks
@@ -134,16 +134,12 @@ def test_fourstep_rns_overload_generic_kernels_on_capped_grid(g):
     oprm = P.fourstep_params(logn)
     x = P.splitmix(901, 0, batch * p4.n, p4.modulus.value)
     want = P.fourstep_ntt(x, oprm)
-    old = os.environ.get("GPUNTT_PATH")
-    os.environ["GPUNTT_PATH"] = "generic-capped"
+    g.set_option("path", "generic-capped")
     try:
         got = run_fourstep(g, p4, x, batch, inverse=False, rns=True)
         back = run_fourstep(g, p4, P.fourstep_intt_first_transpose(want, oprm), batch, inverse=True, rns=True)
     finally:
-        if old is None:
-            del os.environ["GPUNTT_PATH"]
-        else:
-            os.environ["GPUNTT_PATH"] = old
+        g.set_option("path", os.environ.get("GPUNTT_PATH", "default"))
     assert np.array_equal(got, want)
     assert np.array_equal(back, x)
 
@@ -161,16 +157,12 @@ def test_fourstep_natural_order_generic_fallback(g):
     d_in = g.to_device(x)
     d_out = torch.zeros_like(d_in)
     cf = g.ntt4step_configuration(n_power=logn, ntt_type=g.FORWARD)
-    old = os.environ.get("GPUNTT_PATH")
-    os.environ["GPUNTT_PATH"] = "generic"  # the 4-step hosts read it per call
+    g.set_option("path", "generic")
     try:
         g.GPU_4STEP_NTT_NaturalOrder(d_in, d_out, *tf, p4.modulus, cf, 1)
         torch.cuda.synchronize()
     finally:
-        if old is None:
-            del os.environ["GPUNTT_PATH"]
-        else:
-            os.environ["GPUNTT_PATH"] = old
+        g.set_option("path", os.environ.get("GPUNTT_PATH", "default"))
     assert np.array_equal(g.to_host(d_out), P.fourstep_ntt(x, oprm))
 
 

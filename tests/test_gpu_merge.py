@@ -297,30 +297,6 @@ def test_full_size_c4_properties(g):
         assert np.array_equal(g.to_host(out), x)
 
 
-def test_single_launch_kernel_opt_in(g):
-    """GPUNTT_FUSED=1 (the per-XCD persistent kernel, off by default: profiles/r02_fused_single_sweep.md)
-    in its three placement modes -- XCD-aligned groups, groups spanning XCDs (run-time placement check
-    falls back to the fence protocol) and forced fences -- stays bit-exact; run in subprocesses because
-    the switches are read once per process."""
-    code = """
-import numpy as np, sys, os
-sys.path.insert(0, os.path.join(os.path.dirname(os.environ["PYTHONPATH"]), ""))
-from conftest import load_pkg
-from gpu_utils import MergeCase
-from oracle import oracle as O
-g = load_pkg(); g.load_library()
-for logn, batch in ((14, 5), (16, 40), (17, 3)):
-    for poly in (O.X_N_minus, O.X_N_plus):
-        c = MergeCase(g, 64, logn, poly)
-        x = c.random(batch, 31 + logn)
-        want = c.P.merge_ntt(x, c.oprm)
-        assert np.array_equal(c.gpu_forward(x, inplace=bool(logn & 1)), want)
-        assert np.array_equal(c.gpu_inverse(want, inplace=not (logn & 1)), x)
-"""
-    for mode in ("0", "1", "2"):
-        _run_in_subprocess(code, {"GPUNTT_FUSED": "1", "GPUNTT_FUSED_MODE": mode})
-
-
 def test_streams_are_honoured(g):
     import torch
     c = MergeCase(g, 64, 14, O.X_N_minus)

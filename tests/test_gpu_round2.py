@@ -511,8 +511,8 @@ def test_fourstep_plan_slow_modulus_and_errors(g):
     with pytest.raises(ValueError):
         pf.execute(d, d, 1)  # in place is not supported by the 4-step
     pf.execute(d, torch.zeros_like(d), 0)  # empty batch: no-op
-    # generic path under GPUNTT_PATH=generic: plan creation sees it and falls back
-    os.environ["GPUNTT_PATH"] = "generic"
+    # generic path under option path = generic: plan creation sees it and falls back
+    g.set_option("path", "generic")
     try:
         ps = g.FourStepPlan(*tf, p4.modulus, cf)
         assert not ps.fast_path
@@ -525,7 +525,7 @@ def test_fourstep_plan_slow_modulus_and_errors(g):
         torch.cuda.synchronize()
         assert np.array_equal(g.to_host(d_a), g.to_host(d_b))
     finally:
-        del os.environ["GPUNTT_PATH"]
+        g.set_option("path", os.environ.get("GPUNTT_PATH", "default"))
     pf.execute(d, torch.zeros_like(d), 1)  # the fast plan made before still runs its prepared path
     torch.cuda.synchronize()
 
@@ -580,11 +580,11 @@ def test_moduli_just_below_a_power_of_two(g):
     ~2^-48 of a power of two gets its width over-stated by one (2^60 - 107 -> bit 61).  The three words equal the
     oracle's, and every kernel family computes the right transform with them (the over-stated width selects the
     next lazy range: 60-bit -> 8q kernels).  A 61-bit prime that close to 2^61 gets bit = 62 and a mu that no longer
-    fits the word (2^125 / q >= 2^64): the reference's own Barrett product is wrong for it, so only the three words
-    are compared there."""
+    fits the word (2^125 / q >= 2^64): the reference stores the truncated value and its own Barrett product is wrong
+    from then on -- this library refuses to build such a Modulus."""
     fac = find_ntt_factors(61, 3)
-    m = g.Modulus(fac[0], bits=64)
-    assert tuple(m.words()) == O.Port(64).merge_params(3, O.X_N_plus, fac)["mod"] and m.bit == 62
+    with pytest.raises((ValueError, g.GpuNttError)):
+        g.Modulus(fac[0], bits=64)
     seen = set()
     for qbits in (54, 57, 59, 60):
         for logn in (1, 3, 5, 12, 13):

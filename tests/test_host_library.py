@@ -42,10 +42,16 @@ def test_modulus_struct_matches_reference_contract(g):
         m = g.Modulus(q)
         assert (m.value, m.bit, m.mu) == P.modulus(q)
     # just below a power of two the reference's double log2 over-states the width by one (modular_arith.cuh:44-47)
-    for q, bit in ((2**60 - 107, 61), (2**60 - 2559, 61), (2**59 - 55, 60), (2**57 - 111, 58), (2**61 - 31, 62),
+    for q, bit in ((2**60 - 107, 61), (2**60 - 2559, 61), (2**59 - 55, 60), (2**57 - 111, 58),
                    (2**54 - 131, 54), (2**60 - 2**20 + 1, 60)):
         m = g.Modulus(q)
         assert (m.value, m.bit, m.mu) == P.modulus(q) and m.bit == bit
+    # ... and at the top of the domain the over-stated width makes mu pass the word (2^125 / q >= 2^64 for a 61-bit q
+    # with bit = 62): the reference stores the truncated value (its Barrett product is wrong from then on), this
+    # library refuses the modulus
+    assert P.modulus(2**61 - 31)[1] == 62
+    with pytest.raises(ValueError):
+        g.Modulus(2**61 - 31)
     P32 = O.Port(32)
     for q in (469762049, 268460033, 12289):
         m = g.Modulus(q, bits=32)
@@ -138,3 +144,21 @@ def test_shard_range_partitions_batch(g):
             assert all(lo % mc == 0 and hi % mc == 0 for lo, hi in spans)
     with pytest.raises(ValueError):
         g.shard_range(10, 0, 2, 4)
+
+
+def test_options_replace_environment_switches(g):
+    """the C++ library reads no environment variable: tuning / test switches go through gpuntt_set_option
+    (GPU_NTT_SetOption); unknown names and values are refused"""
+    lib = g.load_library()
+    for name, value in (("path", "generic"), ("path", "fast-strict"), ("path", "default"), ("contig_k", "11"),
+                        ("contig_k", "0"), ("xcd_order", "0"), ("xcd_order", "1"), ("lim31", "0"), ("lim31", "1"),
+                        ("reverse", "0"), ("reverse", "1"), ("u64_big_tiles", "13"), ("u64_big_tiles", "14"),
+                        ("u32_tile", "12"), ("u32_tile", "0")):
+        g.set_option(name, value)
+    for name, value in (("path", "sideways"), ("no_such_option", "1")):
+        assert lib.gpuntt_set_option(name.encode(), value.encode()) != 0
+    assert lib.gpuntt_set_option(None, None) != 0
+    import subprocess
+    out = subprocess.run("strings -a %s | grep -c '^GPUNTT_[A-Z0-9_]*$'" % g.LIB_PATH, shell=True, capture_output=True,
+                         text=True).stdout.strip()
+    assert out in ("", "0"), "the library still carries GPUNTT_* environment variable names"
