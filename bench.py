@@ -590,7 +590,7 @@ def run_sweep(g, args, dist_mod, dist, rank, world, dev):
     import torch
     points = sweep_points(args)
     if args.child:
-        mark = torch.zeros(1, dtype=torch.float64, device=dev)
+        mark = torch.empty(1, dtype=torch.float64, device=dev)  # (torch.zeros would itself launch the mark kernel)
         for k, (kind, bits, logn, batch) in enumerate(points):
             first, step, _, _, keep = sweep_case(g, kind, bits, logn, batch, dev, rank)
             torch.cuda.synchronize()

@@ -160,6 +160,7 @@ namespace gpuntt
             PlanMode mode = PLAN_NONE;
             lazy::Tw<T>* ws = nullptr;
             int tile_log = 0; // row-pass tile the n2 table was laid out for (reference-layout plans)
+            int small_tl = 0; // reference-layout plans of one-tile rings: tile of the one-launch path (0: two-phase path)
         };
 
         // fast path: single modulus with lazy headroom.  Workspace layout (Shoup pairs):
@@ -179,9 +180,15 @@ namespace gpuntt
             using TW = lazy::Tw<T>;
             if (plan.mode != PLAN_NONE && mods_dev != nullptr)
                 return false;
-            if (mods_dev == nullptr &&
-                (mod.bit > T(lazy::Mod<T>::MAX_BIT) || mod.value < 3 || (INV && ninv >= mod.value)))
-                return false;
+            // host-side modulus: 61- / 62-bit moduli run the same plans on the LIMIT = 8 / 4 kernels (the whole
+            // documented domain of the reference, modular_arith.cuh:66-67), like the Merge entry points
+            int lim = 0;
+            if (mods_dev == nullptr)
+            {
+                if (!host::modulus_fast<T>(mod) || (INV && ninv >= mod.value))
+                    return false;
+                lim = host::modulus_lim<T>(mod);
+            }
             if (mods_dev != nullptr && INV && ninv_dev == nullptr)
                 return false;
             if (host::forced_path() == 1)
@@ -202,9 +209,123 @@ namespace gpuntt
             unsigned char* tail = reinterpret_cast<unsigned char*>(ws + pairs);
             unsigned* go_flag = mods_dev ? reinterpret_cast<unsigned*>(tail) : nullptr;
             auto* norm_arr = mods_dev ? reinterpret_cast<lazy::NormConst*>(tail + 16) : nullptr;
-            const int tl2 = plan.mode != PLAN_NONE
+            const int tl2 = lim != 0 ? 12 // the LIMIT = 8 / 4 kernels exist for 4096-coefficient tiles only
+                            : plan.mode != PLAN_NONE
                                 ? plan.tile_log
                                 : host::lazy_tile_log<T>(log_n2, INV, static_cast<unsigned long long>(batch_size) << log_n1);
+            // Rings that fit one tile (2^12 .. 2^14): the 4-step transform is the Merge transform of the ring with its
+            // natural-order side transposed, so ONE contiguous pass does it -- Merge table rebuilt from the caller's
+            // tables into the W region of the workspace, transposition in LDS (kern::fourstep_small_lazy)
+            int small_tl = plan.mode != PLAN_NONE
+                               ? plan.small_tl
+                               : host::fourstep_small_tile<T>(n_power, INV, static_cast<unsigned long long>(batch_size));
+            if (lim != 0 && small_tl != 12)
+                small_tl = 0; // the LIMIT = 8 / 4 kernels exist for 4096-coefficient tiles only
+            if (small_tl != 0)
+            {
+                if (plan.mode != PLAN_EXECUTE)
+                    host::launch_prep_merge_from_fourstep<T>(n1_table, w_table, ws_w, log_n1, log_n2,
+                                                             (n_power >= small_tl) ? small_tl : 0, INV, INV, mod.value, ninv,
+                                                             mods_dev, (INV && mods_dev) ? ninv_dev : nullptr, ws_ninv, go_flag,
+                                                             norm_arr, stream);
+                if (go_flag_out != nullptr)
+                    *go_flag_out = go_flag;
+                if (plan.mode == PLAN_PREPARE)
+                    return true;
+                kern::LazyArgsT<T> s{};
+                s.in = in;
+                s.out = out;
+                s.tw = ws_w;
+                s.mods = mods_dev;
+                s.q = mod.value;
+                s.q_bit = mod.bit;
+                s.q_mu = mod.mu;
+                s.ninv = TW{0, 0};
+                if (INV && mods_dev == nullptr)
+                    s.ninv = TW{ninv, host::shoup_host(ninv, mod.value)};
+                if (INV && mods_dev != nullptr)
+                    s.ninv_arr = ws_ninv;
+                s.go_flag = go_flag;
+                s.norm = lazy::make_norm_const(static_cast<uint64_t>(mod.value), static_cast<uint64_t>(mod.bit));
+                s.norm_arr = norm_arr;
+                s.total = static_cast<unsigned long long>(batch_size) << n_power;
+                s.n = n_power;
+                s.poly_shift = n_power;
+                s.mod_count = 1;
+                if constexpr (sizeof(T) == 8)
+                {
+                    if (lim == 8)
+                        host::launch_fourstep_lim<INV, 8>(2, log_n1, s, stream);
+                    else if (lim == 4)
+                        host::launch_fourstep_lim<INV, 4>(2, log_n1, s, stream);
+                    else
+                        host::launch_fourstep_small_lazy<T, INV>(small_tl, n_power, s, stream);
+                }
+                else
+                    host::launch_fourstep_small_lazy<T, INV>(small_tl, n_power, s, stream);
+                return true;
+            }
+            // Forward, rings larger than a tile: Merge form.  Phase 1 does the top log2 n1 stages on the n1-long rows of
+            // the input and stores transposed WITHOUT the W product (lazy); the remaining log2 n2 stages are ordinary
+            // Merge passes over the natural-order layout with the ring's Merge table -- the W matrix is never streamed,
+            // one multiplication and one normalisation per coefficient less than the two-phase form.
+            if constexpr (!INV)
+            {
+                // tile of the contiguous row pass: the one a Merge transform of length n2 over these rows would take
+                // (8192 / 16384-coefficient tiles keep n2 = 2^13 / 2^14 at ONE row sweep); it fixes the table layout
+                const int tlr = (log_n2 >= tl2 || (sizeof(T) == 4 && tl2 == 14 && log_n2 == 13)) ? tl2 : 12;
+                if (plan.mode != PLAN_EXECUTE)
+                    host::launch_prep_merge_from_fourstep<T>(n1_table, w_table, ws_w, log_n1, log_n2, tlr, false, false,
+                                                             mod.value, T(0), mods_dev, nullptr, nullptr, go_flag, norm_arr,
+                                                             stream);
+                if (go_flag_out != nullptr)
+                    *go_flag_out = go_flag;
+                if (plan.mode == PLAN_PREPARE)
+                    return true;
+                kern::LazyArgsT<T> f{};
+                f.in = in;
+                f.out = out;
+                f.tw = ws_w;
+                f.mods = mods_dev;
+                f.q = mod.value;
+                f.q_bit = mod.bit;
+                f.q_mu = mod.mu;
+                f.ninv = TW{0, 0};
+                f.go_flag = go_flag;
+                f.norm = lazy::make_norm_const(static_cast<uint64_t>(mod.value), static_cast<uint64_t>(mod.bit));
+                f.norm_arr = norm_arr;
+                f.n2_log = log_n2;
+                f.batch = batch_size;
+                f.total = static_cast<unsigned long long>(batch_size) << n_power;
+                f.n = log_n1;
+                f.poly_shift = n_power;
+                f.mod_count = 1;
+                f.flags = host::lazy_order_flags();
+                if constexpr (sizeof(T) == 8)
+                {
+                    if (lim == 8)
+                        host::launch_fourstep_lim<false, 8>(1, log_n1, f, stream);
+                    else if (lim == 4)
+                        host::launch_fourstep_lim<false, 4>(1, log_n1, f, stream);
+                    else
+                        host::launch_fourstep_phase1_merge_lazy<T>(log_n1, f, stream);
+                }
+                else
+                    host::launch_fourstep_phase1_merge_lazy<T>(log_n1, f, stream);
+                kern::LazyArgsT<T> r = f;
+                r.in = out;
+                r.n = n_power;
+                r.batch = 0;
+                r.lim = lim;
+                if constexpr (sizeof(T) == 8)
+                    if (lim == 0 && mods_dev == nullptr && host::lazy_lim31_enabled() && host::lazy_lim31_modulus(mod.value))
+                        r.lim = 31;
+                if constexpr (sizeof(T) == 4)
+                    if (mods_dev == nullptr && host::lazy_lim31_enabled() && host::lazy_wide_modulus32(mod.value))
+                        r.lim = 8;
+                host::run_transform_lazy<T, false>(r, 0u, 0u, stream, tlr, log_n2);
+                return true;
+            }
             // one preparation launch; inverse: n^-1 rides on the last row stage (fold = 2)
             if (plan.mode != PLAN_EXECUTE)
                 host::launch_prep_fourstep<T>(n1_table, n2_table, w_table, ws_n1, ws_w, ws_n2, log_n1, log_n2,
@@ -238,7 +359,17 @@ namespace gpuntt
             a.mod_count = 1;
             a.p_lo = 0;
             a.flags = host::lazy_order_flags();
-            host::launch_fourstep_phase1_lazy<T, INV>(log_n1, a, stream);
+            if constexpr (sizeof(T) == 8)
+            {
+                if (lim == 8)
+                    host::launch_fourstep_lim<INV, 8>(0, log_n1, a, stream);
+                else if (lim == 4)
+                    host::launch_fourstep_lim<INV, 4>(0, log_n1, a, stream);
+                else
+                    host::launch_fourstep_phase1_lazy<T, INV>(log_n1, a, stream);
+            }
+            else
+                host::launch_fourstep_phase1_lazy<T, INV>(log_n1, a, stream);
 
             // phase 2: n2-point transforms of the batch * n1 rows of `out`, in place
             kern::LazyArgsT<T> b = a;
@@ -251,6 +382,7 @@ namespace gpuntt
                 b.ninv = TW{ninv, host::shoup_host(ninv, mod.value)};
             if (INV && mods_dev != nullptr)
                 b.ninv_arr = ws_ninv;
+            b.lim = lim;
             // forward row passes of a modulus with 31 q < 2^64: the LIMIT = 31 kernels
             if constexpr (sizeof(T) == 8 && !INV)
                 if (mods_dev == nullptr && host::lazy_lim31_enabled() &&
@@ -259,7 +391,7 @@ namespace gpuntt
             if constexpr (sizeof(T) == 4)
                 if (mods_dev == nullptr && host::lazy_lim31_enabled() && host::lazy_wide_modulus32(mod.value))
                     b.lim = 8;
-            host::run_transform_lazy<T, INV>(b, 0u, 0u, stream, plan.mode != PLAN_NONE ? tl2 : 0);
+            host::run_transform_lazy<T, INV>(b, 0u, 0u, stream, (plan.mode != PLAN_NONE || lim != 0) ? tl2 : 0);
             return true;
         }
 
@@ -478,6 +610,8 @@ namespace gpuntt
                                                      l1, l2, batch_size, stream);
                 if (done)
                     return;
+                if (host::forced_path() == 3) // test hook, like the Merge entry points
+                    throw std::invalid_argument("fast path unavailable for this call (path = fast-strict)");
             }
             if (ntt_type == FORWARD)
                 fourstep_run<T, false>(in, out, n1_table, n2_table, w_table, mods, mod, mod_count,
@@ -622,6 +756,8 @@ namespace gpuntt
             p->use.mode = PLAN_PREPARE;
             p->use.tile_log =
                 host::lazy_tile_log<T>(l2, p->inverse, static_cast<unsigned long long>(batch_hint) << l1);
+            if (!natural_order)
+                p->use.small_tl = host::fourstep_small_tile<T>(p->n, p->inverse, static_cast<unsigned long long>(batch_hint));
             // the eligibility checks of the fast paths decide (modulus width, n^-1 canonical, option "path")
             if (natural_order)
                 p->fast = p->inverse ? fourstep_natural_inverse_lazy<T>(nullptr, nullptr, p->n1_table, p->n2_table,

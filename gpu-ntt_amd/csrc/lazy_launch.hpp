@@ -108,13 +108,32 @@ namespace gpuntt
                                                          uint32_t, hipStream_t, const Modulus<uint32_t>*);
 
         // 4-step phase 1 (fused n1-point transform + transpose + W multiply), log_n1 in 5..8
-        template <typename T, bool INV>
+        template <typename T, bool INV, int LIMSEL = 0>
         void launch_fourstep_phase1_lazy(int log_n1, const kern::LazyArgsT<T>& a, hipStream_t stream);
         extern template void launch_fourstep_phase1_lazy<uint64_t, false>(int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
         extern template void launch_fourstep_phase1_lazy<uint64_t, true>(int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
         extern template void launch_fourstep_phase1_lazy<uint32_t, false>(int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
         extern template void launch_fourstep_phase1_lazy<uint32_t, true>(int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
 
+        // 4-step transform of a ring that fits one tile in one launch: 64-bit 2^12 (tile 12), 2^13 (tile 13), 2^14 forward
+        // (tile 14); 32-bit 2^12 (tile 12), 2^13, 2^14 (tile 14).  a.tw = Merge table of the ring
+        // (launch_prep_merge_from_fourstep).  fourstep_small_tile: the tile such a call runs on, 0 = ring too large
+        template <typename T> inline int fourstep_small_tile(int n_power, bool inverse, unsigned long long polys)
+        {
+            const int tl = lazy_tile_log<T>(n_power, inverse, polys);
+            return (n_power >= 12 && n_power <= tl) ? tl : 0;
+        }
+        template <typename T, bool INV>
+        void launch_fourstep_small_lazy(int tile_log, int n, const kern::LazyArgsT<T>& a, hipStream_t stream);
+        extern template void launch_fourstep_small_lazy<uint64_t, false>(int, int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
+        extern template void launch_fourstep_small_lazy<uint64_t, true>(int, int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
+        extern template void launch_fourstep_small_lazy<uint32_t, false>(int, int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
+        extern template void launch_fourstep_small_lazy<uint32_t, true>(int, int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
+        // forward 4-step phase 1 in Merge form (kern::fourstep_phase1_merge_lazy), log_n1 in 5..8
+        template <typename T, int LIMSEL = 0>
+        void launch_fourstep_phase1_merge_lazy(int log_n1, const kern::LazyArgsT<T>& a, hipStream_t stream);
+        extern template void launch_fourstep_phase1_merge_lazy<uint64_t>(int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
+        extern template void launch_fourstep_phase1_merge_lazy<uint32_t>(int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
         // natural-order forward 4-step passes (instantiated with the forward kernels)
         template <typename T>
         void launch_fourstep_nat_p1_lazy(int log_n1, const kern::LazyArgsT<T>& a, hipStream_t stream);
@@ -148,6 +167,21 @@ namespace gpuntt
                                                             lazy::Tw32*, lazy::Tw32*, int, int, int, bool, int, uint32_t,
                                                             uint32_t, const Modulus<uint32_t>*, const uint32_t*, lazy::Tw32*,
                                                             unsigned*, lazy::NormConst*, hipStream_t);
+        // Merge table of the 4-step ring (bit-reversed powers of its root), rebuilt from the caller's 4-step tables
+        // straight into the Merge kernels' stage layout (prep.hip: prep_merge_from_fourstep)
+        template <typename T>
+        void launch_prep_merge_from_fourstep(const T* n1_table, const T* w_table, lazy::Tw<T>* ws, int log_n1, int log_n2,
+                                             int perm_tile_log, bool inverse, bool fold, T q, T ninv,
+                                             const Modulus<T>* mods, const T* ninv_dev, lazy::Tw<T>* ws_ninv,
+                                             unsigned* go_flag, lazy::NormConst* norm_arr, hipStream_t stream);
+        extern template void launch_prep_merge_from_fourstep<uint64_t>(const uint64_t*, const uint64_t*, lazy::Tw64*, int,
+                                                                       int, int, bool, bool, uint64_t, uint64_t,
+                                                                       const Modulus<uint64_t>*, const uint64_t*,
+                                                                       lazy::Tw64*, unsigned*, lazy::NormConst*, hipStream_t);
+        extern template void launch_prep_merge_from_fourstep<uint32_t>(const uint32_t*, const uint32_t*, lazy::Tw32*, int,
+                                                                       int, int, bool, bool, uint32_t, uint32_t,
+                                                                       const Modulus<uint32_t>*, const uint32_t*,
+                                                                       lazy::Tw32*, unsigned*, lazy::NormConst*, hipStream_t);
         // W table of the inverse direction re-indexed for it: dst[k*n2 + j] = pair(src[brev(k)*n2 + brev(j)])
         template <typename T>
         void launch_prep_pairs_brev(const T* src, lazy::Tw<T>* dst, int log_n1, int log_n2, T q, hipStream_t stream);
@@ -220,6 +254,26 @@ namespace gpuntt
         extern template void launch_pass_lazy_lim<false, 8>(const Pass&, bool, bool, const kern::LazyArgsT<uint64_t>&, hipStream_t);
         extern template void launch_pass_lazy_lim<true, 8>(const Pass&, bool, bool, const kern::LazyArgsT<uint64_t>&, hipStream_t);
         extern template void launch_pass_lazy_lim<false, 4>(const Pass&, bool, bool, const kern::LazyArgsT<uint64_t>&, hipStream_t);
+        template <bool INV, int LIMSEL>
+        void launch_fourstep_lim(int what, int log_n1, const kern::LazyArgsT<uint64_t>& a, hipStream_t stream);
+        extern template void launch_fourstep_lim<false, 8>(int, int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
+        extern template void launch_fourstep_lim<true, 8>(int, int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
+        extern template void launch_fourstep_lim<false, 4>(int, int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
+        extern template void launch_fourstep_lim<true, 4>(int, int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
+        // 64-bit words: lazy range a host-side modulus needs (0: the default 16 q kernels, 8: 61 bit, 4: 62 bit),
+        // and whether the fast kernels can take it at all -- the documented domain of the reference
+        // (src/include/gpuntt/common/modular_arith.cuh:66-67)
+        template <typename TU> inline bool modulus_fast(const Modulus<TU>& m)
+        {
+            const TU max_bit = (sizeof(TU) == 8) ? TU(62) : TU(lazy::Mod<TU>::MAX_BIT);
+            return m.value >= 3 && m.bit <= max_bit;
+        }
+        template <typename TU> inline int modulus_lim(const Modulus<TU>& m)
+        {
+            if (sizeof(TU) != 8)
+                return 0;
+            return m.bit == TU(62) ? 4 : (m.bit == TU(61) ? 8 : 0);
+        }
         // LIMIT = 31 forward kernels on any 64-bit tile size (4096 / 8192 / 16384 coefficients)
         void launch_pass_lazy31(const Pass& p, int tile_log, bool in_first, bool last, const kern::LazyArgsT<uint64_t>& a,
                                 hipStream_t stream);
@@ -252,16 +306,20 @@ namespace gpuntt
         }
 
         // forced_tl: tile size the twiddle table was prepared for (NTTPlan); 0 = choose from the batch
+        // low_stages > 0 (forward only): run only the stages on the low `low_stages` index bits of the ring -- the
+        // values come lazy (below 16 q) from a pass that did the stages above them (4-step phase 1 in Merge form)
         template <typename T, bool INV>
         inline void run_transform_lazy(kern::LazyArgsT<T> base, unsigned first_in_flags,
-                                       unsigned last_out_flags, hipStream_t stream, int forced_tl = 0)
+                                       unsigned last_out_flags, hipStream_t stream, int forced_tl = 0, int low_stages = 0)
         {
             const int tl = (sizeof(T) == 8 && base.lim && base.lim != 31)
                                ? 12
                                : (forced_tl ? forced_tl : lazy_tile_log<T>(base.n, INV, base.total >> base.n));
-            const Plan pl = make_plan_tl(base.n, tl, tl == 12 ? lazy_contig_k(base.n) : tl);
+            const int pn = (!INV && low_stages > 0) ? low_stages : base.n;
+            const bool partial = pn != base.n;
+            const Plan pl = make_plan_tl(pn, tl, tl == 12 ? lazy_contig_k(pn) : tl);
             const void* src = base.in;
-            int fwd_bound = 1; // range bound of the values in flight (forward, 31 q range: see fwd_bound_after)
+            int fwd_bound = partial ? 16 : 1; // range bound of the values in flight (forward, 31 q range: see fwd_bound_after)
             for (int i = 0; i < pl.count; i++)
             {
                 Pass p = INV ? pl.pass[pl.count - 1 - i] : pl.pass[i];
@@ -274,6 +332,7 @@ namespace gpuntt
                 a.in = src;
                 a.p_lo = p.p_lo;
                 a.flags |= lazy_order_flags();
+                const bool first = (i == 0) && !partial; // reads canonical input
                 if (i == 0)
                     a.flags |= first_in_flags;
                 if (i == pl.count - 1)
@@ -294,25 +353,25 @@ namespace gpuntt
                 if constexpr (sizeof(T) == 8)
                 {
                     if (base.lim == 8)
-                        launch_pass_lazy_lim<INV, 8>(p, i == 0, i == pl.count - 1, a, stream);
+                        launch_pass_lazy_lim<INV, 8>(p, first, i == pl.count - 1, a, stream);
                     else if (base.lim == 4)
-                        launch_pass_lazy_lim<INV, 4>(p, i == 0, i == pl.count - 1, a, stream);
+                        launch_pass_lazy_lim<INV, 4>(p, first, i == pl.count - 1, a, stream);
                     else if (base.lim == 31)
                     {
                         if constexpr (!INV)
-                            launch_pass_lazy31(p, tlp, i == 0, i == pl.count - 1, a, stream);
+                            launch_pass_lazy31(p, tlp, first, i == pl.count - 1, a, stream);
                         else
                             throw std::invalid_argument("internal: the 31 q range serves forward transforms only");
                     }
                     else
-                        launch_pass_lazy<T, INV>(p, tlp, i == 0, i == pl.count - 1, a, stream);
+                        launch_pass_lazy<T, INV>(p, tlp, first, i == pl.count - 1, a, stream);
                 }
                 else
                 {
                     if (base.lim == 8)
-                        launch_pass_lazy_u32w<INV>(p, tlp, i == 0, i == pl.count - 1, a, stream);
+                        launch_pass_lazy_u32w<INV>(p, tlp, first, i == pl.count - 1, a, stream);
                     else
-                        launch_pass_lazy<T, INV>(p, tlp, i == 0, i == pl.count - 1, a, stream);
+                        launch_pass_lazy<T, INV>(p, tlp, first, i == pl.count - 1, a, stream);
                 }
                 src = base.out;
             }

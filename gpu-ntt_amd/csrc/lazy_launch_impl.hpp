@@ -113,8 +113,13 @@ namespace gpuntt
                                 default: break;
                             }
                         else if constexpr (TLOG == 14)
+                        {
                             if (p.k == 14)
                                 GPUNTT_ONE(true, 14, LIM, true);
+                            // two rows of 2^13 per tile, lazy input: the row pass of the 32-bit 4-step ring 2^18
+                            if (p.k == 13)
+                                GPUNTT_ONE(true, 13, LIM, true);
+                        }
                     }
                 }
                 else if (INV && in_first && !last)
@@ -188,7 +193,7 @@ namespace gpuntt
 #undef GPUNTT_ONE
         }
 
-        template <typename T, bool INV>
+        template <typename T, bool INV, int LIMSEL>
         void launch_fourstep_phase1_lazy(int log_n1, const kern::LazyArgsT<T>& a, hipStream_t stream)
         {
             constexpr int TLOG = 12;
@@ -197,7 +202,7 @@ namespace gpuntt
             {
 #define GPUNTT_CASE(KK)                                                                          \
     case KK:                                                                                      \
-        hipLaunchKernelGGL((kern::fourstep_phase1_lazy<T, TLOG, INV, KK>), dim3(grid),            \
+        hipLaunchKernelGGL((kern::fourstep_phase1_lazy<T, TLOG, INV, KK, LIMSEL>), dim3(grid),    \
                            dim3(kern::LTile<TLOG>::NT), 0, stream, a);                            \
         break;
                 GPUNTT_CASE(5)
@@ -208,6 +213,71 @@ namespace gpuntt
                 default:
                     throw std::invalid_argument("internal: bad 4-step n1");
             }
+            GPUNTT_HIP_CHECK(hipGetLastError());
+        }
+
+        // forward 4-step phase 1 in Merge form (no W product, lazy hand-over), log_n1 in 5..8
+        template <typename T, int LIMSEL>
+        void launch_fourstep_phase1_merge_lazy(int log_n1, const kern::LazyArgsT<T>& a, hipStream_t stream)
+        {
+            constexpr int TLOG = 12;
+            const unsigned grid = static_cast<unsigned>(a.total >> TLOG);
+            switch (log_n1)
+            {
+#define GPUNTT_CASE(KK)                                                                          \
+    case KK:                                                                                      \
+        hipLaunchKernelGGL((kern::fourstep_phase1_merge_lazy<T, TLOG, KK, LIMSEL>), dim3(grid),   \
+                           dim3(kern::LTile<TLOG>::NT), 0, stream, a);                            \
+        break;
+                GPUNTT_CASE(5)
+                GPUNTT_CASE(6)
+                GPUNTT_CASE(7)
+                GPUNTT_CASE(8)
+#undef GPUNTT_CASE
+                default:
+                    throw std::invalid_argument("internal: bad 4-step n1");
+            }
+            GPUNTT_HIP_CHECK(hipGetLastError());
+        }
+
+        // 4-step transform of a ring that fits one tile: the whole transform in one launch (fourstep_small_lazy)
+        template <typename T, bool INV>
+        void launch_fourstep_small_lazy(int tile_log, int n, const kern::LazyArgsT<T>& a, hipStream_t stream)
+        {
+            const unsigned long long tiles = (a.total + (1ull << tile_log) - 1) >> tile_log;
+            if (tiles == 0)
+                return;
+            if (tiles > 0x7fffffffull)
+                throw std::invalid_argument("batch_size * N too large for one launch");
+            const unsigned grid = static_cast<unsigned>(tiles);
+#define GPUNTT_SMALL(TL_, K_)                                                                                          \
+    hipLaunchKernelGGL((kern::fourstep_small_lazy<T, TL_, INV, K_>), dim3(grid), dim3(kern::LTile<TL_>::NT), 0, stream, a)
+            if constexpr (sizeof(T) == 8)
+            {
+                if (tile_log == 12 && n == 12)
+                    GPUNTT_SMALL(12, 12);
+                else if (tile_log == 13 && n == 13)
+                    GPUNTT_SMALL(13, 13);
+                else if (tile_log == 14 && n == 14 && !INV)
+                {
+                    if constexpr (!INV)
+                        GPUNTT_SMALL(14, 14);
+                }
+                else
+                    throw std::invalid_argument("internal: no one-tile 4-step kernel for this ring");
+            }
+            else
+            {
+                if (tile_log == 12 && n == 12)
+                    GPUNTT_SMALL(12, 12);
+                else if (tile_log == 14 && n == 13)
+                    GPUNTT_SMALL(14, 13);
+                else if (tile_log == 14 && n == 14)
+                    GPUNTT_SMALL(14, 14);
+                else
+                    throw std::invalid_argument("internal: no one-tile 4-step kernel for this ring");
+            }
+#undef GPUNTT_SMALL
             GPUNTT_HIP_CHECK(hipGetLastError());
         }
 
@@ -301,6 +371,31 @@ namespace gpuntt
                     throw std::invalid_argument("internal: bad 4-step n1");
             }
             GPUNTT_HIP_CHECK(hipGetLastError());
+        }
+
+        // 4-step kernels for 64-bit words with a 61- / 62-bit modulus (LIMIT = 8 / 4): what = 0 phase 1 with the W
+        // product (inverse), 1 phase 1 in Merge form (forward), 2 the one-launch 2^12 ring
+        template <bool INV, int LIMSEL>
+        void launch_fourstep_lim(int what, int log_n1, const kern::LazyArgsT<uint64_t>& a, hipStream_t stream)
+        {
+            if (what == 0)
+                return launch_fourstep_phase1_lazy<uint64_t, INV, LIMSEL>(log_n1, a, stream);
+            if constexpr (!INV)
+                if (what == 1)
+                    return launch_fourstep_phase1_merge_lazy<uint64_t, LIMSEL>(log_n1, a, stream);
+            if (what == 2)
+            {
+                const unsigned long long tiles = a.total >> 12;
+                if (tiles == 0)
+                    return;
+                if (tiles > 0x7fffffffull)
+                    throw std::invalid_argument("batch_size * N too large for one launch");
+                hipLaunchKernelGGL((kern::fourstep_small_lazy<uint64_t, 12, INV, 12, LIMSEL>), dim3(static_cast<unsigned>(tiles)),
+                                   dim3(kern::LTile<12>::NT), 0, stream, a);
+                GPUNTT_HIP_CHECK(hipGetLastError());
+                return;
+            }
+            throw std::invalid_argument("internal: bad 4-step kernel selector");
         }
 
         // 64-bit words with a 61- / 62-bit modulus: LIMIT = 8 / 4 kernels, 4096-coefficient tiles only

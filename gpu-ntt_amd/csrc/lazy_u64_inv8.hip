@@ -2,4 +2,5 @@
 #include "lazy_launch_impl.hpp"
 namespace gpuntt { namespace host {
 template void launch_pass_lazy_lim<true, 8>(const Pass&, bool, bool, const kern::LazyArgsT<uint64_t>&, hipStream_t);
+template void launch_fourstep_lim<true, 8>(int, int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
 } }

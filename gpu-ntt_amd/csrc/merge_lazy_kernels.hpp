@@ -253,6 +253,11 @@ namespace gpuntt
         // over the rows (length n1 = 2^K) of the n2 x n1 input, stored transposed into the n1 x n2
         // output with the W multiply fused; output canonical.  Blocks are ordered poly-minor so the
         // polynomials of a batch that share a slice of W run back to back (W stays in L2).
+        // FST = 3, forward 4-step in Merge form (rings larger than a tile): the same pass over the n1-long rows and the
+        // same transposed store, but NO W product and no normalisation -- the top log2 n1 stages of the Merge transform
+        // of the whole ring, handed over lazy to Merge passes that run the remaining stages from the ring's Merge table
+        // (prep.hip: prep_merge_from_fourstep).  One multiplication, one 16-byte W load and one normalisation per
+        // coefficient less than the reference's FourStepForwardCoreT* + W form.
         // FST = 2, natural-order 4-step, last forward pass: CONTIG stages on the same 2^K-column range
         // of 2^(TL-K) consecutive rows (lazy input from the strided row passes, or canonical input
         // when the rows fit one pass), canonical output stored transposed (no W product).
@@ -287,6 +292,29 @@ namespace gpuntt
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
 
+        // XP: the 4-step entry points on rings that fit ONE tile.  GPU_4STEP_NTT is the Merge transform of the ring with
+        // a transposition on the natural-order side (prep.hip: prep_merge_from_fourstep), n1 = 32 for every such ring
+        // (reference launch table src/lib/ntt_4step/ntt_4step.cu:2306-2330: 2^12 .. 2^14 are 32 x n2):
+        //   XP = 1 (forward):  the tile is read as it lies (n2 x 32, coalesced) and dropped into LDS transposed, i.e. at
+        //                      its natural position  e = (i << log n2) | c  for  f = (c << 5) | i;
+        //   XP = 2 (inverse):  the natural-order result leaves through LDS transposed: o = (b << log n2) | a for
+        //                      e = (a << 5) | b, and is stored as it lies (32 x n2, coalesced).
+        // One HBM sweep instead of the reference's two kernels (FourStepForwardCoreT1 + FourStepPartialForwardCore).
+        // LDS layout of the transposition: one pad element per n2-row, so the 32 lanes that write one column and the
+        // lanes that read along a row both hit distinct banks.
+        constexpr int XP_L1 = 5;
+        template <int K> __device__ __forceinline__ unsigned xp_swap_fwd(unsigned f) // f = (c << 5) | i  ->  (i << l2) | c
+        {
+            constexpr unsigned M = (1u << K) - 1u;
+            const unsigned w = f & M;
+            return (f & ~M) | ((w & 31u) << (K - XP_L1)) | (w >> XP_L1);
+        }
+        template <int K> __device__ __forceinline__ unsigned xp_swap_inv(unsigned e) // e = (a << 5) | b  ->  (b << l2) | a
+        {
+            return xp_swap_fwd<K>(e); // the same bit rotation: low five bits to the top of the ring index
+        }
+        template <int K> __device__ __forceinline__ unsigned xp_lds(unsigned e) { return e + (e >> (K - XP_L1)); }
+
         // Block-uniform values that went through a division or a select end up in vector registers, and so does
         // every address derived from them (64-bit VALU adds + v_readfirstlane per access).  Reading them back
         // through v_readfirstlane tells the compiler they are scalar: tile bases, twiddle bases and the modulus
@@ -299,7 +327,7 @@ namespace gpuntt
         }
 
         template <typename T, int TLOG, bool EXACT, bool INV, bool CONTIG, int K, int IN_BOUND, bool LAST,
-                  int FST = 0, bool WMUL = false, int LIM = 0>
+                  int FST = 0, bool WMUL = false, int LIM = 0, int XP = 0>
         __device__ __forceinline__ void pass_body(const LazyArgsT<T>& a, T* lds, T q_value, T q_bit, T q_mu,
                                                   int mi, unsigned long long fst_poly = 0,
                                                   unsigned fst_tile = 0, long long blk_override = -1,
@@ -463,7 +491,26 @@ namespace gpuntt
                         return static_cast<const T*>(a.in)[f];
                     };
                     const T* src = static_cast<const T*>(a.in); // may alias a.out (in-place calls)
-                    if constexpr (SEG && INV)
+                    if constexpr (XP == 1)
+                    {
+                        // coalesced read of the n2 x 32 tile, transposed into natural order through LDS
+                        T tmp[EPT];
+#pragma unroll
+                        for (int j = 0; j < EPT; j++)
+                        {
+                            const unsigned f = static_cast<unsigned>(t + NT * j);
+                            tmp[j] = plain_io ? ld_stream<true>(src + (map.base + f)) : load_guarded(map.base + f);
+                        }
+#pragma unroll
+                        for (int j = 0; j < EPT; j++)
+                            lds[xp_lds<K>(xp_swap_fwd<K>(static_cast<unsigned>(t + NT * j)))] = tmp[j];
+                        __syncthreads();
+#pragma unroll
+                        for (int j = 0; j < EPT; j++)
+                            v[j] = lds[xp_lds<K>(static_cast<unsigned>(elem_of<WL>(t, j)))];
+                        __syncthreads(); // the exchanges below reuse the buffer in the e + (e >> 4) layout
+                    }
+                    else if constexpr (SEG && INV)
                     {
                         // natural-order inverse 4-step, first pass: the tile's 2^RB rows x 2^K columns
                         // come from the column-major side -- in[((seg << K) + c) * n1 + row0 + r] -- as
@@ -730,7 +777,26 @@ namespace gpuntt
                             }
                         });
                     }
-                    if constexpr (FST && !(SEG && INV))
+                    if constexpr (XP == 2)
+                    {
+                        // natural-order result -> LDS at its transposed position -> coalesced stores of the 32 x n2 tile
+                        __syncthreads(); // every wave is done with the e + (e >> 4) layout
+#pragma unroll
+                        for (int j = 0; j < EPT; j++)
+                            lds[xp_lds<K>(xp_swap_inv<K>(static_cast<unsigned>(elem_of<WL>(t, j))))] = v[j];
+                        __syncthreads();
+#pragma unroll
+                        for (int j = 0; j < EPT; j++)
+                        {
+                            const unsigned o = static_cast<unsigned>(t + NT * j);
+                            const T x = lds[xp_lds<K>(o)];
+                            if (full_tile)
+                                st_stream<true>(a.out + (map.base + o), x);
+                            else if (map.base + o < a.total)
+                                a.out[map.base + o] = x;
+                        }
+                    }
+                    else if constexpr (FST && !(SEG && INV))
                     {
                         static_assert(!FST || (CONTIG && K >= 4 && K <= 9), "4-step row runs are 16..512 long");
                         constexpr int RB = TL - K; // log2 rows per tile
@@ -760,7 +826,7 @@ namespace gpuntt
                                 const unsigned lane = (static_cast<unsigned>(t >> RB) << a.n2_log) + (t & ((1 << RB) - 1));
                                 const unsigned long long ubase =
                                     (static_cast<unsigned long long>((NT >> RB) * jr) << a.n2_log) + row0;
-                                if constexpr (!SEG)
+                                if constexpr (!SEG && FST != 3)
                                     wv[jj] = (a.w_pairs + ubase)[lane];
                                 x[jj] = lds[lds_pad_t<K>((jl << K) | i)];
                             }
@@ -773,6 +839,8 @@ namespace gpuntt
                                     (static_cast<unsigned long long>((NT >> RB) * jr) << a.n2_log) + row0;
                                 if constexpr (SEG)
                                     (a.out + ((fst_poly << a.poly_shift) + seg_base + ubase))[lane] = x[jj];
+                                else if constexpr (FST == 3) // Merge form: no W product here, lazy hand-over
+                                    (a.out + ((fst_poly << a.poly_shift) + ubase))[lane] = x[jj];
                                 else
                                     (a.out + ((fst_poly << a.poly_shift) + ubase))[lane] =
                                         lazy::normalize<M::TB>(m, m.mul(x[jj], wv[jj]));
@@ -1062,8 +1130,50 @@ namespace gpuntt
             pass_body<T, TLOG, false, true, false, K, M::TB, true, 0, true>(a, lds, a.q, a.q_bit, a.q_mu, 0, 0, 0, blk);
         }
 
+        // forward 4-step phase 1 in Merge form (FST = 3); block order as fourstep_phase1_lazy
+        template <typename T, int TLOG, int K, int LIM = 0>
+        __global__ __launch_bounds__(LTile<TLOG>::NT, (LOcc<TLOG, T>::WAVES)) void fourstep_phase1_merge_lazy(LazyArgsT<T> a)
+        {
+            __shared__ T lds[LTile<TLOG>::LDS_ELEMS_FST];
+            if (a.go_flag != nullptr && *a.go_flag == 0u)
+                return;
+            T qv = a.q, qb = a.q_bit, qm = a.q_mu;
+            if (a.mods != nullptr)
+            {
+                const Modulus<T> md = a.mods[0];
+                qv = md.value;
+                qb = md.bit;
+                qm = md.mu;
+            }
+            unsigned poly, tile;
+            poly_minor_order(blockIdx.x, static_cast<unsigned>(a.batch), a.poly_shift - TLOG, poly, tile, a.flags | F_PLAIN_ORDER);
+            pass_body<T, TLOG, false, false, true, K, 1, false, 3, false, LIM>(a, lds, qv, qb, qm, 0, uniform32(poly),
+                                                                                 uniform32(tile));
+        }
+
+        // 4-step transform of a ring that fits one tile (2^12 .. 2^14): ONE contiguous Merge pass over the whole ring
+        // with the transposition of the natural-order side done in LDS (XP above).  a.tw = Merge table of the ring.
+        template <typename T, int TLOG, bool INV, int K, int LIM = 0>
+        __global__ __launch_bounds__(LTile<TLOG>::NT, (LOcc<TLOG, T>::WAVES)) void fourstep_small_lazy(LazyArgsT<T> a)
+        {
+            static_assert(K >= 12 && K <= TLOG, "one-tile 4-step rings are 32 x n2 with n2 >= 128");
+            __shared__ T lds[LTile<TLOG>::LDS_ELEMS];
+            if (a.go_flag != nullptr && *a.go_flag == 0u)
+                return;
+            T qv = a.q, qb = a.q_bit, qm = a.q_mu;
+            if (a.mods != nullptr)
+            {
+                const Modulus<T> md = a.mods[0];
+                qv = md.value;
+                qb = md.bit;
+                qm = md.mu;
+            }
+            pass_body<T, TLOG, false, INV, true, K, 1, true, 0, false, LIM, INV ? 2 : 1>(a, lds, qv, qb, qm, 0, 0, 0,
+                                                                                       static_cast<long long>(blockIdx.x));
+        }
+
         // 4-step phase 1 kernel; grid = batch * N / TILE blocks, block b -> (tile b / batch, poly b % batch)
-        template <typename T, int TLOG, bool INV, int K>
+        template <typename T, int TLOG, bool INV, int K, int LIM = 0>
         __global__ __launch_bounds__(LTile<TLOG>::NT, (LOcc<TLOG, T>::WAVES)) void fourstep_phase1_lazy(LazyArgsT<T> a)
         {
             __shared__ T lds[LTile<TLOG>::LDS_ELEMS_FST];
@@ -1080,7 +1190,7 @@ namespace gpuntt
             }
             unsigned poly, tile;
             poly_minor_order(blockIdx.x, static_cast<unsigned>(a.batch), a.poly_shift - TLOG, poly, tile, a.flags);
-            pass_body<T, TLOG, false, INV, true, K, 1, false, true>(a, lds, qv, qb, qm, 0, poly, tile);
+            pass_body<T, TLOG, false, INV, true, K, 1, false, 1, false, LIM>(a, lds, qv, qb, qm, 0, poly, tile);
         }
 
     } // namespace kern

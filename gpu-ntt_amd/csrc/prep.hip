@@ -280,6 +280,79 @@ namespace gpuntt
             }
         }
 
+        // The 4-step transform IS the Merge transform of the same ring with one transposition on the natural-order
+        // side (forward: GPU_4STEP_NTT(in) = MergeNTT(in read as the n2 x n1 transpose of x); inverse: the output is
+        // stored transposed), so the Merge kernels can run it from a MERGE table of the ring -- bit-reversed powers of
+        // the 4-step root w, rebuilt here from the caller's 4-step tables and written straight into the kernels' stage
+        // layout (same slots / permutation as prep_twiddles, cyclic):
+        //   w^k = Wrow(k mod n2) * n1_table[brev(k >> log n2, log n1 - 1)],      k = brev(i, n - 1)
+        //   forward  Wrow(j) = W[(n1 / 2) * n2 + j]          (W[r * n2 + j] = w^(brev(r, log n1) * j))
+        //   inverse  Wrow(j) = W[n2 + brev(j, log n2)]       (W[r * n2 + c] = w^-(r * brev(c, log n2)))
+        // (reference table generators: src/lib/common/nttparameters.cu:356-444).  fold: n^-1 into the single twiddle of
+        // the final inverse stage (slot 1).  mods != nullptr: one device-side modulus, classified like prep_fourstep.
+        template <typename T>
+        __global__ __launch_bounds__(256) void prep_merge_from_fourstep(
+            const T* __restrict__ n1_table, const T* __restrict__ w_table, lazy::Tw<T>* __restrict__ ws, int log_n1,
+            int log_n2, int perm_tile_log, int inverse, int fold, T q_single, T rinv_single, T ninv_single,
+            const Modulus<T>* __restrict__ mods, const T* __restrict__ ninv_dev, lazy::Tw<T>* __restrict__ ws_ninv,
+            unsigned* __restrict__ go_flag, lazy::NormConst* __restrict__ norm_arr)
+        {
+            const unsigned long long gid = blockIdx.x * 256ull + threadIdx.x;
+            __shared__ T s_rinv;
+            T q = q_single, rinv = rinv_single;
+            if (mods != nullptr)
+            {
+                const Modulus<T> md = mods[0];
+                q = md.value;
+                if (threadIdx.x == 0)
+                    s_rinv = recip_norm<T>(q);
+                __syncthreads();
+                rinv = s_rinv;
+                if (gid == 0)
+                {
+                    if (go_flag != nullptr)
+                        *go_flag = (md.bit > static_cast<T>(lazy::Mod<T>::MAX_BIT) || md.value < 3) ? 0u : 1u;
+                    if (norm_arr != nullptr)
+                        norm_arr[0] = lazy::make_norm_const(md.value, md.bit);
+                }
+            }
+            const T ninv = (ninv_dev != nullptr) ? ninv_dev[0] : ninv_single;
+            if (gid == 0 && ninv_dev != nullptr && ws_ninv != nullptr)
+                ws_ninv[0] = lazy::Tw<T>{ninv, shoup_quotient_r<T>(ninv, q, rinv)};
+            const int n = log_n1 + log_n2;
+            if (gid >= (1ull << n))
+                return;
+            const unsigned slot = static_cast<unsigned>(gid);
+            if (slot == 0)
+            {
+                ws[0] = lazy::Tw<T>{0, 0};
+                return;
+            }
+            const int S = 31 - __clz(slot);
+            unsigned i = slot - (1u << S);
+            const int P = n - 1 - S;
+            if (perm_tile_log > 0 && P <= 2)
+            {
+                const unsigned nt = 1u << (perm_tile_log - 4);
+                const unsigned rp = 16u >> (P + 1);
+                const unsigned tile = i / (rp * nt), rem = i % (rp * nt);
+                const unsigned kk = rem / nt, t = rem % nt;
+                i = tile * (rp * nt) + t * rp + kk;
+            }
+            const unsigned k = (n > 1) ? (__brev(i) >> (33 - n)) : 0u; // brev(i, n - 1)
+            const unsigned n2 = 1u << log_n2;
+            const unsigned j = k & (n2 - 1u), m = k >> log_n2;
+            const unsigned long long widx =
+                inverse ? (static_cast<unsigned long long>(n2) + (__brev(j) >> (32 - log_n2)))
+                        : ((static_cast<unsigned long long>(n2) << (log_n1 - 1)) + j);
+            T w = w_table[widx];
+            if (m != 0u)
+                w = mulmod_r<T>(w, n1_table[__brev(m) >> (33 - log_n1)], q, rinv);
+            if (fold && slot == 1)
+                w = mulmod_r<T>(w, ninv, q, rinv);
+            ws[slot] = lazy::Tw<T>{w, shoup_quotient_r<T>(w, q, rinv)};
+        }
+
         // plain residues -> Shoup pairs with both matrix indices bit-reversed:
         // dst[k * n2 + j] = pair(src[brev(k, log n1) * n2 + brev(j, log n2)])
         template <typename T>
@@ -528,6 +601,29 @@ namespace gpuntt
                                                      lazy::Tw32*, lazy::Tw32*, int, int, int, bool, int, uint32_t, uint32_t,
                                                      const Modulus<uint32_t>*, const uint32_t*, lazy::Tw32*, unsigned*,
                                                      lazy::NormConst*, hipStream_t);
+
+        template <typename T>
+        void launch_prep_merge_from_fourstep(const T* n1_table, const T* w_table, lazy::Tw<T>* ws, int log_n1, int log_n2,
+                                             int perm_tile_log, bool inverse, bool fold, T q, T ninv,
+                                             const Modulus<T>* mods, const T* ninv_dev, lazy::Tw<T>* ws_ninv,
+                                             unsigned* go_flag, lazy::NormConst* norm_arr, hipStream_t stream)
+        {
+            const unsigned long long count = 1ull << (log_n1 + log_n2);
+            const unsigned grid = static_cast<unsigned>((count + 255) / 256);
+            hipLaunchKernelGGL((kern::prep_merge_from_fourstep<T>), dim3(grid), dim3(256), 0, stream, n1_table, w_table, ws,
+                               log_n1, log_n2, perm_tile_log, inverse ? 1 : 0, fold ? 1 : 0, q,
+                               mods ? static_cast<T>(0) : recip_norm_host<T>(q), ninv, mods, ninv_dev, ws_ninv, go_flag,
+                               norm_arr);
+            GPUNTT_HIP_CHECK(hipGetLastError());
+        }
+        template void launch_prep_merge_from_fourstep<uint64_t>(const uint64_t*, const uint64_t*, lazy::Tw64*, int, int, int,
+                                                                bool, bool, uint64_t, uint64_t, const Modulus<uint64_t>*,
+                                                                const uint64_t*, lazy::Tw64*, unsigned*, lazy::NormConst*,
+                                                                hipStream_t);
+        template void launch_prep_merge_from_fourstep<uint32_t>(const uint32_t*, const uint32_t*, lazy::Tw32*, int, int, int,
+                                                                bool, bool, uint32_t, uint32_t, const Modulus<uint32_t>*,
+                                                                const uint32_t*, lazy::Tw32*, unsigned*, lazy::NormConst*,
+                                                                hipStream_t);
 
         template <typename T>
         void launch_prep_pairs_brev(const T* src, lazy::Tw<T>* dst, int log_n1, int log_n2, T q, hipStream_t stream)

@@ -259,3 +259,76 @@ def test_fourstep_unsupported_size_is_silent(g, capfd):
     cfg = g.ntt4step_configuration(n_power=11)
     g.GPU_4STEP_NTT(d, o, t1, t2, w, p4.modulus, cfg, 1)
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("bits,logn,batch", [(64, 12, 5), (64, 13, 3), (64, 14, 256), (64, 14, 3), (32, 12, 3),
+                                             (32, 13, 3), (32, 13, 8), (32, 14, 1), (32, 14, 5)])
+def test_fourstep_rings_that_fit_one_tile(g, bits, logn, batch):
+    """2^12 .. 2^14: GPU_4STEP_NTT is the Merge transform of the ring with the natural-order side transposed, and
+    runs as ONE launch (kern::fourstep_small_lazy: Merge table rebuilt from the 4-step tables, transposition in LDS)
+    where the ring fits a tile -- 64-bit 2^12 / 2^13, 2^14 forward from 256 polynomials (smaller batches and the
+    inverse keep the two-phase path), 32-bit 2^12 .. 2^14 incl. tiles that hold two polynomials and a ragged last
+    tile.  Both overloads, both directions, against NTT_4STEP_CPU."""
+    P = O.Port(bits)
+    p4 = g.NTTParameters4Step(logn, bits)
+    oprm = P.fourstep_params(logn)
+    x = P.splitmix(1200 + logn + batch, 0, batch * p4.n, p4.modulus.value)
+    sample = sorted({0, batch // 2, batch - 1})
+    want = {p: P.fourstep_ntt(x[p * p4.n:(p + 1) * p4.n], oprm) for p in sample}
+    for rns in (False, True):
+        got = run_fourstep(g, p4, x, batch, inverse=False, rns=rns)
+        for p in sample:
+            assert np.array_equal(got[p * p4.n:(p + 1) * p4.n], want[p]), ("forward", bits, logn, batch, rns, p)
+        xin = np.concatenate([P.fourstep_intt_first_transpose(got[p * p4.n:(p + 1) * p4.n], oprm) for p in range(batch)])
+        back = run_fourstep(g, p4, xin, batch, inverse=True, rns=rns)
+        assert np.array_equal(back, x), ("inverse", bits, logn, batch, rns)
+
+
+@pytest.mark.parametrize("qbits", [61, 62])
+def test_fourstep_61_and_62_bit_moduli_on_the_fast_kernels(g, qbits):
+    """GPU_4STEP_NTT with a 61- / 62-bit prime (inside the reference's documented domain,
+    src/include/gpuntt/common/modular_arith.cuh:66-67) runs on the LIMIT = 8 / 4 fast kernels under path = fast-strict:
+    the one-launch 2^12 ring, the Merge-form forward plans and the two-phase inverse.  NTTParameters4Step has no
+    custom-prime constructor (neither has the reference), so the tables are generated on the device; the expected
+    values come from the Merge oracle through the identity GPU_4STEP_NTT(transpose(x)) == MergeNTT(x) (forward) and
+    transpose(GPU_4STEP_NTT(y, INVERSE)) == x (inverse), with the 4-step root as the ring's root."""
+    import torch
+    from gpu_utils import find_ntt_factors
+    P = O.Port(64)
+    g.set_option("path", "fast-strict")
+    try:
+        for logn, batch in ((12, 3), (13, 2), (16, 2), (18, 1)):
+            q, omega, psi = find_ntt_factors(qbits, logn)
+            m = g.Modulus(q, bits=64)
+            assert m.bit == qbits
+            shape = g.NTTParameters4Step(logn, 64)  # n1 x n2 of this ring
+            n, n1, n2 = shape.n, shape.n1, shape.n2
+            oprm = P.merge_params(logn, O.X_N_minus, (q, omega, psi))
+            x = P.splitmix(4100 + logn + qbits, 0, batch * n, q)
+            y = np.concatenate([P.merge_ntt(x[p * n:(p + 1) * n], oprm) for p in range(batch)])
+            for inverse in (False, True):
+                r = pow(omega, -1, q) if inverse else omega
+                kind = g.INVERSE if inverse else g.FORWARD
+                w = torch.zeros(n, dtype=torch.int64, device="cuda")
+                t1 = torch.zeros(n1 >> 1, dtype=torch.int64, device="cuda")
+                t2 = torch.zeros(n2 >> 1, dtype=torch.int64, device="cuda")
+                g.GPU_Generate4StepW(w, r, m, logn, kind)
+                g.GPU_GeneratePowerTable(t1, pow(r, n // n1, q), m, int(np.log2(n1)) - 1, True)
+                g.GPU_GeneratePowerTable(t2, pow(r, n // n2, q), m, int(np.log2(n2)) - 1, True)
+                cfg = g.ntt4step_configuration(n_power=logn, ntt_type=kind, mod_inverse=pow(n, -1, q) if inverse else 0)
+                if not inverse:
+                    src = x.reshape(batch, n1, n2).transpose(0, 2, 1).reshape(-1).copy()
+                else:
+                    src = y
+                d_in = g.to_device(src)
+                d_out = torch.zeros_like(d_in)
+                g.GPU_4STEP_NTT(d_in, d_out, t1, t2, w, m, cfg, batch)
+                torch.cuda.synchronize()
+                got = g.to_host(d_out)
+                if not inverse:
+                    assert np.array_equal(got, y), ("forward", qbits, logn)
+                else:
+                    back = got.reshape(batch, n1, n2).transpose(0, 2, 1).reshape(-1)
+                    assert np.array_equal(back, x), ("inverse", qbits, logn)
+    finally:
+        g.set_option("path", os.environ.get("GPUNTT_PATH", "default"))

@@ -215,6 +215,56 @@ def test_rns_c5_against_golden(g, golden_dir):
             assert sha(z[p * n:(p + 1) * n]) == rns["primes"][p % 8]["sha_inv_" + tag]
 
 
+def test_full_size_c5_properties(g, golden_dir):
+    """BASELINE config 5 at its real batch (512 polynomials over 8 primes, N = 2^16, X^N+1), drop-in call and
+    NTTPlan: the first 8 polynomials by the reference build's digests, sampled polynomials of every prime against
+    the oracle, range per prime, the exact round trip, and linearity of the first half against the second."""
+    import torch
+    rns = json.load(open(os.path.join(golden_dir, "rns_c5.json")))
+    fl = [(e["q"], e["omega"], e["psi"]) for e in rns["primes"]]
+    cases, fwd, inv, mods, ninv = _rns_setup(g, 64, 16, O.X_N_plus, fl)
+    n, batch, mc = 1 << 16, 512, 8
+    P = cases[0].P
+    x = np.concatenate([P.splitmix(rns["primes"][p]["seed_plus"] if p < mc else 7000 + p, 0, n, cases[p % mc].q)
+                        for p in range(batch)])
+    d = g.to_device(x)
+    out = torch.zeros_like(d)
+    cfg = g.ntt_rns_configuration(n_power=16, reduction_poly=O.X_N_plus)
+    g.GPU_NTT(d, out, fwd, mods, cfg, batch, mc)
+    torch.cuda.synchronize()
+    y = g.to_host(out)
+    for p in range(mc):
+        assert sha(y[p * n:(p + 1) * n]) == rns["primes"][p]["sha_fwd_plus"], p
+    for p in (8, 77, 255, 256, 509, 510, 511):
+        c = cases[p % mc]
+        assert np.array_equal(y[p * n:(p + 1) * n], P.merge_ntt(x[p * n:(p + 1) * n], c.oprm)), p
+    yr = y.reshape(batch, n)
+    for i, c in enumerate(cases):
+        assert int(yr[i::mc].max()) < c.q
+    plan = g.NTTPlan(fwd, [c.prm.modulus for c in cases], 16, O.X_N_plus, g.FORWARD, batch_hint=batch)
+    out2 = torch.zeros_like(d)
+    plan.execute(d, out2, batch)
+    torch.cuda.synchronize()
+    assert np.array_equal(g.to_host(out2), y)
+    plan.close()
+    # linearity: polynomials p and p + 256 share a prime
+    h = batch // 2
+    qs = np.tile(np.array([c.q for c in cases], dtype=np.uint64), h // mc)  # 60-bit primes: a + b < 2^61, no wrap
+    a, b = x[:h * n].reshape(h, n), x[h * n:].reshape(h, n)
+    s = ((a + b) % qs[:, None]).reshape(-1)
+    ds = g.to_device(s)
+    g.GPU_NTT_Inplace(ds, fwd, mods, cfg, h, mc)
+    torch.cuda.synchronize()
+    ys = g.to_host(ds).reshape(h, n)
+    for p in (0, 1, 7, 100, 255):
+        want = (yr[p] + yr[p + h]) % qs[p]
+        assert np.array_equal(ys[p], want), p
+    icfg = g.ntt_rns_configuration(n_power=16, ntt_type=g.INVERSE, reduction_poly=O.X_N_plus, mod_inverse=ninv)
+    g.GPU_INTT_Inplace(out, inv, mods, icfg, batch, mc)
+    torch.cuda.synchronize()
+    assert np.array_equal(g.to_host(out), x)
+
+
 @pytest.mark.parametrize("bits", [32, 64])
 def test_golden_vectors(g, bits, golden_dir):
     gold = np.load(os.path.join(golden_dir, "merge_u%d.npz" % bits))

@@ -319,7 +319,7 @@ print("OK")
     assert "OK" in _run_in_subprocess(code, {"GPUNTT_PATH": "fast-strict"})
 
 
-@pytest.mark.parametrize("bits,logn,poly", [(64, 28, O.X_N_plus), (32, 25, O.X_N_minus)])
+@pytest.mark.parametrize("bits,logn,poly", [(64, 28, O.X_N_plus), (64, 27, O.X_N_minus), (32, 25, O.X_N_minus)])
 def test_largest_rings_sparse_known_answer(g, bits, logn, poly):
     """the top of the documented range (n_power <= 28, reference ntt.cu:2088-2091) without a CPU transform of
     that size: a polynomial with a handful of non-zero coefficients has the closed-form spectrum
