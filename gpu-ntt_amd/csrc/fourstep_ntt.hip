@@ -301,6 +301,13 @@ namespace gpuntt
                 f.poly_shift = n_power;
                 f.mod_count = 1;
                 f.flags = host::lazy_order_flags();
+                {
+                    // consecutive sweeps walk the batch in opposite directions (Infinity Cache reuse of the hand-off): the
+                    // row passes alternate with the LAST one forwards, so phase 1 runs backwards when their number is odd
+                    const host::Plan rp = host::make_plan_tl(log_n2, tlr, tlr == 12 ? host::lazy_contig_k(log_n2) : tlr);
+                    if ((rp.count & 1) != 0 && host::lazy_reverse_passes())
+                        f.flags |= kern::F_REVERSE;
+                }
                 if constexpr (sizeof(T) == 8)
                 {
                     if (lim == 8)
@@ -316,6 +323,7 @@ namespace gpuntt
                 r.in = out;
                 r.n = n_power;
                 r.batch = 0;
+                r.flags = host::lazy_order_flags();
                 r.lim = lim;
                 if constexpr (sizeof(T) == 8)
                     if (lim == 0 && mods_dev == nullptr && host::lazy_lim31_enabled() && host::lazy_lim31_modulus(mod.value))
@@ -359,17 +367,20 @@ namespace gpuntt
             a.mod_count = 1;
             a.p_lo = 0;
             a.flags = host::lazy_order_flags();
-            if constexpr (sizeof(T) == 8)
+            if constexpr (INV) // (the forward direction returned above)
             {
-                if (lim == 8)
-                    host::launch_fourstep_lim<INV, 8>(0, log_n1, a, stream);
-                else if (lim == 4)
-                    host::launch_fourstep_lim<INV, 4>(0, log_n1, a, stream);
+                if constexpr (sizeof(T) == 8)
+                {
+                    if (lim == 8)
+                        host::launch_fourstep_lim<true, 8>(0, log_n1, a, stream);
+                    else if (lim == 4)
+                        host::launch_fourstep_lim<true, 4>(0, log_n1, a, stream);
+                    else
+                        host::launch_fourstep_phase1_lazy<T, true>(log_n1, a, stream);
+                }
                 else
-                    host::launch_fourstep_phase1_lazy<T, INV>(log_n1, a, stream);
+                    host::launch_fourstep_phase1_lazy<T, true>(log_n1, a, stream);
             }
-            else
-                host::launch_fourstep_phase1_lazy<T, INV>(log_n1, a, stream);
 
             // phase 2: n2-point transforms of the batch * n1 rows of `out`, in place
             kern::LazyArgsT<T> b = a;

@@ -107,21 +107,22 @@ namespace gpuntt
         extern template void launch_prep_pairs<uint32_t>(const uint32_t*, lazy::Tw32*, unsigned long long,
                                                          uint32_t, hipStream_t, const Modulus<uint32_t>*);
 
-        // 4-step phase 1 (fused n1-point transform + transpose + W multiply), log_n1 in 5..8
+        // 4-step phase 1 with the W product (fused n1-point transform + W multiply + transposed store), log_n1 in 5..8:
+        // the inverse direction (the forward one runs in Merge form, launch_fourstep_phase1_merge_lazy)
         template <typename T, bool INV, int LIMSEL = 0>
         void launch_fourstep_phase1_lazy(int log_n1, const kern::LazyArgsT<T>& a, hipStream_t stream);
-        extern template void launch_fourstep_phase1_lazy<uint64_t, false>(int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
         extern template void launch_fourstep_phase1_lazy<uint64_t, true>(int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
-        extern template void launch_fourstep_phase1_lazy<uint32_t, false>(int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
         extern template void launch_fourstep_phase1_lazy<uint32_t, true>(int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
 
         // 4-step transform of a ring that fits one tile in one launch: 64-bit 2^12 (tile 12), 2^13 (tile 13), 2^14 forward
-        // (tile 14); 32-bit 2^12 (tile 12), 2^13, 2^14 (tile 14).  a.tw = Merge table of the ring
+        // (tile 14); 32-bit 2^12 (tile 12), 2^14 (tile 14).  a.tw = Merge table of the ring
         // (launch_prep_merge_from_fourstep).  fourstep_small_tile: the tile such a call runs on, 0 = ring too large
         template <typename T> inline int fourstep_small_tile(int n_power, bool inverse, unsigned long long polys)
         {
+            // the ring must fill the tile: the 32-bit ring 2^13 would share a 16384-coefficient tile between two
+            // polynomials, and that kernel spills at the tile's 64-VGPR budget (it takes the two-sweep Merge form)
             const int tl = lazy_tile_log<T>(n_power, inverse, polys);
-            return (n_power >= 12 && n_power <= tl) ? tl : 0;
+            return (n_power >= 12 && n_power == tl) ? tl : 0;
         }
         template <typename T, bool INV>
         void launch_fourstep_small_lazy(int tile_log, int n, const kern::LazyArgsT<T>& a, hipStream_t stream);

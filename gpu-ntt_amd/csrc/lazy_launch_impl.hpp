@@ -270,8 +270,6 @@ namespace gpuntt
             {
                 if (tile_log == 12 && n == 12)
                     GPUNTT_SMALL(12, 12);
-                else if (tile_log == 14 && n == 13)
-                    GPUNTT_SMALL(14, 13);
                 else if (tile_log == 14 && n == 14)
                     GPUNTT_SMALL(14, 14);
                 else
@@ -378,8 +376,9 @@ namespace gpuntt
         template <bool INV, int LIMSEL>
         void launch_fourstep_lim(int what, int log_n1, const kern::LazyArgsT<uint64_t>& a, hipStream_t stream)
         {
-            if (what == 0)
-                return launch_fourstep_phase1_lazy<uint64_t, INV, LIMSEL>(log_n1, a, stream);
+            if constexpr (INV)
+                if (what == 0)
+                    return launch_fourstep_phase1_lazy<uint64_t, true, LIMSEL>(log_n1, a, stream);
             if constexpr (!INV)
                 if (what == 1)
                     return launch_fourstep_phase1_merge_lazy<uint64_t, LIMSEL>(log_n1, a, stream);

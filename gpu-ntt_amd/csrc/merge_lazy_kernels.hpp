@@ -479,35 +479,61 @@ namespace gpuntt
                 {
                     // fast path: whole tile in range and unsigned input -> 16 independent loads
                     // in flight; the guarded path only serves ragged last tiles / signed input
+                    // ragged last tile: the load itself is unconditional (a clamped, always valid address), only the
+                    // value is selected -- a branch per element serialised the 16 loads of a thread (a single 2^13
+                    // polynomial in a 16384-coefficient tile took longer than a 2^14 one)
                     auto load_guarded = [&](unsigned long long f) -> T {
-                        if (f >= a.total)
-                            return 0;
+                        const bool inside = f < a.total;
+                        const T raw = static_cast<const T*>(a.in)[inside ? f : 0ull];
+                        T val = raw;
                         if (a.flags & F_SIGNED_IN)
                         {
                             using S = typename std::make_signed<T>::type;
-                            const S sv = static_cast<const S*>(a.in)[f];
-                            return (sv < 0) ? static_cast<T>(m.q + static_cast<T>(sv)) : static_cast<T>(sv);
+                            val = (static_cast<S>(raw) < 0) ? static_cast<T>(m.q + raw) : raw;
                         }
-                        return static_cast<const T*>(a.in)[f];
+                        return inside ? val : static_cast<T>(0);
                     };
                     const T* src = static_cast<const T*>(a.in); // may alias a.out (in-place calls)
                     if constexpr (XP == 1)
                     {
                         // coalesced read of the n2 x 32 tile, transposed into natural order through LDS
-                        T tmp[EPT];
+                        // (groups of XG loads in flight: the 64-VGPR kernels of the 32-bit big tile spill with all 16)
+                        constexpr int XG = 8;
 #pragma unroll
-                        for (int j = 0; j < EPT; j++)
+                        for (int part = 0; part < EPT / XG; part++)
                         {
-                            const unsigned f = static_cast<unsigned>(t + NT * j);
-                            tmp[j] = plain_io ? ld_stream<true>(src + (map.base + f)) : load_guarded(map.base + f);
+                            T tmp[XG];
+                            if (plain_io)
+                            {
+#pragma unroll
+                                for (int jj = 0; jj < XG; jj++)
+                                    tmp[jj] = ld_stream<true>((src + (map.base + static_cast<unsigned>(NT * (part * XG + jj)))) + t);
+                            }
+                            else
+                            {
+#pragma unroll
+                                for (int jj = 0; jj < XG; jj++)
+                                    tmp[jj] = load_guarded(map.base + static_cast<unsigned>(t + NT * (part * XG + jj)));
+                            }
+#pragma unroll
+                            for (int jj = 0; jj < XG; jj++)
+                                lds[xp_lds<K>(xp_swap_fwd<K>(static_cast<unsigned>(t + NT * (part * XG + jj))))] = tmp[jj];
                         }
-#pragma unroll
-                        for (int j = 0; j < EPT; j++)
-                            lds[xp_lds<K>(xp_swap_fwd<K>(static_cast<unsigned>(t + NT * j)))] = tmp[j];
                         __syncthreads();
+                        if constexpr (WL >= K - XP_L1)
+                        {
+                            // the register bits lie above the row shift: one base address + compile-time offsets
+                            const T* lx = lds + xp_lds<K>(static_cast<unsigned>(elem_of<WL>(t, 0)));
 #pragma unroll
-                        for (int j = 0; j < EPT; j++)
-                            v[j] = lds[xp_lds<K>(static_cast<unsigned>(elem_of<WL>(t, j)))];
+                            for (int j = 0; j < EPT; j++)
+                                v[j] = lx[(j << WL) + ((j << WL) >> (K - XP_L1))];
+                        }
+                        else
+                        {
+#pragma unroll
+                            for (int j = 0; j < EPT; j++)
+                                v[j] = lds[xp_lds<K>(static_cast<unsigned>(elem_of<WL>(t, j)))];
+                        }
                         __syncthreads(); // the exchanges below reuse the buffer in the e + (e >> 4) layout
                     }
                     else if constexpr (SEG && INV)
@@ -1145,10 +1171,12 @@ namespace gpuntt
                 qb = md.bit;
                 qm = md.mu;
             }
-            unsigned poly, tile;
-            poly_minor_order(blockIdx.x, static_cast<unsigned>(a.batch), a.poly_shift - TLOG, poly, tile, a.flags | F_PLAIN_ORDER);
-            pass_body<T, TLOG, false, false, true, K, 1, false, 3, false, LIM>(a, lds, qv, qb, qm, 0, uniform32(poly),
-                                                                                 uniform32(tile));
+            // no W slice to share between polynomials here: plain poly-major order, walked backwards when the host
+            // asks (F_REVERSE: the first row pass then starts on what this pass wrote last -- Infinity Cache)
+            const unsigned bx = (a.flags & F_REVERSE) ? (gridDim.x - 1u - blockIdx.x) : blockIdx.x;
+            const int tiles_log = a.poly_shift - TLOG;
+            pass_body<T, TLOG, false, false, true, K, 1, false, 3, false, LIM>(a, lds, qv, qb, qm, 0, bx >> tiles_log,
+                                                                                 bx & ((1u << tiles_log) - 1u));
         }
 
         // 4-step transform of a ring that fits one tile (2^12 .. 2^14): ONE contiguous Merge pass over the whole ring
@@ -1156,7 +1184,7 @@ namespace gpuntt
         template <typename T, int TLOG, bool INV, int K, int LIM = 0>
         __global__ __launch_bounds__(LTile<TLOG>::NT, (LOcc<TLOG, T>::WAVES)) void fourstep_small_lazy(LazyArgsT<T> a)
         {
-            static_assert(K >= 12 && K <= TLOG, "one-tile 4-step rings are 32 x n2 with n2 >= 128");
+            static_assert(K >= 12 && K == TLOG, "one-tile 4-step rings fill their tile: 32 x n2 with n2 >= 128");
             __shared__ T lds[LTile<TLOG>::LDS_ELEMS];
             if (a.go_flag != nullptr && *a.go_flag == 0u)
                 return;
