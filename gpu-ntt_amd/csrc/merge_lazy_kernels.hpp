@@ -1171,12 +1171,15 @@ namespace gpuntt
                 qb = md.bit;
                 qm = md.mu;
             }
-            // no W slice to share between polynomials here: plain poly-major order, walked backwards when the host
-            // asks (F_REVERSE: the first row pass then starts on what this pass wrote last -- Infinity Cache)
+            // poly-minor order although there is no W slice to share: consecutive workgroups then store their 128-byte
+            // transposed runs into DIFFERENT polynomials.  In poly-major order neighbouring tiles write neighbouring runs
+            // of the same rows (one HBM channel for all eight XCDs): measured 4.24 against 3.90 ms at 2^24 x 64.
+            // F_REVERSE (host): walked backwards, so the first row pass starts on what this pass wrote last.
             const unsigned bx = (a.flags & F_REVERSE) ? (gridDim.x - 1u - blockIdx.x) : blockIdx.x;
-            const int tiles_log = a.poly_shift - TLOG;
-            pass_body<T, TLOG, false, false, true, K, 1, false, 3, false, LIM>(a, lds, qv, qb, qm, 0, bx >> tiles_log,
-                                                                                 bx & ((1u << tiles_log) - 1u));
+            unsigned poly, tile;
+            poly_minor_order(bx, static_cast<unsigned>(a.batch), a.poly_shift - TLOG, poly, tile, a.flags | F_PLAIN_ORDER);
+            pass_body<T, TLOG, false, false, true, K, 1, false, 3, false, LIM>(a, lds, qv, qb, qm, 0, uniform32(poly),
+                                                                                 uniform32(tile));
         }
 
         // 4-step transform of a ring that fits one tile (2^12 .. 2^14): ONE contiguous Merge pass over the whole ring
