@@ -448,6 +448,7 @@ namespace gpuntt
                 std::atomic<int> reverse{1};    // consecutive passes walk the batch in opposite directions
                 std::atomic<int> big_tiles{14}; // largest 64-bit ring done in one big tile
                 std::atomic<int> u32_tile{0};   // 12 | 14: 32-bit tile above 2^14
+                std::atomic<int> no_scratch{0}; // test hook: behave as if the twiddle scratch could not be allocated
             } g_opt;
         } // namespace
 
@@ -477,6 +478,8 @@ namespace gpuntt
                 g_opt.big_tiles = iv;
             else if (k == "u32_tile")
                 g_opt.u32_tile = (iv == 12 || iv == 14) ? iv : 0;
+            else if (k == "no_scratch")
+                g_opt.no_scratch = iv != 0;
             else
                 return false;
             return true;
@@ -508,6 +511,8 @@ namespace gpuntt
 
         void* lazy_workspace(hipStream_t stream, size_t bytes, bool or_null)
         {
+            if (or_null && g_opt.no_scratch.load(std::memory_order_relaxed) != 0)
+                return nullptr; // test hook: the out-of-memory fall-back of the drop-in entry points
             int dev = 0;
             GPUNTT_HIP_CHECK(hipGetDevice(&dev));
             Slot* sp;

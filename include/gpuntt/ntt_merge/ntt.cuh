@@ -204,6 +204,8 @@ namespace gpuntt
     //   reverse        0 | 1     consecutive passes walk the batch in opposite directions (default 1)
     //   u64_big_tiles  0|13|14   largest 64-bit ring transformed inside one big tile (default 14)
     //   u32_tile       0|12|14   32-bit tile size above 2^14 (default 0: built-in choice)
+    //   no_scratch     0 | 1     test hook: the drop-in calls behave as if their twiddle scratch could not be allocated
+    //                            (they run on the generic kernels, which need none)
     // Returns false for an unknown name or value.  Plans keep the choice made when they were created.
     bool GPU_NTT_SetOption(const char* name, const char* value);
 

@@ -757,3 +757,42 @@ def test_31q_range_at_its_boundary(g):
                 want = c.P.merge_ntt(x, c.oprm)
                 assert np.array_equal(c.gpu_forward(x), want), (logn, below, poly)
                 assert np.array_equal(c.gpu_inverse(want, inplace=True), x), (logn, below, poly)
+
+
+def test_scratch_exhaustion_falls_back_to_the_generic_kernels(g):
+    """a drop-in call whose per-(device, stream) twiddle scratch cannot be allocated (several streams, nearly full HBM)
+    runs on the generic kernels, which need none, instead of failing; option no_scratch = 1 simulates the
+    failed hipMalloc.  Merge single / RNS, 4-step both directions; under fast-strict the same situation throws."""
+    import torch
+    g.set_option("no_scratch", 1)
+    try:
+        for bits, logn, batch in ((64, 13, 5), (32, 14, 3), (64, 16, 2)):
+            c = MergeCase(g, bits, logn, O.X_N_plus)
+            x = c.random(batch, 8800 + logn)
+            want = c.P.merge_ntt(x, c.oprm)
+            assert np.array_equal(c.gpu_forward(x), want)
+            assert np.array_equal(c.gpu_inverse(want, inplace=True), x)
+        P = O.Port(64)
+        fl = _small_prime_factors(P, 12, 3)
+        cases, fwd, inv, mods, ninv = _rns_setup(g, 64, 12, O.X_N_minus, fl)
+        x = np.concatenate([cases[p % 3].random(1, 8900 + p) for p in range(6)])
+        d = g.to_device(x)
+        g.GPU_NTT_Inplace(d, fwd, mods, g.ntt_rns_configuration(n_power=12, reduction_poly=O.X_N_minus), 6, 3)
+        torch.cuda.synchronize()
+        y = g.to_host(d)
+        for p in range(6):
+            assert np.array_equal(y[p * 4096:(p + 1) * 4096], P.merge_ntt(x[p * 4096:(p + 1) * 4096], cases[p % 3].oprm))
+        from test_gpu_4step import run_fourstep
+        p4 = g.NTTParameters4Step(13, 64)
+        oprm = P.fourstep_params(13)
+        x4 = P.splitmix(8950, 0, 2 * p4.n, p4.modulus.value)
+        want4 = P.fourstep_ntt(x4, oprm)
+        assert np.array_equal(run_fourstep(g, p4, x4, 2, inverse=False), want4)
+        assert np.array_equal(run_fourstep(g, p4, P.fourstep_intt_first_transpose(want4, oprm), 2, inverse=True), x4)
+        g.set_option("path", "fast-strict")
+        c = MergeCase(g, 64, 13, O.X_N_plus)
+        with pytest.raises((ValueError, g.GpuNttError)):
+            c.gpu_forward(c.random(1, 1))
+    finally:
+        g.set_option("path", os.environ.get("GPUNTT_PATH", "default"))
+        g.set_option("no_scratch", 0)

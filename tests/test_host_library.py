@@ -153,7 +153,7 @@ def test_options_replace_environment_switches(g):
     for name, value in (("path", "generic"), ("path", "fast-strict"), ("path", "default"), ("contig_k", "11"),
                         ("contig_k", "0"), ("xcd_order", "0"), ("xcd_order", "1"), ("lim31", "0"), ("lim31", "1"),
                         ("reverse", "0"), ("reverse", "1"), ("u64_big_tiles", "13"), ("u64_big_tiles", "14"),
-                        ("u32_tile", "12"), ("u32_tile", "0")):
+                        ("u32_tile", "12"), ("u32_tile", "0"), ("no_scratch", "1"), ("no_scratch", "0")):
         g.set_option(name, value)
     for name, value in (("path", "sideways"), ("no_such_option", "1")):
         assert lib.gpuntt_set_option(name.encode(), value.encode()) != 0
