@@ -337,7 +337,7 @@ namespace gpuntt
             // one preparation launch; inverse: n^-1 rides on the last row stage (fold = 2)
             if (plan.mode != PLAN_EXECUTE)
                 host::launch_prep_fourstep<T>(n1_table, n2_table, w_table, ws_n1, ws_w, ws_n2, log_n1, log_n2,
-                                              (log_n2 >= tl2) ? tl2 : 0, false, INV ? 2 : 0, mod.value, ninv, mods_dev,
+                                              (log_n2 >= tl2) ? tl2 : 0, INV ? 2 : 0, mod.value, ninv, mods_dev,
                                               (INV && mods_dev) ? ninv_dev : nullptr, ws_ninv, go_flag, norm_arr,
                                               stream);
             if (go_flag_out != nullptr)
@@ -406,13 +406,43 @@ namespace gpuntt
             return true;
         }
 
-        // Natural-order forward transform in three sweeps (no transposes):
-        //   1. STRIDED pass over the top log2(n1) bits of the row-major n1 x n2 input = the n1-point
-        //      column transforms, in place, W product on the way out (canonical);
-        //   2. n2 > 512: STRIDED pass over row bits [8, log2 n2) in place (lazy);
-        //   3. CONTIG stages on 2^K-column runs of 2^(12-K) consecutive rows, stored transposed into
-        //      `out` (canonical) -- out[(c)*n1 + r] = row r, column c, the order of NTT_4STEP_CPU::ntt.
-        // `in` is overwritten (the reference's own three-call sequence ping-pongs through it too).
+        // Natural-order transforms (extension) in Merge form.  With x the natural-order polynomial,
+        // NTT_4STEP_CPU::ntt(x) is the TRANSPOSE of the bit-reversed Merge spectrum of x (read as n1 x n2), so:
+        //   forward  1. STRIDED Merge pass over the top log2(n1) index bits, in place on `in` (lazy out);
+        //            2. n2 > 512: STRIDED Merge pass over index bits [8, log2 n2), in place (lazy);
+        //            3. the low K <= 9 stages on 2^K-column runs of 2^(12-K) consecutive rows, stored transposed
+        //               into `out` (canonical): out[c * n1 + r] = row r, column c.
+        //   inverse  the same sweeps backwards: transposed load + low K Gentleman-Sande stages into `out`, the
+        //            strided passes in place on `out`, N^-1 folded into the final stage; `in` is left intact.
+        // All twiddles come from the ring's Merge table (rebuilt from the caller's 4-step tables into the W region of
+        // the workspace, plain stage layout): no W stream, no W product.  `in` is overwritten by the forward transform
+        // (the reference's own three-call sequence ping-pongs through it too).
+        template <typename T>
+        void natural_args(kern::LazyArgsT<T>& a, const lazy::Tw<T>* table, const Modulus<T>& mod, int n_power, int log_n1,
+                          int log_n2, int batch_size)
+        {
+            a.tw = table;
+            a.mods = nullptr;
+            a.q = mod.value;
+            a.q_bit = mod.bit;
+            a.q_mu = mod.mu;
+            a.ninv_arr = nullptr;
+            a.ninv = lazy::Tw<T>{0, 0};
+            a.go_flag = nullptr;
+            a.norm = lazy::make_norm_const(static_cast<uint64_t>(mod.value), static_cast<uint64_t>(mod.bit));
+            a.norm_arr = nullptr;
+            a.w_pairs = nullptr;
+            a.n2_log = log_n1;  // row stride of the column-major (n2 x n1) side
+            a.row_log = log_n2; // row stride of the row-major (n1 x n2) side
+            a.batch = 0;        // plain block order
+            a.total = static_cast<unsigned long long>(batch_size) << n_power;
+            a.n = n_power;
+            a.poly_shift = n_power;
+            a.mod_count = 1;
+            a.p_lo = 0;
+            a.flags = host::lazy_order_flags();
+        }
+
         template <typename T>
         bool fourstep_natural_forward_lazy(T* in, T* out, const T* n1_table, const T* n2_table,
                                            const T* w_table, const Modulus<T>& mod, int n_power, int log_n1,
@@ -420,6 +450,7 @@ namespace gpuntt
                                            const PlanUse<T>& plan = PlanUse<T>())
         {
             using TW = lazy::Tw<T>;
+            (void) n2_table;
             if (mod.bit > T(lazy::Mod<T>::MAX_BIT) || mod.value < 3)
                 return false;
             if (host::forced_path() == 1)
@@ -430,76 +461,36 @@ namespace gpuntt
                            : static_cast<TW*>(host::lazy_workspace(stream, sizeof(TW) * (n1 + n + n2 + 2), true));
             if (ws == nullptr)
                 return false; // no device memory for the scratch: the generic kernels need none
-            TW* ws_n1 = ws;
-            TW* ws_w = ws + n1;
-            TW* ws_n2 = ws + n1 + n;
-            // plain stage layout of the n2 table (no per-tile permutation: the last pass works on row runs)
+            TW* ws_merge = ws + n1; // the W region of the workspace holds the ring's Merge table
             if (plan.mode != PLAN_EXECUTE)
-                host::launch_prep_fourstep<T>(n1_table, n2_table, w_table, ws_n1, ws_w, ws_n2, log_n1, log_n2, 0, false,
-                                              0, mod.value, T(0), nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+                host::launch_prep_merge_from_fourstep<T>(n1_table, w_table, ws_merge, log_n1, log_n2, 0, false, false,
+                                                         mod.value, T(0), nullptr, nullptr, nullptr, nullptr, nullptr, stream);
             if (plan.mode == PLAN_PREPARE)
                 return true;
 
             kern::LazyArgsT<T> a{};
+            natural_args<T>(a, ws_merge, mod, n_power, log_n1, log_n2, batch_size);
             a.in = in;
             a.out = in;
-            a.tw = ws_n1;
-            a.mods = nullptr;
-            a.q = mod.value;
-            a.q_bit = mod.bit;
-            a.q_mu = mod.mu;
-            a.ninv_arr = nullptr;
-            a.ninv = TW{0, 0};
-            a.go_flag = nullptr;
-            a.norm = lazy::make_norm_const(static_cast<uint64_t>(mod.value), static_cast<uint64_t>(mod.bit));
-            a.norm_arr = nullptr;
-            a.w_pairs = ws_w;
-            a.n2_log = log_n2;
-            a.batch = batch_size;
-            a.total = static_cast<unsigned long long>(batch_size) << n_power;
-            a.n = n_power;
-            a.poly_shift = n_power;
-            a.mod_count = 1;
+            // 1. top log2(n1) stages, canonical in, lazy out
             a.p_lo = log_n2;
-            a.flags = host::lazy_order_flags();
-            host::launch_fourstep_nat_p1_lazy<T>(log_n1, a, stream);
-
-            // rows of length n2
-            kern::LazyArgsT<T> b = a;
-            b.tw = ws_n2;
-            b.w_pairs = nullptr;
-            b.n = log_n2;
-            int k_last = log_n2;
-            bool lazy_in = false;
+            host::launch_pass_lazy<T, false>(host::Pass{false, log_n1, log_n2}, 12, true, false, a, stream);
+            // 2. index bits [8, log2 n2)
+            const int k_last = (log_n2 > 9) ? 8 : log_n2;
             if (log_n2 > 9)
             {
-                k_last = 8;
-                lazy_in = true;
-                b.poly_shift = log_n2;
-                b.p_lo = k_last;
-                b.batch = 0; // plain block order
-                const host::Pass sp{false, log_n2 - k_last, k_last};
-                host::launch_pass_lazy<T, false>(sp, 12, true, false, b, stream);
+                a.p_lo = k_last;
+                host::launch_pass_lazy<T, false>(host::Pass{false, log_n2 - k_last, k_last}, 12, false, false, a, stream);
             }
-            b.in = in;
-            b.out = out;
-            b.poly_shift = n_power; // the transposing pass addresses whole polynomials
-            b.n2_log = log_n1;      // output row stride
-            b.p_lo = 0;
-            host::launch_fourstep_nat_last_lazy<T>(k_last, lazy_in, b, stream);
+            // 3. low stages + transposed store (big rings: poly-minor block order, the batch shares the table in L2)
+            a.in = in;
+            a.out = out;
+            a.p_lo = 0;
+            a.batch = (n_power >= 20 && batch_size >= 2) ? batch_size : 0;
+            host::launch_fourstep_nat_last_lazy<T>(k_last, a, stream);
             return true;
         }
 
-        // Natural-order inverse transform: the three forward sweeps run backwards.
-        //   1. transposed load of the column-major input (the forward result) + the low row stages
-        //      (Gentleman-Sande) on 2^K-column runs of 2^(12-K) rows, row-major `out`, lazy;
-        //   2. n2 > 512: STRIDED inverse pass over row bits [8, log2 n2), in place;
-        //   3. W^-1 product on the way in + STRIDED inverse pass over the top log2(n1) bits of the
-        //      N-ring with N^-1 folded into its last stage: canonical, natural order, in `out`.
-        // The caller's inverse W table is indexed W[i*n2 + j] = root^-(bitrev(j)*i) (reference
-        // nttparameters.cu:430-444); sweep 3 needs root^-(bitrev(k)*j) at [k*n2 + j], i.e. the same
-        // matrix with both indices bit-reversed -- the pair preparation re-indexes it.  `in` is
-        // left intact.
         template <typename T>
         bool fourstep_natural_inverse_lazy(T* in, T* out, const T* n1_table, const T* n2_table,
                                            const T* w_table, const Modulus<T>& mod, T ninv, int n_power,
@@ -507,6 +498,7 @@ namespace gpuntt
                                            const PlanUse<T>& plan = PlanUse<T>())
         {
             using TW = lazy::Tw<T>;
+            (void) n2_table;
             if (mod.bit > T(lazy::Mod<T>::MAX_BIT) || mod.value < 3 || ninv >= mod.value)
                 return false;
             if (host::forced_path() == 1)
@@ -517,61 +509,34 @@ namespace gpuntt
                            : static_cast<TW*>(host::lazy_workspace(stream, sizeof(TW) * (n1 + n + n2 + 2), true));
             if (ws == nullptr)
                 return false; // no device memory for the scratch: the generic kernels need none
-            TW* ws_n1 = ws;
-            TW* ws_w = ws + n1;
-            TW* ws_n2 = ws + n1 + n;
-            // N^-1 rides on the very last stage (fold = 1: the n1 table); W re-indexed (w_brev)
+            TW* ws_merge = ws + n1;
+            // inverse Merge table of the ring, N^-1 folded into the single twiddle of the final stage (slot 1)
             if (plan.mode != PLAN_EXECUTE)
-                host::launch_prep_fourstep<T>(n1_table, n2_table, w_table, ws_n1, ws_w, ws_n2, log_n1, log_n2, 0, true,
-                                              1, mod.value, ninv, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+                host::launch_prep_merge_from_fourstep<T>(n1_table, w_table, ws_merge, log_n1, log_n2, 0, true, true, mod.value,
+                                                         ninv, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
             if (plan.mode == PLAN_PREPARE)
                 return true;
 
             kern::LazyArgsT<T> a{};
+            natural_args<T>(a, ws_merge, mod, n_power, log_n1, log_n2, batch_size);
+            // 1. transposed load + the low stages, row-major `out`, lazy
             a.in = in;
             a.out = out;
-            a.tw = ws_n2;
-            a.mods = nullptr;
-            a.q = mod.value;
-            a.q_bit = mod.bit;
-            a.q_mu = mod.mu;
-            a.ninv_arr = nullptr;
-            a.ninv = TW{0, 0};
-            a.go_flag = nullptr;
-            a.norm = lazy::make_norm_const(static_cast<uint64_t>(mod.value), static_cast<uint64_t>(mod.bit));
-            a.norm_arr = nullptr;
-            a.w_pairs = nullptr;
-            a.n2_log = log_n1; // input column stride
-            a.batch = batch_size;
-            a.total = static_cast<unsigned long long>(batch_size) << n_power;
-            a.n = log_n2;
-            a.poly_shift = n_power;
-            a.mod_count = 1;
-            a.p_lo = 0;
-            a.flags = host::lazy_order_flags();
             const int k_first = (log_n2 > 9) ? 8 : log_n2;
+            a.batch = (n_power >= 20 && batch_size >= 2) ? batch_size : 0; // poly-minor: the batch shares the table in L2
             host::launch_fourstep_nat_first_inv_lazy<T>(k_first, a, stream);
-
+            a.batch = 0;
+            // 2. index bits [8, log2 n2), in place
+            a.in = out;
             if (log_n2 > 9)
             {
-                kern::LazyArgsT<T> b = a;
-                b.in = out;
-                b.poly_shift = log_n2;
-                b.p_lo = k_first;
-                b.batch = 0; // plain block order
-                const host::Pass sp{false, log_n2 - k_first, k_first};
-                host::launch_pass_lazy<T, true>(sp, 12, false, false, b, stream);
+                a.p_lo = k_first;
+                host::launch_pass_lazy<T, true>(host::Pass{false, log_n2 - k_first, k_first}, 12, false, false, a, stream);
             }
-
-            kern::LazyArgsT<T> c = a;
-            c.in = out;
-            c.tw = ws_n1;
-            c.w_pairs = ws_w;
-            c.n = n_power;
-            c.poly_shift = n_power;
-            c.p_lo = log_n2;
-            c.ninv = TW{ninv, host::shoup_host(ninv, mod.value)};
-            host::launch_fourstep_nat_last_inv_lazy<T>(log_n1, c, stream);
+            // 3. top log2(n1) stages with N^-1: canonical, natural order
+            a.p_lo = log_n2;
+            a.ninv = TW{ninv, host::shoup_host(ninv, mod.value)};
+            host::launch_pass_lazy<T, true>(host::Pass{false, log_n1, log_n2}, 12, false, true, a, stream);
             return true;
         }
 

@@ -135,37 +135,27 @@ namespace gpuntt
         void launch_fourstep_phase1_merge_lazy(int log_n1, const kern::LazyArgsT<T>& a, hipStream_t stream);
         extern template void launch_fourstep_phase1_merge_lazy<uint64_t>(int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
         extern template void launch_fourstep_phase1_merge_lazy<uint32_t>(int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
-        // natural-order forward 4-step passes (instantiated with the forward kernels)
+        // natural-order 4-step (extension) in Merge form: strided Merge passes + one transposing row pass
         template <typename T>
-        void launch_fourstep_nat_p1_lazy(int log_n1, const kern::LazyArgsT<T>& a, hipStream_t stream);
-        template <typename T>
-        void launch_fourstep_nat_last_lazy(int k, bool lazy_in, const kern::LazyArgsT<T>& a, hipStream_t stream);
-        extern template void launch_fourstep_nat_p1_lazy<uint64_t>(int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
-        extern template void launch_fourstep_nat_p1_lazy<uint32_t>(int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
-        extern template void launch_fourstep_nat_last_lazy<uint64_t>(int, bool, const kern::LazyArgsT<uint64_t>&, hipStream_t);
-        extern template void launch_fourstep_nat_last_lazy<uint32_t>(int, bool, const kern::LazyArgsT<uint32_t>&, hipStream_t);
-
-        // natural-order inverse 4-step passes (instantiated with the inverse kernels)
+        void launch_fourstep_nat_last_lazy(int k, const kern::LazyArgsT<T>& a, hipStream_t stream);
+        extern template void launch_fourstep_nat_last_lazy<uint64_t>(int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
+        extern template void launch_fourstep_nat_last_lazy<uint32_t>(int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
         template <typename T>
         void launch_fourstep_nat_first_inv_lazy(int k, const kern::LazyArgsT<T>& a, hipStream_t stream);
-        template <typename T>
-        void launch_fourstep_nat_last_inv_lazy(int log_n1, const kern::LazyArgsT<T>& a, hipStream_t stream);
         extern template void launch_fourstep_nat_first_inv_lazy<uint64_t>(int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
         extern template void launch_fourstep_nat_first_inv_lazy<uint32_t>(int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
-        extern template void launch_fourstep_nat_last_inv_lazy<uint64_t>(int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
-        extern template void launch_fourstep_nat_last_inv_lazy<uint32_t>(int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
         // everything a 4-step call prepares, in one launch (prep.hip: prep_fourstep)
         template <typename T>
         void launch_prep_fourstep(const T* n1_table, const T* n2_table, const T* w_table, lazy::Tw<T>* ws_n1,
-                                  lazy::Tw<T>* ws_w, lazy::Tw<T>* ws_n2, int log_n1, int log_n2, int perm2, bool w_brev,
+                                  lazy::Tw<T>* ws_w, lazy::Tw<T>* ws_n2, int log_n1, int log_n2, int perm2,
                                   int fold, T q, T ninv, const Modulus<T>* mods, const T* ninv_dev, lazy::Tw<T>* ws_ninv,
                                   unsigned* go_flag, lazy::NormConst* norm_arr, hipStream_t stream);
         extern template void launch_prep_fourstep<uint64_t>(const uint64_t*, const uint64_t*, const uint64_t*, lazy::Tw64*,
-                                                            lazy::Tw64*, lazy::Tw64*, int, int, int, bool, int, uint64_t,
+                                                            lazy::Tw64*, lazy::Tw64*, int, int, int, int, uint64_t,
                                                             uint64_t, const Modulus<uint64_t>*, const uint64_t*, lazy::Tw64*,
                                                             unsigned*, lazy::NormConst*, hipStream_t);
         extern template void launch_prep_fourstep<uint32_t>(const uint32_t*, const uint32_t*, const uint32_t*, lazy::Tw32*,
-                                                            lazy::Tw32*, lazy::Tw32*, int, int, int, bool, int, uint32_t,
+                                                            lazy::Tw32*, lazy::Tw32*, int, int, int, int, uint32_t,
                                                             uint32_t, const Modulus<uint32_t>*, const uint32_t*, lazy::Tw32*,
                                                             unsigned*, lazy::NormConst*, hipStream_t);
         // Merge table of the 4-step ring (bit-reversed powers of its root), rebuilt from the caller's 4-step tables
@@ -183,12 +173,6 @@ namespace gpuntt
                                                                        int, int, bool, bool, uint32_t, uint32_t,
                                                                        const Modulus<uint32_t>*, const uint32_t*,
                                                                        lazy::Tw32*, unsigned*, lazy::NormConst*, hipStream_t);
-        // W table of the inverse direction re-indexed for it: dst[k*n2 + j] = pair(src[brev(k)*n2 + brev(j)])
-        template <typename T>
-        void launch_prep_pairs_brev(const T* src, lazy::Tw<T>* dst, int log_n1, int log_n2, T q, hipStream_t stream);
-        extern template void launch_prep_pairs_brev<uint64_t>(const uint64_t*, lazy::Tw64*, int, int, uint64_t, hipStream_t);
-        extern template void launch_prep_pairs_brev<uint32_t>(const uint32_t*, lazy::Tw32*, int, int, uint32_t, hipStream_t);
-
         // host Shoup companion floor(w * 2^W / q)
         inline uint64_t shoup_host(uint64_t w, uint64_t q)
         {

@@ -279,54 +279,30 @@ namespace gpuntt
             GPUNTT_HIP_CHECK(hipGetLastError());
         }
 
-        // natural-order forward 4-step (fourstep_ntt.hip): column pass with W, and the transposing
-        // last row pass (k = stages, lazy_in = its input comes from a strided row pass)
+        // natural-order forward 4-step (fourstep_ntt.hip): the transposing last row pass, k = 7 .. 9 low stages of the
+        // ring, lazy input from the strided passes above it
         template <typename T>
-        void launch_fourstep_nat_p1_lazy(int log_n1, const kern::LazyArgsT<T>& a, hipStream_t stream)
-        {
-            constexpr int TLOG = 12;
-            const unsigned grid = static_cast<unsigned>(a.total >> TLOG);
-            switch (log_n1)
-            {
-#define GPUNTT_CASE(KK)                                                                          \
-    case KK:                                                                                      \
-        hipLaunchKernelGGL((kern::fourstep_nat_p1_lazy<T, TLOG, KK>), dim3(grid),                 \
-                           dim3(kern::LTile<TLOG>::NT), 0, stream, a);                            \
-        break;
-                GPUNTT_CASE(5)
-                GPUNTT_CASE(6)
-                GPUNTT_CASE(7)
-                GPUNTT_CASE(8)
-#undef GPUNTT_CASE
-                default:
-                    throw std::invalid_argument("internal: bad 4-step n1");
-            }
-            GPUNTT_HIP_CHECK(hipGetLastError());
-        }
-        template <typename T>
-        void launch_fourstep_nat_last_lazy(int k, bool lazy_in, const kern::LazyArgsT<T>& a, hipStream_t stream)
+        void launch_fourstep_nat_last_lazy(int k, const kern::LazyArgsT<T>& a, hipStream_t stream)
         {
             constexpr int TLOG = 12;
             constexpr int LIM = lazy::Mod<T>::LIMIT;
             const unsigned grid = static_cast<unsigned>(a.total >> TLOG);
-#define GPUNTT_ONE(KK, IN_)                                                                       \
-    hipLaunchKernelGGL((kern::fourstep_nat_last_lazy<T, TLOG, KK, IN_>), dim3(grid),               \
+#define GPUNTT_ONE(KK)                                                                            \
+    hipLaunchKernelGGL((kern::fourstep_nat_last_lazy<T, TLOG, KK, LIM>), dim3(grid),               \
                        dim3(kern::LTile<TLOG>::NT), 0, stream, a)
-            if (k == 7 && !lazy_in)
-                GPUNTT_ONE(7, 1);
-            else if (k == 8 && !lazy_in)
-                GPUNTT_ONE(8, 1);
-            else if (k == 9 && !lazy_in)
-                GPUNTT_ONE(9, 1);
-            else if (k == 8 && lazy_in)
-                GPUNTT_ONE(8, LIM);
+            if (k == 7)
+                GPUNTT_ONE(7);
+            else if (k == 8)
+                GPUNTT_ONE(8);
+            else if (k == 9)
+                GPUNTT_ONE(9);
             else
                 throw std::invalid_argument("internal: bad natural-order 4-step row pass");
 #undef GPUNTT_ONE
             GPUNTT_HIP_CHECK(hipGetLastError());
         }
 
-        // natural-order inverse 4-step: transposing first row pass (k stages) and the column pass with W^-1
+        // natural-order inverse 4-step: the transposing first row pass (k = 7 .. 9 low stages of the ring)
         template <typename T>
         void launch_fourstep_nat_first_inv_lazy(int k, const kern::LazyArgsT<T>& a, hipStream_t stream)
         {
@@ -348,29 +324,6 @@ namespace gpuntt
             }
             GPUNTT_HIP_CHECK(hipGetLastError());
         }
-        template <typename T>
-        void launch_fourstep_nat_last_inv_lazy(int log_n1, const kern::LazyArgsT<T>& a, hipStream_t stream)
-        {
-            constexpr int TLOG = 12;
-            const unsigned grid = static_cast<unsigned>(a.total >> TLOG);
-            switch (log_n1)
-            {
-#define GPUNTT_CASE(KK)                                                                          \
-    case KK:                                                                                      \
-        hipLaunchKernelGGL((kern::fourstep_nat_last_inv_lazy<T, TLOG, KK>), dim3(grid),           \
-                           dim3(kern::LTile<TLOG>::NT), 0, stream, a);                            \
-        break;
-                GPUNTT_CASE(5)
-                GPUNTT_CASE(6)
-                GPUNTT_CASE(7)
-                GPUNTT_CASE(8)
-#undef GPUNTT_CASE
-                default:
-                    throw std::invalid_argument("internal: bad 4-step n1");
-            }
-            GPUNTT_HIP_CHECK(hipGetLastError());
-        }
-
         // 4-step kernels for 64-bit words with a 61- / 62-bit modulus (LIMIT = 8 / 4): what = 0 phase 1 with the W
         // product (inverse), 1 phase 1 in Merge form (forward), 2 the one-launch 2^12 ring
         template <bool INV, int LIMSEL>

@@ -38,6 +38,7 @@ namespace gpuntt
             const lazy::Tw<T>* w_pairs;      // 4-step phase 1: prepared W matrix (N pairs)
             int lim;                         // 64-bit words: 0, or 8 / 4 = a 61- / 62-bit modulus in the call -> the LIMIT = 8 / 4 kernels (host-side switch)
             int n2_log;                      // 4-step phase 1: log2 n2
+            int row_log;                     // natural-order 4-step row passes (FST = 2): log2 of the row stride of the row-major side (n2); a.n stays the ring (twiddle indices)
             int batch;                       // > 1: polynomials of the call, blocks are ordered poly-minor (4-step phase 1; big-ring passes)
             unsigned long long total;
             int n;
@@ -261,9 +262,6 @@ namespace gpuntt
         // FST = 2, natural-order 4-step, last forward pass: CONTIG stages on the same 2^K-column range
         // of 2^(TL-K) consecutive rows (lazy input from the strided row passes, or canonical input
         // when the rows fit one pass), canonical output stored transposed (no W product).
-        // WMUL (STRIDED passes): natural-order 4-step, first forward pass: the column transforms run
-        // in place on the row-major input, the W product is applied on the way out; blocks are
-        // ordered poly-minor (blk_override) so a batch shares each W slice in L2.
         // streaming forms (global_load / global_store ... nt): the first pass reads input nobody reads again, the
         // last pass writes output nobody reads again -- what should stay in the caches is the hand-off between the
         // passes (C2 0.437 -> 0.422 ms, C5 0.235 -> 0.227 ms, C4 0.310 -> 0.303 ms; nt on the hand-off loads as well
@@ -326,8 +324,25 @@ namespace gpuntt
                    uniform32(static_cast<unsigned>(v));
         }
 
+        // LDS reads that must have COMPLETED before the barrier that follows (other waves overwrite the buffer behind it):
+        // the compiler is free to sink a load whose value is first used after the barrier below that barrier -- a release
+        // fence only keeps earlier loads ahead of later STORES of the same thread -- and it does (found in round 3: the
+        // one-launch 4-step kernel on the 16384-coefficient tile returned a wrong polynomial once in ~1000).  A volatile asm
+        // that "uses" every value forces the loads and their s_waitcnt in front of it.
+        template <typename T, int N> __device__ __forceinline__ void pin_loaded(T (&v)[N])
+        {
+#pragma unroll
+            for (int j = 0; j < N; j++)
+            {
+                if constexpr (sizeof(T) == 8)
+                    asm volatile("" : "+v"(v[j])::"memory");
+                else
+                    asm volatile("" : "+v"(v[j])::"memory");
+            }
+        }
+
         template <typename T, int TLOG, bool EXACT, bool INV, bool CONTIG, int K, int IN_BOUND, bool LAST,
-                  int FST = 0, bool WMUL = false, int LIM = 0, int XP = 0>
+                  int FST = 0, int LIM = 0, int XP = 0>
         __device__ __forceinline__ void pass_body(const LazyArgsT<T>& a, T* lds, T q_value, T q_bit, T q_mu,
                                                   int mi, unsigned long long fst_poly = 0,
                                                   unsigned fst_tile = 0, long long blk_override = -1,
@@ -356,9 +371,9 @@ namespace gpuntt
             constexpr bool SEG = (FST == 2);
             using Map = LTileMap<TLOG, CONTIG, K, SEG>;
             Map map = SEG   ? Map((fst_poly << a.poly_shift) +
-                                      ((static_cast<unsigned long long>(fst_tile) << (TL - K)) << a.n) +
+                                      ((static_cast<unsigned long long>(fst_tile) << (TL - K)) << a.row_log) +
                                       (static_cast<unsigned long long>(fst_seg) << K),
-                                  a.n)
+                                  a.row_log)
                       : FST ? Map((fst_poly << a.poly_shift) + (static_cast<unsigned long long>(fst_tile) << TL))
                             : Map(a.n, a.p_lo,
                                   blk_override >= 0 ? static_cast<unsigned long long>(blk_override)
@@ -447,7 +462,7 @@ namespace gpuntt
             const bool full_tile = tile_in_range;
             const bool plain_io = full_tile; // signed input is converted after the unguarded loads
             // (only the first pass of a forward transform can see signed words)
-            const bool signed_in = (!INV && IN_BOUND == 1 && !FST && !WMUL) ? ((a.flags & F_SIGNED_IN) != 0u) : false;
+            const bool signed_in = (!INV && IN_BOUND == 1 && !FST) ? ((a.flags & F_SIGNED_IN) != 0u) : false;
             auto to_residue = [&](T x) -> T {
                 using S = typename std::make_signed<T>::type;
                 return (static_cast<S>(x) < 0) ? static_cast<T>(x + m.q) : x;
@@ -458,12 +473,9 @@ namespace gpuntt
             // 8 waves per SIMD cover the latency)
             constexpr bool TW_AHEAD = (LOcc<TLOG, T>::WAVES <= 4);
 
-            // natural-order inverse 4-step, last pass: the W^-1 pairs of the gather are live first -- the round's own
-            // twiddles are requested behind it (with both in flight the kernel spills)
-            constexpr bool TW0_LATE = WMUL && INV;
             T v[EPT];
             TW tw_next[TW_PER_ROUND];
-            if constexpr (TW_AHEAD && !TW0_LATE)
+            if constexpr (TW_AHEAD)
                 load_twiddles(std::integral_constant<int, 0>{}, tw_next);
 
             static_for<G::NR>([&](auto r_) {
@@ -534,6 +546,7 @@ namespace gpuntt
                             for (int j = 0; j < EPT; j++)
                                 v[j] = lds[xp_lds<K>(static_cast<unsigned>(elem_of<WL>(t, j)))];
                         }
+                        pin_loaded(v);
                         __syncthreads(); // the exchanges below reuse the buffer in the e + (e >> 4) layout
                     }
                     else if constexpr (SEG && INV)
@@ -560,35 +573,12 @@ namespace gpuntt
 #pragma unroll
                         for (int j = 0; j < EPT; j++)
                             v[j] = lds[lds_pad_t<K>(elem_of<WL>(t, j))];
+                        pin_loaded(v);
                         __syncthreads(); // the exchanges below reuse the buffer in the e + (e >> 4) layout
                     }
                     else if constexpr (DIRECT_IO)
                     {
-                        if constexpr (WMUL && INV)
-                        {
-                            // natural-order inverse 4-step, last pass: W^-1[f mod N] on the way in
-                            const unsigned lane = map.part(elem_of<WL>(t, 0));
-                            const unsigned long long wb = map.base & nmask;
-                            // quarters of 4 bound the live W pairs (16 VGPRs): with halves of 8 the 64-bit kernels
-                            // spilled once v126 / v127 became the quotient chain's fixed pair (lazy.hpp)
-                            constexpr int QW = (sizeof(T) == 8) ? EPT / 4 : EPT / 2;
-#pragma unroll
-                            for (int part = 0; part < EPT / QW; part++)
-                            {
-                                TW wv[QW];
-#pragma unroll
-                                for (int jj = 0; jj < QW; jj++)
-                                {
-                                    const int j = part * QW + jj;
-                                    wv[jj] = (a.w_pairs + (wb + map.part(static_cast<unsigned>(j) << WL)))[lane];
-                                    v[j] = (src + (map.base + map.part(static_cast<unsigned>(j) << WL)))[lane];
-                                }
-#pragma unroll
-                                for (int jj = 0; jj < QW; jj++)
-                                    v[part * QW + jj] = m.mul(v[part * QW + jj], wv[jj]);
-                            }
-                        }
-                        else if (plain_io)
+                        if (plain_io)
                         {
                             const unsigned lane = map.part(elem_of<WL>(t, 0));
 #pragma unroll
@@ -670,8 +660,6 @@ namespace gpuntt
                 }
 
                 TW tw_cur[TW_PER_ROUND];
-                if constexpr (TW_AHEAD && TW0_LATE && r == 0)
-                    load_twiddles(r_, tw_next);
                 if constexpr (TW_AHEAD)
                 {
 #pragma unroll
@@ -764,7 +752,7 @@ namespace gpuntt
                 // ---- scatter ----------------------------------------------------------
                 if constexpr (r == G::NR - 1)
                 {
-                    constexpr bool PMUL_OK = LAST && !INV && !FST && !WMUL && !EXACT;
+                    constexpr bool PMUL_OK = LAST && !INV && !FST && !EXACT;
                     const T* mul_in = PMUL_OK ? a.mul_in : nullptr;
                     (void) mul_in;
                     if constexpr (LAST && !INV && !EXACT && sizeof(T) == 8)
@@ -806,6 +794,7 @@ namespace gpuntt
                     if constexpr (XP == 2)
                     {
                         // natural-order result -> LDS at its transposed position -> coalesced stores of the 32 x n2 tile
+                        pin_loaded(v);   // (everything read from the e + (e >> 4) layout has arrived)
                         __syncthreads(); // every wave is done with the e + (e >> 4) layout
 #pragma unroll
                         for (int j = 0; j < EPT; j++)
@@ -826,6 +815,7 @@ namespace gpuntt
                     {
                         static_assert(!FST || (CONTIG && K >= 4 && K <= 9), "4-step row runs are 16..512 long");
                         constexpr int RB = TL - K; // log2 rows per tile
+                        pin_loaded(v);
                         __syncthreads();           // all gathers from the e + (e >> 4) layout are done
 #pragma unroll
                         for (int j = 0; j < EPT; j++)
@@ -900,28 +890,7 @@ namespace gpuntt
                     }
                     else if constexpr (DIRECT_IO)
                     {
-                        if constexpr (WMUL && !INV)
-                        {
-                            // W[f mod N] rides on the store; halves of 8 bound the live W pairs
-                            const unsigned lane = map.part(elem_of<WL>(t, 0));
-                            const unsigned long long wb = map.base & nmask;
-#pragma unroll
-                            for (int half = 0; half < 2; half++)
-                            {
-                                TW wv[EPT / 2];
-#pragma unroll
-                                for (int jj = 0; jj < EPT / 2; jj++)
-                                    wv[jj] = (a.w_pairs + (wb + map.part(static_cast<unsigned>(half * (EPT / 2) + jj) << WL)))[lane];
-#pragma unroll
-                                for (int jj = 0; jj < EPT / 2; jj++)
-                                {
-                                    const int j = half * (EPT / 2) + jj;
-                                    (a.out + (map.base + map.part(static_cast<unsigned>(j) << WL)))[lane] =
-                                        lazy::normalize<M::TB>(m, m.mul(v[j], wv[jj]));
-                                }
-                            }
-                        }
-                        else if (full_tile)
+                        if (full_tile)
                         {
                             const unsigned lane = map.part(elem_of<WL>(t, 0));
                             if (PMUL_OK && mul_in != nullptr)
@@ -1084,41 +1053,43 @@ namespace gpuntt
                 qb = md.bit;
                 qm = md.mu;
             }
-            pass_body<T, TLOG, false, INV, CONTIG, K, IN_BOUND, LAST, 0, false, LIM>(a, lds, qv, qb, qm, mi, 0,
+            pass_body<T, TLOG, false, INV, CONTIG, K, IN_BOUND, LAST, 0, LIM>(a, lds, qv, qb, qm, mi, 0,
                                                                                                    0, blk);
         }
 
-        // natural-order 4-step, forward pass 1: STRIDED column transforms (K = log2 n1 top bits of the
-        // N-ring, in place) + W product; block b -> (tile b / batch, poly b % batch)
-        template <typename T, int TLOG, int K>
-        __global__ __launch_bounds__(LTile<TLOG>::NT, (LOcc<TLOG, T>::WAVES)) void fourstep_nat_p1_lazy(LazyArgsT<T> a)
+        // block -> (polynomial, tile of the polynomial) for the transposing row passes of the natural-order 4-step: tile =
+        // (column run << log2 row blocks) | row block.  a.batch > 1 (the host asks for it from 2^20): poly-minor order, so
+        // the polynomials of a batch read each slice of the ring's Merge table back to back (an L2 hit instead of one HBM
+        // read per polynomial: the table is as large as the polynomial).  Plain poly-minor order, not the XCD-aware one of
+        // the Merge passes: with the grouping 2^20 x 64 measured 0.734 against 0.693 ms (2^24 x 64: 11.78 / 11.75 ms)
+        template <typename T>
+        __device__ __forceinline__ void nat_block(const LazyArgsT<T>& a, int tlog, unsigned& poly, unsigned& tile)
         {
-            using G = LGeo<TLOG, false, K>;
-            using M = lazy::Mod<T>;
-            using SCH = PassSched<TLOG, false, false, K, 1, M::LIMIT, M::TB>;
-            constexpr bool NEEDS_LDS = (G::NR > 1) || (SCH::wl_of(0) < 4);
-            __shared__ T lds[NEEDS_LDS ? LTile<TLOG>::LDS_ELEMS : 1];
-            unsigned poly, tile;
-            // plain order here: with the XCD grouping this strided column pass measured 8 % slower at batch 64 (12.58 ->
-            // 13.64 ms for the whole natural-order forward transform, A/B GPUNTT_XCD_ORDER on one box)
-            poly_minor_order(blockIdx.x, static_cast<unsigned>(a.batch), a.n - TLOG, poly, tile, a.flags | F_PLAIN_ORDER);
-            const long long blk = static_cast<long long>((static_cast<unsigned long long>(poly) << (a.n - TLOG)) | tile);
-            pass_body<T, TLOG, false, false, false, K, 1, false, 0, true>(a, lds, a.q, a.q_bit, a.q_mu, 0, 0, 0, blk);
+            const int tiles_log = a.n - tlog;
+            if (a.batch > 1)
+                poly_minor_order(blockIdx.x, static_cast<unsigned>(a.batch), tiles_log, poly, tile, a.flags | F_PLAIN_ORDER);
+            else
+            {
+                poly = blockIdx.x >> tiles_log;
+                tile = blockIdx.x & ((1u << tiles_log) - 1u);
+            }
+            poly = uniform32(poly);
+            tile = uniform32(tile);
         }
 
-        // natural-order 4-step, last forward pass: block b -> (row block fastest, column run, poly);
-        // a.n = log2 n2 (row length and input row stride), a.n2_log = log2 n1 (output row stride)
+        // natural-order 4-step, last forward pass: block b -> nat_block;
+        // a.row_log = log2 n2 (row length and stride of the row-major side), a.n2_log = log2 n1 (row stride of the
+        // column-major side), a.n = log2 N: the stages are the low K stages of the Merge transform of the whole ring, so
+        // the twiddles come from the ring's Merge table and depend on the row as well (4-step in Merge form)
         template <typename T, int TLOG, int K, int IN_BOUND>
         __global__ __launch_bounds__(LTile<TLOG>::NT, (LOcc<TLOG, T>::WAVES)) void fourstep_nat_last_lazy(LazyArgsT<T> a)
         {
             __shared__ T lds[LTile<TLOG>::LDS_ELEMS_FST];
             constexpr int RB = TLOG - K;
-            const unsigned row_blocks = 1u << (a.n2_log - RB);
-            const unsigned runs = 1u << (a.n - K);
-            const unsigned rb = blockIdx.x % row_blocks;
-            const unsigned rest = blockIdx.x / row_blocks;
-            const unsigned seg = rest % runs;
-            const unsigned long long poly = rest / runs;
+            const int rb_log = a.n2_log - RB;
+            unsigned poly, tile;
+            nat_block(a, TLOG, poly, tile);
+            const unsigned rb = tile & ((1u << rb_log) - 1u), seg = tile >> rb_log;
             pass_body<T, TLOG, false, false, true, K, IN_BOUND, true, 2>(a, lds, a.q, a.q_bit, a.q_mu, 0, poly, rb, -1, seg);
         }
 
@@ -1130,30 +1101,11 @@ namespace gpuntt
         {
             __shared__ T lds[LTile<TLOG>::LDS_ELEMS_FST];
             constexpr int RB = TLOG - K;
-            const unsigned row_blocks = 1u << (a.n2_log - RB);
-            const unsigned runs = 1u << (a.n - K);
-            const unsigned rb = blockIdx.x % row_blocks;
-            const unsigned rest = blockIdx.x / row_blocks;
-            const unsigned seg = rest % runs;
-            const unsigned long long poly = rest / runs;
-            pass_body<T, TLOG, false, true, true, K, 1, false, 2>(a, lds, a.q, a.q_bit, a.q_mu, 0, poly, rb, -1, seg);
-        }
-        //   last pass   W^-1 product on the way in, then the n1-point column transforms over the top
-        //               log2 n1 bits of the N-ring with n^-1 folded into the final stage; canonical,
-        //               natural order, in place; block b -> (tile b / batch, poly b % batch)
-        template <typename T, int TLOG, int K>
-        __global__ __launch_bounds__(LTile<TLOG>::NT, (LOcc<TLOG, T>::WAVES)) void fourstep_nat_last_inv_lazy(LazyArgsT<T> a)
-        {
-            using G = LGeo<TLOG, false, K>;
-            using M = lazy::Mod<T>;
-            using SCH = PassSched<TLOG, true, false, K, M::TB, M::LIMIT, M::TB>;
-            constexpr bool NEEDS_LDS = (G::NR > 1) || (SCH::wl_of(0) < 4);
-            __shared__ T lds[NEEDS_LDS ? LTile<TLOG>::LDS_ELEMS : 1];
+            const int rb_log = a.n2_log - RB;
             unsigned poly, tile;
-            // strided pass: plain order (see fourstep_nat_p1_lazy; 2^18 .. 2^20 measured 2-5 % slower with the grouping)
-            poly_minor_order(blockIdx.x, static_cast<unsigned>(a.batch), a.n - TLOG, poly, tile, a.flags | F_PLAIN_ORDER);
-            const long long blk = static_cast<long long>((static_cast<unsigned long long>(poly) << (a.n - TLOG)) | tile);
-            pass_body<T, TLOG, false, true, false, K, M::TB, true, 0, true>(a, lds, a.q, a.q_bit, a.q_mu, 0, 0, 0, blk);
+            nat_block(a, TLOG, poly, tile);
+            const unsigned rb = tile & ((1u << rb_log) - 1u), seg = tile >> rb_log;
+            pass_body<T, TLOG, false, true, true, K, 1, false, 2>(a, lds, a.q, a.q_bit, a.q_mu, 0, poly, rb, -1, seg);
         }
 
         // forward 4-step phase 1 in Merge form (FST = 3); block order as fourstep_phase1_lazy
@@ -1178,7 +1130,7 @@ namespace gpuntt
             const unsigned bx = (a.flags & F_REVERSE) ? (gridDim.x - 1u - blockIdx.x) : blockIdx.x;
             unsigned poly, tile;
             poly_minor_order(bx, static_cast<unsigned>(a.batch), a.poly_shift - TLOG, poly, tile, a.flags | F_PLAIN_ORDER);
-            pass_body<T, TLOG, false, false, true, K, 1, false, 3, false, LIM>(a, lds, qv, qb, qm, 0, uniform32(poly),
+            pass_body<T, TLOG, false, false, true, K, 1, false, 3, LIM>(a, lds, qv, qb, qm, 0, uniform32(poly),
                                                                                  uniform32(tile));
         }
 
@@ -1199,7 +1151,7 @@ namespace gpuntt
                 qb = md.bit;
                 qm = md.mu;
             }
-            pass_body<T, TLOG, false, INV, true, K, 1, true, 0, false, LIM, INV ? 2 : 1>(a, lds, qv, qb, qm, 0, 0, 0,
+            pass_body<T, TLOG, false, INV, true, K, 1, true, 0, LIM, INV ? 2 : 1>(a, lds, qv, qb, qm, 0, 0, 0,
                                                                                        static_cast<long long>(blockIdx.x));
         }
 
@@ -1221,7 +1173,7 @@ namespace gpuntt
             }
             unsigned poly, tile;
             poly_minor_order(blockIdx.x, static_cast<unsigned>(a.batch), a.poly_shift - TLOG, poly, tile, a.flags);
-            pass_body<T, TLOG, false, INV, true, K, 1, false, 1, false, LIM>(a, lds, qv, qb, qm, 0, poly, tile);
+            pass_body<T, TLOG, false, INV, true, K, 1, false, 1, LIM>(a, lds, qv, qb, qm, 0, poly, tile);
         }
 
     } // namespace kern

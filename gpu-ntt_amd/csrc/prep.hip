@@ -225,7 +225,7 @@ namespace gpuntt
         __global__ __launch_bounds__(256) void prep_fourstep(const T* __restrict__ n1_table, const T* __restrict__ n2_table,
                                                              const T* __restrict__ w_table, lazy::Tw<T>* __restrict__ ws_n1,
                                                              lazy::Tw<T>* __restrict__ ws_w, lazy::Tw<T>* __restrict__ ws_n2,
-                                                             int log_n1, int log_n2, int perm2, int w_brev, int fold,
+                                                             int log_n1, int log_n2, int perm2, int fold,
                                                              T q_single, T rinv_single, T ninv_single,
                                                              const Modulus<T>* __restrict__ mods,
                                                              const T* __restrict__ ninv_dev, lazy::Tw<T>* __restrict__ ws_ninv,
@@ -262,15 +262,7 @@ namespace gpuntt
             else if (gid < n1 + n)
             {
                 const unsigned long long e = gid - n1;
-                unsigned long long src = e;
-                if (w_brev)
-                {
-                    const unsigned k = static_cast<unsigned>(e >> log_n2);
-                    const unsigned j = static_cast<unsigned>(e & (n2 - 1));
-                    src = (static_cast<unsigned long long>(__brev(k) >> (32 - log_n1)) << log_n2) +
-                          (__brev(j) >> (32 - log_n2));
-                }
-                const T w = w_table[src];
+                const T w = w_table[e];
                 ws_w[e] = lazy::Tw<T>{w, shoup_quotient_r<T>(w, q, rinv)};
             }
             else if (gid < n1 + n + n2)
@@ -353,22 +345,6 @@ namespace gpuntt
             ws[slot] = lazy::Tw<T>{w, shoup_quotient_r<T>(w, q, rinv)};
         }
 
-        // plain residues -> Shoup pairs with both matrix indices bit-reversed:
-        // dst[k * n2 + j] = pair(src[brev(k, log n1) * n2 + brev(j, log n2)])
-        template <typename T>
-        __global__ __launch_bounds__(256) void prep_pairs_brev(const T* __restrict__ src, lazy::Tw<T>* __restrict__ dst,
-                                                               int log_n1, int log_n2, T q, T rinv)
-        {
-            const unsigned long long gid = blockIdx.x * 256ull + threadIdx.x;
-            if (gid >= (1ull << (log_n1 + log_n2)))
-                return;
-            const unsigned k = static_cast<unsigned>(gid >> log_n2);
-            const unsigned j = static_cast<unsigned>(gid & ((1ull << log_n2) - 1));
-            const unsigned kr = __brev(k) >> (32 - log_n1);
-            const unsigned jr = __brev(j) >> (32 - log_n2);
-            const T w = src[(static_cast<unsigned long long>(kr) << log_n2) + jr];
-            dst[gid] = lazy::Tw<T>{w, shoup_quotient_r<T>(w, q, rinv)};
-        }
     } // namespace kern
 
     namespace host
@@ -586,24 +562,24 @@ namespace gpuntt
         }
         template <typename T>
         void launch_prep_fourstep(const T* n1_table, const T* n2_table, const T* w_table, lazy::Tw<T>* ws_n1,
-                                  lazy::Tw<T>* ws_w, lazy::Tw<T>* ws_n2, int log_n1, int log_n2, int perm2, bool w_brev,
+                                  lazy::Tw<T>* ws_w, lazy::Tw<T>* ws_n2, int log_n1, int log_n2, int perm2,
                                   int fold, T q, T ninv, const Modulus<T>* mods, const T* ninv_dev, lazy::Tw<T>* ws_ninv,
                                   unsigned* go_flag, lazy::NormConst* norm_arr, hipStream_t stream)
         {
             const unsigned long long count = (1ull << log_n1) + (1ull << (log_n1 + log_n2)) + (1ull << log_n2);
             const unsigned grid = static_cast<unsigned>((count + 255) / 256);
             hipLaunchKernelGGL((kern::prep_fourstep<T>), dim3(grid), dim3(256), 0, stream, n1_table, n2_table, w_table,
-                               ws_n1, ws_w, ws_n2, log_n1, log_n2, perm2, w_brev ? 1 : 0, fold, q,
+                               ws_n1, ws_w, ws_n2, log_n1, log_n2, perm2, fold, q,
                                mods ? static_cast<T>(0) : recip_norm_host<T>(q), ninv, mods, ninv_dev, ws_ninv, go_flag,
                                norm_arr);
             GPUNTT_HIP_CHECK(hipGetLastError());
         }
         template void launch_prep_fourstep<uint64_t>(const uint64_t*, const uint64_t*, const uint64_t*, lazy::Tw64*,
-                                                     lazy::Tw64*, lazy::Tw64*, int, int, int, bool, int, uint64_t, uint64_t,
+                                                     lazy::Tw64*, lazy::Tw64*, int, int, int, int, uint64_t, uint64_t,
                                                      const Modulus<uint64_t>*, const uint64_t*, lazy::Tw64*, unsigned*,
                                                      lazy::NormConst*, hipStream_t);
         template void launch_prep_fourstep<uint32_t>(const uint32_t*, const uint32_t*, const uint32_t*, lazy::Tw32*,
-                                                     lazy::Tw32*, lazy::Tw32*, int, int, int, bool, int, uint32_t, uint32_t,
+                                                     lazy::Tw32*, lazy::Tw32*, int, int, int, int, uint32_t, uint32_t,
                                                      const Modulus<uint32_t>*, const uint32_t*, lazy::Tw32*, unsigned*,
                                                      lazy::NormConst*, hipStream_t);
 
@@ -630,17 +606,6 @@ namespace gpuntt
                                                                 const uint32_t*, lazy::Tw32*, unsigned*, lazy::NormConst*,
                                                                 hipStream_t);
 
-        template <typename T>
-        void launch_prep_pairs_brev(const T* src, lazy::Tw<T>* dst, int log_n1, int log_n2, T q, hipStream_t stream)
-        {
-            const unsigned long long count = 1ull << (log_n1 + log_n2);
-            const unsigned grid = static_cast<unsigned>((count + 255) / 256);
-            hipLaunchKernelGGL((kern::prep_pairs_brev<T>), dim3(grid), dim3(256), 0, stream, src, dst, log_n1, log_n2, q,
-                               recip_norm_host<T>(q));
-            GPUNTT_HIP_CHECK(hipGetLastError());
-        }
-        template void launch_prep_pairs_brev<uint64_t>(const uint64_t*, lazy::Tw64*, int, int, uint64_t, hipStream_t);
-        template void launch_prep_pairs_brev<uint32_t>(const uint32_t*, lazy::Tw32*, int, int, uint32_t, hipStream_t);
         template void launch_prep_pairs<uint64_t>(const uint64_t*, lazy::Tw64*, unsigned long long, uint64_t,
                                                   hipStream_t, const Modulus<uint64_t>*);
         template void launch_prep_pairs<uint32_t>(const uint32_t*, lazy::Tw32*, unsigned long long, uint32_t,

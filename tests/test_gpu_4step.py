@@ -332,3 +332,22 @@ def test_fourstep_61_and_62_bit_moduli_on_the_fast_kernels(g, qbits):
                     assert np.array_equal(back, x), ("inverse", qbits, logn)
     finally:
         g.set_option("path", os.environ.get("GPUNTT_PATH", "default"))
+
+
+@pytest.mark.parametrize("bits,logn,batch", [(64, 14, 256), (32, 14, 96), (64, 13, 64)])
+def test_one_launch_rings_every_polynomial_repeatedly(g, bits, logn, batch):
+    """stress form of the test above: EVERY polynomial of the batch is compared, six times over.  Round 3 found the
+    one-launch kernel on the 16384-coefficient tile returning one wrong polynomial in about a thousand: the compiler had
+    sunk LDS reads below the barrier that protects the buffer from the next round's writes (kern::pin_loaded); a sampled
+    check passes that almost every time."""
+    P = O.Port(bits)
+    p4 = g.NTTParameters4Step(logn, bits)
+    oprm = P.fourstep_params(logn)
+    x = P.splitmix(1900 + logn + batch, 0, batch * p4.n, p4.modulus.value)
+    want = np.concatenate([P.fourstep_ntt(x[p * p4.n:(p + 1) * p4.n], oprm) for p in range(batch)])
+    xin = np.concatenate([P.fourstep_intt_first_transpose(want[p * p4.n:(p + 1) * p4.n], oprm) for p in range(batch)])
+    for it in range(6):
+        got = run_fourstep(g, p4, x, batch, inverse=False, rns=bool(it & 1))
+        assert np.array_equal(got, want), ("forward", bits, logn, it)
+        back = run_fourstep(g, p4, xin, batch, inverse=True, rns=bool(it & 1))
+        assert np.array_equal(back, x), ("inverse", bits, logn, it)
