@@ -462,14 +462,26 @@ namespace gpuntt
             if (ws == nullptr)
                 return false; // no device memory for the scratch: the generic kernels need none
             TW* ws_merge = ws + n1; // the W region of the workspace holds the ring's Merge table
+            // rings that fill one tile: ONE launch (contiguous Merge pass, the transposition in LDS); the table then
+            // carries the per-tile permutation of its last three stages
+            const int small_tl = plan.mode != PLAN_NONE
+                                     ? plan.small_tl
+                                     : host::fourstep_small_tile<T>(n_power, false, static_cast<unsigned long long>(batch_size));
             if (plan.mode != PLAN_EXECUTE)
-                host::launch_prep_merge_from_fourstep<T>(n1_table, w_table, ws_merge, log_n1, log_n2, 0, false, false,
+                host::launch_prep_merge_from_fourstep<T>(n1_table, w_table, ws_merge, log_n1, log_n2, small_tl, false, false,
                                                          mod.value, T(0), nullptr, nullptr, nullptr, nullptr, nullptr, stream);
             if (plan.mode == PLAN_PREPARE)
                 return true;
 
             kern::LazyArgsT<T> a{};
             natural_args<T>(a, ws_merge, mod, n_power, log_n1, log_n2, batch_size);
+            if (small_tl != 0)
+            {
+                a.in = in;
+                a.out = out;
+                host::launch_fourstep_small_lazy<T, false>(small_tl, n_power, a, stream, true);
+                return true;
+            }
             a.in = in;
             a.out = in;
             // 1. top log2(n1) stages, canonical in, lazy out
@@ -510,15 +522,26 @@ namespace gpuntt
             if (ws == nullptr)
                 return false; // no device memory for the scratch: the generic kernels need none
             TW* ws_merge = ws + n1;
+            const int small_tl = plan.mode != PLAN_NONE
+                                     ? plan.small_tl
+                                     : host::fourstep_small_tile<T>(n_power, true, static_cast<unsigned long long>(batch_size));
             // inverse Merge table of the ring, N^-1 folded into the single twiddle of the final stage (slot 1)
             if (plan.mode != PLAN_EXECUTE)
-                host::launch_prep_merge_from_fourstep<T>(n1_table, w_table, ws_merge, log_n1, log_n2, 0, true, true, mod.value,
-                                                         ninv, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+                host::launch_prep_merge_from_fourstep<T>(n1_table, w_table, ws_merge, log_n1, log_n2, small_tl, true, true,
+                                                         mod.value, ninv, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
             if (plan.mode == PLAN_PREPARE)
                 return true;
 
             kern::LazyArgsT<T> a{};
             natural_args<T>(a, ws_merge, mod, n_power, log_n1, log_n2, batch_size);
+            if (small_tl != 0)
+            {
+                a.in = in;
+                a.out = out;
+                a.ninv = TW{ninv, host::shoup_host(ninv, mod.value)};
+                host::launch_fourstep_small_lazy<T, true>(small_tl, n_power, a, stream, true);
+                return true;
+            }
             // 1. transposed load + the low stages, row-major `out`, lazy
             a.in = in;
             a.out = out;
@@ -732,8 +755,7 @@ namespace gpuntt
             p->use.mode = PLAN_PREPARE;
             p->use.tile_log =
                 host::lazy_tile_log<T>(l2, p->inverse, static_cast<unsigned long long>(batch_hint) << l1);
-            if (!natural_order)
-                p->use.small_tl = host::fourstep_small_tile<T>(p->n, p->inverse, static_cast<unsigned long long>(batch_hint));
+            p->use.small_tl = host::fourstep_small_tile<T>(p->n, p->inverse, static_cast<unsigned long long>(batch_hint));
             // the eligibility checks of the fast paths decide (modulus width, n^-1 canonical, option "path")
             if (natural_order)
                 p->fast = p->inverse ? fourstep_natural_inverse_lazy<T>(nullptr, nullptr, p->n1_table, p->n2_table,

@@ -125,11 +125,12 @@ namespace gpuntt
             return (n_power >= 12 && n_power == tl) ? tl : 0;
         }
         template <typename T, bool INV>
-        void launch_fourstep_small_lazy(int tile_log, int n, const kern::LazyArgsT<T>& a, hipStream_t stream);
-        extern template void launch_fourstep_small_lazy<uint64_t, false>(int, int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
-        extern template void launch_fourstep_small_lazy<uint64_t, true>(int, int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
-        extern template void launch_fourstep_small_lazy<uint32_t, false>(int, int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
-        extern template void launch_fourstep_small_lazy<uint32_t, true>(int, int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
+        void launch_fourstep_small_lazy(int tile_log, int n, const kern::LazyArgsT<T>& a, hipStream_t stream,
+                                        bool natural = false);
+        extern template void launch_fourstep_small_lazy<uint64_t, false>(int, int, const kern::LazyArgsT<uint64_t>&, hipStream_t, bool);
+        extern template void launch_fourstep_small_lazy<uint64_t, true>(int, int, const kern::LazyArgsT<uint64_t>&, hipStream_t, bool);
+        extern template void launch_fourstep_small_lazy<uint32_t, false>(int, int, const kern::LazyArgsT<uint32_t>&, hipStream_t, bool);
+        extern template void launch_fourstep_small_lazy<uint32_t, true>(int, int, const kern::LazyArgsT<uint32_t>&, hipStream_t, bool);
         // forward 4-step phase 1 in Merge form (kern::fourstep_phase1_merge_lazy), log_n1 in 5..8
         template <typename T, int LIMSEL = 0>
         void launch_fourstep_phase1_merge_lazy(int log_n1, const kern::LazyArgsT<T>& a, hipStream_t stream);

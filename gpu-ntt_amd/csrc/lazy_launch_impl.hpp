@@ -240,9 +240,10 @@ namespace gpuntt
             GPUNTT_HIP_CHECK(hipGetLastError());
         }
 
-        // 4-step transform of a ring that fits one tile: the whole transform in one launch (fourstep_small_lazy)
-        template <typename T, bool INV>
-        void launch_fourstep_small_lazy(int tile_log, int n, const kern::LazyArgsT<T>& a, hipStream_t stream)
+        // 4-step transform of a ring that fits one tile: the whole transform in one launch (fourstep_small_lazy);
+        // natural: the natural-order extension (spectrum side in NTT_4STEP_CPU order)
+        template <typename T, bool INV, bool NAT>
+        void launch_fourstep_small_impl(int tile_log, int n, const kern::LazyArgsT<T>& a, hipStream_t stream)
         {
             const unsigned long long tiles = (a.total + (1ull << tile_log) - 1) >> tile_log;
             if (tiles == 0)
@@ -251,7 +252,8 @@ namespace gpuntt
                 throw std::invalid_argument("batch_size * N too large for one launch");
             const unsigned grid = static_cast<unsigned>(tiles);
 #define GPUNTT_SMALL(TL_, K_)                                                                                          \
-    hipLaunchKernelGGL((kern::fourstep_small_lazy<T, TL_, INV, K_>), dim3(grid), dim3(kern::LTile<TL_>::NT), 0, stream, a)
+    hipLaunchKernelGGL((kern::fourstep_small_lazy<T, TL_, INV, K_, 0, NAT>), dim3(grid), dim3(kern::LTile<TL_>::NT), 0, \
+                       stream, a)
             if constexpr (sizeof(T) == 8)
             {
                 if (tile_log == 12 && n == 12)
@@ -277,6 +279,14 @@ namespace gpuntt
             }
 #undef GPUNTT_SMALL
             GPUNTT_HIP_CHECK(hipGetLastError());
+        }
+        template <typename T, bool INV>
+        void launch_fourstep_small_lazy(int tile_log, int n, const kern::LazyArgsT<T>& a, hipStream_t stream, bool natural)
+        {
+            if (natural)
+                launch_fourstep_small_impl<T, INV, true>(tile_log, n, a, stream);
+            else
+                launch_fourstep_small_impl<T, INV, false>(tile_log, n, a, stream);
         }
 
         // natural-order forward 4-step (fourstep_ntt.hip): the transposing last row pass, k = 7 .. 9 low stages of the

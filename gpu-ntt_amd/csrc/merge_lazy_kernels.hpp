@@ -300,6 +300,10 @@ namespace gpuntt
         // One HBM sweep instead of the reference's two kernels (FourStepForwardCoreT1 + FourStepPartialForwardCore).
         // LDS layout of the transposition: one pad element per n2-row, so the 32 lanes that write one column and the
         // lanes that read along a row both hit distinct banks.
+        //   XP = 3 (natural-order forward): natural-order input, the spectrum leaves transposed -- out[(a << 5) | b] =
+        //                      y[(b << log n2) | a] (NTT_4STEP_CPU::ntt order): wave-local turn into the 64-contiguous
+        //                      window, then through LDS at (o + (o >> 5)) and out as it lies;
+        //   XP = 4 (natural-order inverse): the mirror image on the way in.
         constexpr int XP_L1 = 5;
         template <int K> __device__ __forceinline__ unsigned xp_swap_fwd(unsigned f) // f = (c << 5) | i  ->  (i << l2) | c
         {
@@ -312,6 +316,15 @@ namespace gpuntt
             return xp_swap_fwd<K>(e); // the same bit rotation: low five bits to the top of the ring index
         }
         template <int K> __device__ __forceinline__ unsigned xp_lds(unsigned e) { return e + (e >> (K - XP_L1)); }
+        // natural-order side of XP = 3 / 4: spectrum position e = (b << l2) | a  <->  o = (a << 5) | b; one pad element per
+        // 32-element row of o, so the 64 lanes that hold consecutive a (stride 32 in o) hit distinct banks
+        template <int K> __device__ __forceinline__ unsigned xp_nat_pos(unsigned e)
+        {
+            constexpr unsigned M = (1u << K) - 1u;
+            const unsigned w = e & M;
+            return (e & ~M) | ((w & ((1u << (K - XP_L1)) - 1u)) << XP_L1) | (w >> (K - XP_L1));
+        }
+        __device__ __forceinline__ unsigned xp_nat_lds(unsigned o) { return o + (o >> 5); }
 
         // Block-uniform values that went through a division or a select end up in vector registers, and so does
         // every address derived from them (64-bit VALU adds + v_readfirstlane per access).  Reading them back
@@ -387,9 +400,15 @@ namespace gpuntt
             m.set(q_value, (a.norm_arr != nullptr) ? a.norm_arr[mi] : a.norm);
             const dev::ModCtx<T> em{q_value, q_bit, q_mu};
             const unsigned long long root_base = static_cast<unsigned long long>(mi) << a.n;
-            TW ninv = a.ninv;
+            // (word by word: selecting between the two 8-byte structs as a whole left a dead 16-byte stack slot --
+            // and with it a scratch allocation -- in every 32-bit inverse kernel)
+            T ninv_w = a.ninv.w, ninv_wp = a.ninv.wp;
             if (LAST && INV && a.ninv_arr != nullptr)
-                ninv = a.ninv_arr[mi];
+            {
+                ninv_w = a.ninv_arr[mi].w;
+                ninv_wp = a.ninv_arr[mi].wp;
+            }
+            const TW ninv{ninv_w, ninv_wp};
             const unsigned nmask = (1u << a.n) - 1u;
             const TW* __restrict__ tw_mod = a.tw + root_base;
 
@@ -605,9 +624,34 @@ namespace gpuntt
                         constexpr int IWL = WIO;
                         const unsigned lane = map.part(elem_of<IWL>(t, 0));
                         T tmp[EPT];
+                        if constexpr (XP == 4)
+                        {
+                            // natural-order inverse 4-step: the tile is read as it lies (n2 x 32), staged in LDS and
+                            // picked up at the spectrum positions of the 64-contiguous window
 #pragma unroll
-                        for (int j = 0; j < EPT; j++)
-                            tmp[j] = ld_stream<(IN_BOUND == 1)>((src + (map.base + map.part(static_cast<unsigned>(j) << IWL))) + lane);
+                            for (int half = 0; half < 2; half++)
+                            {
+                                T ld[EPT / 2];
+#pragma unroll
+                                for (int jj = 0; jj < EPT / 2; jj++)
+                                    ld[jj] = ld_stream<true>((src + (map.base + static_cast<unsigned>(NT * (half * (EPT / 2) + jj)))) + t);
+#pragma unroll
+                                for (int jj = 0; jj < EPT / 2; jj++)
+                                    lds[xp_nat_lds(static_cast<unsigned>(t + NT * (half * (EPT / 2) + jj)))] = ld[jj];
+                            }
+                            __syncthreads();
+#pragma unroll
+                            for (int j = 0; j < EPT; j++)
+                                tmp[j] = lds[xp_nat_lds(xp_nat_pos<K>(static_cast<unsigned>(elem_of<IWL>(t, j))))];
+                            pin_loaded(tmp);
+                            __syncthreads(); // the wave-local turn below rewrites the buffer in the e + (e >> 4) layout
+                        }
+                        else
+                        {
+#pragma unroll
+                            for (int j = 0; j < EPT; j++)
+                                tmp[j] = ld_stream<(IN_BOUND == 1)>((src + (map.base + map.part(static_cast<unsigned>(j) << IWL))) + lane);
+                        }
                         T* li = lds + lds_pad(elem_of<IWL>(t, 0));
 #pragma unroll
                         for (int j = 0; j < EPT; j++)
@@ -877,6 +921,24 @@ namespace gpuntt
 #pragma unroll
                         for (int j = 0; j < EPT; j++)
                             v[j] = lo[lds_joff<OWL>(j)];
+                        if constexpr (XP == 3)
+                        {
+                            // natural-order forward 4-step: from the 64-contiguous window (lanes = consecutive a) into LDS
+                            // at the transposed position, then out as it lies (n2 x 32, coalesced)
+                            pin_loaded(v);
+                            __syncthreads(); // every wave is done with the e + (e >> 4) layout
+#pragma unroll
+                            for (int j = 0; j < EPT; j++)
+                                lds[xp_nat_lds(xp_nat_pos<K>(static_cast<unsigned>(elem_of<OWL>(t, j))))] = v[j];
+                            __syncthreads();
+#pragma unroll
+                            for (int j = 0; j < EPT; j++)
+                            {
+                                const unsigned o = static_cast<unsigned>(t + NT * j);
+                                st_stream<true>(a.out + (map.base + o), lds[xp_nat_lds(o)]);
+                            }
+                            return;
+                        }
                         const unsigned lane = map.part(elem_of<OWL>(t, 0));
                         if (PMUL_OK && mul_in != nullptr)
                         {
@@ -1136,7 +1198,9 @@ namespace gpuntt
 
         // 4-step transform of a ring that fits one tile (2^12 .. 2^14): ONE contiguous Merge pass over the whole ring
         // with the transposition of the natural-order side done in LDS (XP above).  a.tw = Merge table of the ring.
-        template <typename T, int TLOG, bool INV, int K, int LIM = 0>
+        // NAT: the natural-order extension (NTT_4STEP_CPU order on the spectrum side, XP = 3 / 4) instead of the
+        // reference layout (XP = 1 / 2)
+        template <typename T, int TLOG, bool INV, int K, int LIM = 0, bool NAT = false>
         __global__ __launch_bounds__(LTile<TLOG>::NT, (LOcc<TLOG, T>::WAVES)) void fourstep_small_lazy(LazyArgsT<T> a)
         {
             static_assert(K >= 12 && K == TLOG, "one-tile 4-step rings fill their tile: 32 x n2 with n2 >= 128");
@@ -1151,8 +1215,8 @@ namespace gpuntt
                 qb = md.bit;
                 qm = md.mu;
             }
-            pass_body<T, TLOG, false, INV, true, K, 1, true, 0, LIM, INV ? 2 : 1>(a, lds, qv, qb, qm, 0, 0, 0,
-                                                                                       static_cast<long long>(blockIdx.x));
+            pass_body<T, TLOG, false, INV, true, K, 1, true, 0, LIM, NAT ? (INV ? 4 : 3) : (INV ? 2 : 1)>(
+                a, lds, qv, qb, qm, 0, 0, 0, static_cast<long long>(blockIdx.x));
         }
 
         // 4-step phase 1 kernel; grid = batch * N / TILE blocks, block b -> (tile b / batch, poly b % batch)

@@ -346,8 +346,23 @@ def test_one_launch_rings_every_polynomial_repeatedly(g, bits, logn, batch):
     x = P.splitmix(1900 + logn + batch, 0, batch * p4.n, p4.modulus.value)
     want = np.concatenate([P.fourstep_ntt(x[p * p4.n:(p + 1) * p4.n], oprm) for p in range(batch)])
     xin = np.concatenate([P.fourstep_intt_first_transpose(want[p * p4.n:(p + 1) * p4.n], oprm) for p in range(batch)])
+    import torch
+    tf = [g.to_device(t) for t in p4.tables["fwd"]]
+    ti = [g.to_device(t) for t in p4.tables["inv"]]
+    cf = g.ntt4step_configuration(n_power=logn, ntt_type=g.FORWARD)
+    ci = g.ntt4step_configuration(n_power=logn, ntt_type=g.INVERSE, mod_inverse=p4.n_inv)
     for it in range(6):
         got = run_fourstep(g, p4, x, batch, inverse=False, rns=bool(it & 1))
         assert np.array_equal(got, want), ("forward", bits, logn, it)
         back = run_fourstep(g, p4, xin, batch, inverse=True, rns=bool(it & 1))
         assert np.array_equal(back, x), ("inverse", bits, logn, it)
+        # the natural-order extension takes the one-launch path for the same rings (transposition on the spectrum side)
+        d_in = g.to_device(x)
+        d_out = torch.zeros_like(d_in)
+        g.GPU_4STEP_NTT_NaturalOrder(d_in, d_out, *tf, p4.modulus, cf, batch)
+        torch.cuda.synchronize()
+        assert np.array_equal(g.to_host(d_out), want), ("natural forward", bits, logn, it)
+        d_back = torch.zeros_like(d_out)
+        g.GPU_4STEP_NTT_NaturalOrder(d_out, d_back, *ti, p4.modulus, ci, batch)
+        torch.cuda.synchronize()
+        assert np.array_equal(g.to_host(d_back), x), ("natural inverse", bits, logn, it)
