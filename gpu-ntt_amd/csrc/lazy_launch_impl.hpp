@@ -165,9 +165,47 @@ namespace gpuntt
 #undef GPUNTT_CASE
                             default: break;
                         }
+                    // strided passes that END a forward transform / BEGIN an inverse one: the PerCoefficient layout
+                    // (rows = coefficients, every stage is a strided stage; default lazy range, 4096-coefficient tiles)
+                    if constexpr (LIMSEL == 0 && TLOG == 12)
+                        if (last)
+                            switch (p.k * 2 + (in_first ? 1 : 0))
+                            {
+#define GPUNTT_CASE(KK)                                                                          \
+    case KK * 2 + 1: GPUNTT_ONE(false, KK, 1, true);                                             \
+    case KK * 2: GPUNTT_ONE(false, KK, LIM, true);
+                                GPUNTT_CASE(1)
+                                GPUNTT_CASE(2)
+                                GPUNTT_CASE(3)
+                                GPUNTT_CASE(4)
+                                GPUNTT_CASE(5)
+                                GPUNTT_CASE(6)
+                                GPUNTT_CASE(7)
+                                GPUNTT_CASE(8)
+#undef GPUNTT_CASE
+                                default: break;
+                            }
                 }
                 else
                 {
+                    if constexpr (LIMSEL == 0 && TLOG == 12)
+                        if (in_first)
+                            switch (p.k * 2 + (last ? 1 : 0))
+                            {
+#define GPUNTT_CASE(KK)                                                                          \
+    case KK * 2 + 1: GPUNTT_ONE(false, KK, 1, true);                                             \
+    case KK * 2: GPUNTT_ONE(false, KK, 1, false);
+                                GPUNTT_CASE(1)
+                                GPUNTT_CASE(2)
+                                GPUNTT_CASE(3)
+                                GPUNTT_CASE(4)
+                                GPUNTT_CASE(5)
+                                GPUNTT_CASE(6)
+                                GPUNTT_CASE(7)
+                                GPUNTT_CASE(8)
+#undef GPUNTT_CASE
+                                default: break;
+                            }
                     if (!in_first)
                         switch (p.k * 2 + (last ? 1 : 0))
                         {

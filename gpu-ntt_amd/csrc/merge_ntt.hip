@@ -191,6 +191,77 @@ namespace gpuntt
         // power-of-two batch the element (c, x) sits at flat index (c << log2 batch) | x, i.e. the
         // columns are exactly a STRIDED tile pass over one virtual ring of N * batch coefficients
         // whose stage bits start at bit log2(batch) -- no transpose, rows stay coalesced.
+        // Fast kernels for the PerCoefficient layout (round 3), single modulus with lazy headroom: the same strided passes
+        // over the virtual ring of N * batch coefficients, run by the lazy-residue strided kernels from the prepared
+        // (Shoup) table of the N-ring -- the twiddle index of a stage only looks at the index bits above it, which
+        // are row (coefficient) bits here, so the N-ring's stage layout serves unchanged; no permuted stages (there
+        // is no contiguous pass).  Returns false when the call must take the generic kernels.
+        template <typename TU, bool INV>
+        bool run_percoefficient_lazy(const void* in, TU* out, const TU* roots, const Modulus<TU>& modulus, TU ninv,
+                                     int n_power, ReductionPolynomial poly, int batch_size, unsigned in_flags,
+                                     unsigned out_flags, hipStream_t stream)
+        {
+            using TW = lazy::Tw<TU>;
+            if (batch_size <= 0 || (batch_size & (batch_size - 1)) != 0)
+                return false; // (the generic path reports the error)
+            if (forced_path() == 1 || modulus.value < 3 || modulus.bit > TU(lazy::Mod<TU>::MAX_BIT) ||
+                (INV && ninv >= modulus.value))
+                return false;
+            int log_w = 0;
+            while ((1 << log_w) < batch_size)
+                log_w++;
+            const int nv = n_power + log_w;
+            if (nv < 12 || nv > 30 || n_power > host::LAZY_MAX_N_POWER)
+                return false;
+            host::Plan pl{};
+            const int np = (n_power + 7) / 8;
+            int top = n_power;
+            for (int i = 0; i < np; i++)
+            {
+                const int k = n_power / np + ((i < n_power % np) ? 1 : 0);
+                top -= k;
+                pl.pass[pl.count++] = host::Pass{false, k, log_w + top};
+                if (12 - k > log_w + top)
+                    return false; // a tile row would be wider than the matrix row: small-matrix kernel (generic)
+            }
+            const size_t entries = (size_t(1) << n_power) + 1;
+            auto* ws = static_cast<TW*>(host::lazy_workspace(stream, sizeof(TW) * entries + 16, true));
+            if (ws == nullptr)
+                return false;
+            const bool neg = (poly == ReductionPolynomial::X_N_plus);
+            host::launch_prep<TU>(roots, ws, nullptr, modulus.value, 1, n_power, neg, 0, nullptr, nullptr, nullptr, nullptr,
+                                  stream, nullptr, INV ? &ninv : nullptr, false);
+            kern::LazyArgsT<TU> a{};
+            a.tw = ws;
+            a.q = modulus.value;
+            a.q_bit = modulus.bit;
+            a.q_mu = modulus.mu;
+            a.ninv = TW{0, 0};
+            if (INV)
+                a.ninv = TW{ninv, host::shoup_host(ninv, modulus.value)};
+            a.norm = lazy::make_norm_const(static_cast<uint64_t>(modulus.value), static_cast<uint64_t>(modulus.bit));
+            a.total = 1ull << nv;
+            a.n = nv;
+            a.poly_shift = nv;
+            a.mod_count = 1;
+            const void* src = in;
+            for (int i = 0; i < pl.count; i++)
+            {
+                const host::Pass& p = INV ? pl.pass[pl.count - 1 - i] : pl.pass[i];
+                kern::LazyArgsT<TU> b = a;
+                b.in = src;
+                b.out = out;
+                b.p_lo = p.p_lo;
+                if (i == 0)
+                    b.flags |= in_flags;
+                if (i == pl.count - 1)
+                    b.flags |= out_flags;
+                host::launch_pass_lazy<TU, INV>(p, 12, i == 0, i == pl.count - 1, b, stream);
+                src = out;
+            }
+            return true;
+        }
+
         template <typename TU, bool INV>
         void run_percoefficient(kern::PassArgs<TU> a, int n_power, int batch_size, unsigned in_flags,
                                 unsigned out_flags, hipStream_t stream)
@@ -272,6 +343,11 @@ namespace gpuntt
         const unsigned in_flags = std::is_signed<T>::value ? kern::F_SIGNED_IN : 0u;
         if (cfg.ntt_layout == PerCoefficient)
         {
+            if (run_percoefficient_lazy<TU, false>(device_in, device_out, root_of_unity_table, modulus, TU(0), cfg.n_power,
+                                                   cfg.reduction_poly, batch_size, in_flags, 0u, cfg.stream))
+                return;
+            if (forced_path() == 3)
+                throw std::invalid_argument("fast path unavailable for this call (path = fast-strict)");
             kern::PassArgs<TU> a = base_args<TU>(device_in, device_out, root_of_unity_table, cfg.n_power,
                                                  cfg.reduction_poly, batch_size);
             a.mod = modulus;
@@ -306,6 +382,12 @@ namespace gpuntt
             kern::F_SCALE | (std::is_signed<T>::value ? kern::F_CENTERED : 0u);
         if (cfg.ntt_layout == PerCoefficient)
         {
+            if (run_percoefficient_lazy<TU, true>(device_in, reinterpret_cast<TU*>(device_out), root_of_unity_table, modulus,
+                                                  cfg.mod_inverse, cfg.n_power, cfg.reduction_poly, batch_size, 0u, out_flags,
+                                                  cfg.stream))
+                return;
+            if (forced_path() == 3)
+                throw std::invalid_argument("fast path unavailable for this call (path = fast-strict)");
             kern::PassArgs<TU> a =
                 base_args<TU>(device_in, reinterpret_cast<TU*>(device_out), root_of_unity_table,
                               cfg.n_power, cfg.reduction_poly, batch_size);

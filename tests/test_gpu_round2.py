@@ -796,3 +796,34 @@ def test_scratch_exhaustion_falls_back_to_the_generic_kernels(g):
     finally:
         g.set_option("path", os.environ.get("GPUNTT_PATH", "default"))
         g.set_option("no_scratch", 0)
+
+
+@pytest.mark.parametrize("bits", [32, 64])
+def test_percoefficient_on_the_fast_kernels(g, bits):
+    """PerCoefficient layout (reference ForwardCoreTranspose / InverseCoreTranspose, ntt.cu:1554-2074), single modulus:
+    since round 3 the strided lazy-residue kernels run it from the prepared table of the N-ring (4-7x the Barrett
+    kernels: 2^9 x 2^17 u64 1.59 -> 0.37 ms).  Under path = fast-strict a call that fell back would throw.  Column x of
+    the output == NTTCPU::ntt(column x of the input), both polynomials, both directions, one and two strided passes."""
+    import torch
+    g.set_option("path", "fast-strict")
+    try:
+        for logn, w, poly in ((9, 4096, O.X_N_plus), (9, 512, O.X_N_minus), (8, 8192, O.X_N_plus), (5, 65536, O.X_N_minus),
+                              (6, 1024, O.X_N_plus), (3, 16384, O.X_N_minus)):
+            c = MergeCase(g, bits, logn, poly)
+            n = c.n
+            cols = c.random(w, 9900 + logn + w).reshape(w, n)
+            mat = np.ascontiguousarray(cols.T)
+            want_f = np.ascontiguousarray(c.P.merge_ntt(cols.reshape(-1), c.oprm).reshape(w, n).T)
+            cfg = g.ntt_configuration(n_power=logn, ntt_layout=g.PerCoefficient, reduction_poly=poly)
+            d = g.to_device(mat.reshape(-1))
+            o = torch.zeros_like(d)
+            g.GPU_NTT(d, o, c.fwd_dev, c.prm.modulus, cfg, w)
+            torch.cuda.synchronize()
+            assert np.array_equal(g.to_host(o).reshape(n, w), want_f), ("fwd", bits, logn, w)
+            icfg = g.ntt_configuration(n_power=logn, ntt_type=g.INVERSE, ntt_layout=g.PerCoefficient,
+                                       reduction_poly=poly, mod_inverse=c.prm.n_inv)
+            g.GPU_INTT_Inplace(o, c.inv_dev, c.prm.modulus, icfg, w)
+            torch.cuda.synchronize()
+            assert np.array_equal(g.to_host(o).reshape(n, w), mat), ("inv", bits, logn, w)
+    finally:
+        g.set_option("path", os.environ.get("GPUNTT_PATH", "default"))
