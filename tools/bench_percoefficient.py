@@ -1,3 +1,5 @@
+"""PerCoefficient layout: the Barrett (generic) kernels against the fast strided kernels on the same call, bit-identical
+outputs required:   python tools/bench_percoefficient.py"""
 import os, sys, time
 import numpy as np
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
