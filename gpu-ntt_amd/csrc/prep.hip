@@ -152,11 +152,12 @@ namespace gpuntt
             if (perm_tile_log > 0 && P <= 2)
             {
                 // [tile][k][thread] layout of the stages whose twiddles differ per thread
-                const unsigned nt = 1u << (perm_tile_log - 4); // threads per tile (16 coefficients each)
-                const unsigned rp = 16u >> (P + 1);            // twiddles per thread
-                const unsigned tile = i / (rp * nt), rem = i % (rp * nt);
-                const unsigned kk = rem / nt, t = rem % nt;
-                i = tile * (rp * nt) + t * rp + kk;
+                // (powers of two throughout: shifts and masks, no integer division)
+                const int nt_log = perm_tile_log - 4; // threads per tile (16 coefficients each)
+                const int rp_log = 3 - P;             // twiddles per thread = 16 >> (P + 1)
+                const unsigned tile = i >> (rp_log + nt_log), rem = i & ((1u << (rp_log + nt_log)) - 1u);
+                const unsigned kk = rem >> nt_log, t = rem & ((1u << nt_log) - 1u);
+                i = (tile << (rp_log + nt_log)) + (t << rp_log) + kk;
             }
             const unsigned src = negacyclic ? ((1u << S) + i) : i;
             T w = roots[(static_cast<unsigned long long>(prime) << n) + src];
@@ -209,11 +210,11 @@ namespace gpuntt
             const int P = n - 1 - S;
             if (perm_tile_log > 0 && P <= 2)
             {
-                const unsigned nt = 1u << (perm_tile_log - 4);
-                const unsigned rp = 16u >> (P + 1);
-                const unsigned tile = i / (rp * nt), rem = i % (rp * nt);
-                const unsigned kk = rem / nt, t = rem % nt;
-                i = tile * (rp * nt) + t * rp + kk;
+                const int nt_log = perm_tile_log - 4;
+                const int rp_log = 3 - P;
+                const unsigned tile = i >> (rp_log + nt_log), rem = i & ((1u << (rp_log + nt_log)) - 1u);
+                const unsigned kk = rem >> nt_log, t = rem & ((1u << nt_log) - 1u);
+                i = (tile << (rp_log + nt_log)) + (t << rp_log) + kk;
             }
             T w = roots[i];
             if (fold && slot == 1)
@@ -325,11 +326,11 @@ namespace gpuntt
             const int P = n - 1 - S;
             if (perm_tile_log > 0 && P <= 2)
             {
-                const unsigned nt = 1u << (perm_tile_log - 4);
-                const unsigned rp = 16u >> (P + 1);
-                const unsigned tile = i / (rp * nt), rem = i % (rp * nt);
-                const unsigned kk = rem / nt, t = rem % nt;
-                i = tile * (rp * nt) + t * rp + kk;
+                const int nt_log = perm_tile_log - 4;
+                const int rp_log = 3 - P;
+                const unsigned tile = i >> (rp_log + nt_log), rem = i & ((1u << (rp_log + nt_log)) - 1u);
+                const unsigned kk = rem >> nt_log, t = rem & ((1u << nt_log) - 1u);
+                i = (tile << (rp_log + nt_log)) + (t << rp_log) + kk;
             }
             const unsigned k = (n > 1) ? (__brev(i) >> (33 - n)) : 0u; // brev(i, n - 1)
             const unsigned n2 = 1u << log_n2;
