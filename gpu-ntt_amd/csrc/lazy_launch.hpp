@@ -115,12 +115,15 @@ namespace gpuntt
         extern template void launch_fourstep_phase1_lazy<uint32_t, true>(int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
 
         // 4-step transform of a ring that fits one tile in one launch: 64-bit 2^12 (tile 12), 2^13 (tile 13), 2^14 forward
-        // (tile 14); 32-bit 2^12 (tile 12), 2^14 (tile 14).  a.tw = Merge table of the ring
+        // (tile 14); 32-bit 2^12 (tile 12), 2^13 (tile 13), 2^14 (tile 14).  a.tw = Merge table of the ring
         // (launch_prep_merge_from_fourstep).  fourstep_small_tile: the tile such a call runs on, 0 = ring too large
         template <typename T> inline int fourstep_small_tile(int n_power, bool inverse, unsigned long long polys)
         {
             // the ring must fill the tile: the 32-bit ring 2^13 would share a 16384-coefficient tile between two
-            // polynomials, and that kernel spills at the tile's 64-VGPR budget (it takes the two-sweep Merge form)
+            // polynomials, and that kernel spills at the tile's 64-VGPR budget -- it gets a 8192-coefficient tile of
+            // its own, which no Merge plan uses
+            if (sizeof(T) == 4 && n_power == 13)
+                return 13;
             const int tl = lazy_tile_log<T>(n_power, inverse, polys);
             return (n_power >= 12 && n_power == tl) ? tl : 0;
         }

@@ -310,6 +310,8 @@ namespace gpuntt
             {
                 if (tile_log == 12 && n == 12)
                     GPUNTT_SMALL(12, 12);
+                else if (tile_log == 13 && n == 13)
+                    GPUNTT_SMALL(13, 13);
                 else if (tile_log == 14 && n == 14)
                     GPUNTT_SMALL(14, 14);
                 else

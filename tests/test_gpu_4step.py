@@ -267,8 +267,8 @@ def test_fourstep_rings_that_fit_one_tile(g, bits, logn, batch):
     """2^12 .. 2^14: GPU_4STEP_NTT is the Merge transform of the ring with the natural-order side transposed, and
     runs as ONE launch (kern::fourstep_small_lazy: Merge table rebuilt from the 4-step tables, transposition in LDS)
     where the ring fits a tile -- 64-bit 2^12 / 2^13, 2^14 forward from 256 polynomials (smaller batches and the
-    inverse keep the two-phase path), 32-bit 2^12 .. 2^14 incl. tiles that hold two polynomials and a ragged last
-    tile.  Both overloads, both directions, against NTT_4STEP_CPU."""
+    inverse keep the two-phase path), 32-bit 2^12 .. 2^14 (2^13 on a 8192-coefficient tile no Merge plan uses) incl.
+    a ragged last tile.  Both overloads, both directions, against NTT_4STEP_CPU."""
     P = O.Port(bits)
     p4 = g.NTTParameters4Step(logn, bits)
     oprm = P.fourstep_params(logn)
@@ -334,7 +334,7 @@ def test_fourstep_61_and_62_bit_moduli_on_the_fast_kernels(g, qbits):
         g.set_option("path", os.environ.get("GPUNTT_PATH", "default"))
 
 
-@pytest.mark.parametrize("bits,logn,batch", [(64, 14, 256), (32, 14, 96), (64, 13, 64)])
+@pytest.mark.parametrize("bits,logn,batch", [(64, 14, 256), (32, 14, 96), (64, 13, 64), (32, 13, 96)])
 def test_one_launch_rings_every_polynomial_repeatedly(g, bits, logn, batch):
     """stress form of the test above: EVERY polynomial of the batch is compared, six times over.  Round 3 found the
     one-launch kernel on the 16384-coefficient tile returning one wrong polynomial in about a thousand: the compiler had

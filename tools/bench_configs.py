@@ -2,7 +2,7 @@
 """Secondary benchmark lines (not the driver's bench.py contract): every BASELINE.json config
 and the log2N sweep, one JSON object per line, for DESIGN.md / profiles/.
 
-    python tools/bench_configs.py [--what configs|sweep|all] [--iters 20] > profiles/configs_rNN.jsonl
+    python tools/bench_configs.py [--what configs|sweep|sweep32|sweep64|4step32|all] [--iters 20] > profiles/configs_rNN.jsonl
 
 Each line: {"name", "dtype", "algo", "log2N", "batch", "ms", "ntt_per_s", "alg_GBps", "frac_of_8TBps",
             "checked"} -- `checked` = a sampled polynomial matched the oracle bit-for-bit.
@@ -228,6 +228,9 @@ def main():
             batch = max(1, 1 << (26 - logn))
             merge_case(g, bits, logn, batch, g.X_N_minus, max(3, args.iters // 2), "sweep-merge")
             merge_case(g, bits, logn, batch, g.X_N_minus, max(3, args.iters // 2), "sweep-merge-inv", inverse=True)
+    if args.what == "4step32":  # the 32-bit one-launch rings and their neighbours
+        for logn in range(12, 17):
+            fourstep_case(g, 32, logn, 1 << (26 - logn), max(3, args.iters // 2), "sweep-4step-u32")
     if args.what in ("sweep", "all"):
         for bits in (64, 32):
             for logn in range(12, 25):
