@@ -161,6 +161,8 @@ namespace gpuntt
             lazy::Tw<T>* ws = nullptr;
             int tile_log = 0; // row-pass tile the n2 table was laid out for (reference-layout plans)
             int small_tl = 0; // reference-layout plans of one-tile rings: tile of the one-launch path (0: two-phase path)
+            int first_k = 0;  // forward reference-layout plans: stages of the first Merge pass (the one that reads the
+                              // transposed input); tile_log is then the tile of the RING's Merge plan
         };
 
         // fast path: single modulus with lazy headroom.  Workspace layout (Shoup pairs):
@@ -265,74 +267,77 @@ namespace gpuntt
                     host::launch_fourstep_small_lazy<T, INV>(small_tl, n_power, s, stream);
                 return true;
             }
-            // Forward, rings larger than a tile: Merge form.  Phase 1 does the top log2 n1 stages on the n1-long rows of
-            // the input and stores transposed WITHOUT the W product (lazy); the remaining log2 n2 stages are ordinary
-            // Merge passes over the natural-order layout with the ring's Merge table -- the W matrix is never streamed,
-            // one multiplication and one normalisation per coefficient less than the two-phase form.
+            // Forward, rings larger than a tile: the Merge plan of the ring itself (GPU_4STEP_NTT(x^T) == MergeNTT_w(x)),
+            // its first strided pass reading the transposed input (kern::fourstep_first_lazy): in[(c << l1) | r] holds the
+            // tile's columns x n1 rows as one run per value of the stage bits below r, so a first pass of k1 >= l1 stages
+            // gathers 2^(k1 - l1) coalesced runs, and everything behind it is the Merge transform as it stands with the
+            // ring's Merge table (2^17 .. 2^22: the same two sweeps) -- the W matrix is never streamed.
             if constexpr (!INV)
             {
-                // tile of the contiguous row pass: the one a Merge transform of length n2 over these rows would take
-                // (8192 / 16384-coefficient tiles keep n2 = 2^13 / 2^14 at ONE row sweep); it fixes the table layout
-                const int tlr = (log_n2 >= tl2 || (sizeof(T) == 4 && tl2 == 14 && log_n2 == 13)) ? tl2 : 12;
-                if (plan.mode != PLAN_EXECUTE)
-                    host::launch_prep_merge_from_fourstep<T>(n1_table, w_table, ws_w, log_n1, log_n2, tlr, false, false,
-                                                             mod.value, T(0), mods_dev, nullptr, nullptr, go_flag, norm_arr,
-                                                             stream);
-                if (go_flag_out != nullptr)
-                    *go_flag_out = go_flag;
-                if (plan.mode == PLAN_PREPARE)
-                    return true;
-                kern::LazyArgsT<T> f{};
-                f.in = in;
-                f.out = out;
-                f.tw = ws_w;
-                f.mods = mods_dev;
-                f.q = mod.value;
-                f.q_bit = mod.bit;
-                f.q_mu = mod.mu;
-                f.ninv = TW{0, 0};
-                f.go_flag = go_flag;
-                f.norm = lazy::make_norm_const(static_cast<uint64_t>(mod.value), static_cast<uint64_t>(mod.bit));
-                f.norm_arr = norm_arr;
-                f.n2_log = log_n2;
-                f.batch = batch_size;
-                f.total = static_cast<unsigned long long>(batch_size) << n_power;
-                f.n = log_n1;
-                f.poly_shift = n_power;
-                f.mod_count = 1;
-                f.flags = host::lazy_order_flags();
                 {
-                    // consecutive sweeps walk the batch in opposite directions (Infinity Cache reuse of the hand-off): the
-                    // row passes alternate with the LAST one forwards, so phase 1 runs backwards when their number is odd
-                    const host::Plan rp = host::make_plan_tl(log_n2, tlr, tlr == 12 ? host::lazy_contig_k(log_n2) : tlr);
-                    if ((rp.count & 1) != 0 && host::lazy_reverse_passes())
-                        f.flags |= kern::F_REVERSE;
-                }
-                if constexpr (sizeof(T) == 8)
-                {
-                    if (lim == 8)
-                        host::launch_fourstep_lim<false, 8>(1, log_n1, f, stream);
-                    else if (lim == 4)
-                        host::launch_fourstep_lim<false, 4>(1, log_n1, f, stream);
+                    const int tlf = lim != 0 ? 12
+                                    : plan.mode != PLAN_NONE
+                                        ? plan.tile_log
+                                        : host::lazy_tile_log<T>(n_power, false, static_cast<unsigned long long>(batch_size));
+                    const int k1 = plan.mode != PLAN_NONE ? plan.first_k : host::fourstep_first_k(n_power, log_n1, tlf);
+                    if (plan.mode != PLAN_EXECUTE)
+                        host::launch_prep_merge_from_fourstep<T>(n1_table, w_table, ws_w, log_n1, log_n2, tlf, false, false,
+                                                                 mod.value, T(0), mods_dev, nullptr, nullptr, go_flag,
+                                                                 norm_arr, stream);
+                    if (go_flag_out != nullptr)
+                        *go_flag_out = go_flag;
+                    if (plan.mode == PLAN_PREPARE)
+                        return true;
+                    kern::LazyArgsT<T> f{};
+                    f.in = in;
+                    f.out = out;
+                    f.tw = ws_w;
+                    f.mods = mods_dev;
+                    f.q = mod.value;
+                    f.q_bit = mod.bit;
+                    f.q_mu = mod.mu;
+                    f.ninv = TW{0, 0};
+                    f.go_flag = go_flag;
+                    f.norm = lazy::make_norm_const(static_cast<uint64_t>(mod.value), static_cast<uint64_t>(mod.bit));
+                    f.norm_arr = norm_arr;
+                    f.n2_log = log_n1; // row stride of the transposed side
+                    f.total = static_cast<unsigned long long>(batch_size) << n_power;
+                    f.n = n_power;
+                    f.p_lo = n_power - k1;
+                    f.poly_shift = n_power;
+                    f.mod_count = 1;
+                    f.flags = host::lazy_order_flags();
+                    {
+                        // consecutive sweeps walk the batch in opposite directions, the LAST one forwards
+                        const int pn = n_power - k1;
+                        const host::Plan rp = host::make_plan_tl(pn, tlf, tlf == 12 ? host::lazy_contig_k(pn) : tlf);
+                        if ((rp.count & 1) != 0 && host::lazy_reverse_passes())
+                            f.flags |= kern::F_REVERSE;
+                    }
+                    if constexpr (sizeof(T) == 8)
+                    {
+                        if (lim == 8)
+                            host::launch_fourstep_lim<false, 8>(1, k1, f, stream);
+                        else if (lim == 4)
+                            host::launch_fourstep_lim<false, 4>(1, k1, f, stream);
+                        else
+                            host::launch_fourstep_first_lazy<T>(k1, f, stream);
+                    }
                     else
-                        host::launch_fourstep_phase1_merge_lazy<T>(log_n1, f, stream);
+                        host::launch_fourstep_first_lazy<T>(k1, f, stream);
+                    kern::LazyArgsT<T> r = f;
+                    r.in = out;
+                    r.flags = host::lazy_order_flags();
+                    r.lim = lim;
+                    if constexpr (sizeof(T) == 8)
+                        if (lim == 0 && mods_dev == nullptr && host::lazy_lim31_enabled() && host::lazy_lim31_modulus(mod.value))
+                            r.lim = 31;
+                    if constexpr (sizeof(T) == 4)
+                        if (mods_dev == nullptr && host::lazy_lim31_enabled() && host::lazy_wide_modulus32(mod.value))
+                            r.lim = 8;
+                    host::run_transform_lazy<T, false>(r, 0u, 0u, stream, tlf, n_power - k1);
+                    return true;
                 }
-                else
-                    host::launch_fourstep_phase1_merge_lazy<T>(log_n1, f, stream);
-                kern::LazyArgsT<T> r = f;
-                r.in = out;
-                r.n = n_power;
-                r.batch = 0;
-                r.flags = host::lazy_order_flags();
-                r.lim = lim;
-                if constexpr (sizeof(T) == 8)
-                    if (lim == 0 && mods_dev == nullptr && host::lazy_lim31_enabled() && host::lazy_lim31_modulus(mod.value))
-                        r.lim = 31;
-                if constexpr (sizeof(T) == 4)
-                    if (mods_dev == nullptr && host::lazy_lim31_enabled() && host::lazy_wide_modulus32(mod.value))
-                        r.lim = 8;
-                host::run_transform_lazy<T, false>(r, 0u, 0u, stream, tlr, log_n2);
-                return true;
             }
             // one preparation launch; inverse: n^-1 rides on the last row stage (fold = 2)
             if (plan.mode != PLAN_EXECUTE)
@@ -755,6 +760,14 @@ namespace gpuntt
             p->use.mode = PLAN_PREPARE;
             p->use.tile_log =
                 host::lazy_tile_log<T>(l2, p->inverse, static_cast<unsigned long long>(batch_hint) << l1);
+            if (!p->inverse && !natural_order)
+            {
+                // forward: the Merge plan of the ring, first pass with the transposed gather
+                p->use.tile_log = host::modulus_lim<T>(modulus) != 0
+                                      ? 12
+                                      : host::lazy_tile_log<T>(p->n, false, static_cast<unsigned long long>(batch_hint));
+                p->use.first_k = host::fourstep_first_k(p->n, l1, p->use.tile_log);
+            }
             p->use.small_tl = host::fourstep_small_tile<T>(p->n, p->inverse, static_cast<unsigned long long>(batch_hint));
             // the eligibility checks of the fast paths decide (modulus width, n^-1 canonical, option "path")
             if (natural_order)

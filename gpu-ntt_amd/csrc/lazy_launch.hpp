@@ -108,7 +108,7 @@ namespace gpuntt
                                                          uint32_t, hipStream_t, const Modulus<uint32_t>*);
 
         // 4-step phase 1 with the W product (fused n1-point transform + W multiply + transposed store), log_n1 in 5..8:
-        // the inverse direction (the forward one runs in Merge form, launch_fourstep_phase1_merge_lazy)
+        // the inverse direction (the forward one is the ring's Merge plan, launch_fourstep_first_lazy)
         template <typename T, bool INV, int LIMSEL = 0>
         void launch_fourstep_phase1_lazy(int log_n1, const kern::LazyArgsT<T>& a, hipStream_t stream);
         extern template void launch_fourstep_phase1_lazy<uint64_t, true>(int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
@@ -134,11 +134,12 @@ namespace gpuntt
         extern template void launch_fourstep_small_lazy<uint64_t, true>(int, int, const kern::LazyArgsT<uint64_t>&, hipStream_t, bool);
         extern template void launch_fourstep_small_lazy<uint32_t, false>(int, int, const kern::LazyArgsT<uint32_t>&, hipStream_t, bool);
         extern template void launch_fourstep_small_lazy<uint32_t, true>(int, int, const kern::LazyArgsT<uint32_t>&, hipStream_t, bool);
-        // forward 4-step phase 1 in Merge form (kern::fourstep_phase1_merge_lazy), log_n1 in 5..8
+        // forward 4-step, first pass of the ring's Merge plan reading the transposed input (kern::fourstep_first_lazy):
+        // k = 5 .. 8 stages, k >= log2 n1 = a.n2_log
         template <typename T, int LIMSEL = 0>
-        void launch_fourstep_phase1_merge_lazy(int log_n1, const kern::LazyArgsT<T>& a, hipStream_t stream);
-        extern template void launch_fourstep_phase1_merge_lazy<uint64_t>(int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
-        extern template void launch_fourstep_phase1_merge_lazy<uint32_t>(int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
+        void launch_fourstep_first_lazy(int k, const kern::LazyArgsT<T>& a, hipStream_t stream);
+        extern template void launch_fourstep_first_lazy<uint64_t>(int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
+        extern template void launch_fourstep_first_lazy<uint32_t>(int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
         // natural-order 4-step (extension) in Merge form: strided Merge passes + one transposing row pass
         template <typename T>
         void launch_fourstep_nat_last_lazy(int k, const kern::LazyArgsT<T>& a, hipStream_t stream);
@@ -223,6 +224,15 @@ namespace gpuntt
         int lazy_contig_k(int n);
 
         bool lazy_reverse_passes();
+        // forward 4-step in Merge form: stages of the first pass (the one that reads the transposed input) -- the first
+        // strided pass of the ring's Merge plan on tile `tl`, widened to log2 n1 where that is larger (5 .. 8)
+        inline int fourstep_first_k(int n_power, int log_n1, int tl)
+        {
+            const Plan pl = make_plan_tl(n_power, tl, tl == 12 ? lazy_contig_k(n_power) : tl);
+            const int k0 = (pl.count >= 2 && !pl.pass[0].contig) ? pl.pass[0].k : 0;
+            const int k = k0 > log_n1 ? k0 : log_n1;
+            return k > 8 ? 8 : k;
+        }
 
         // in_first: the pass reads canonical input (first pass of the transform)
         template <typename T, bool INV>

@@ -254,18 +254,21 @@ namespace gpuntt
             GPUNTT_HIP_CHECK(hipGetLastError());
         }
 
-        // forward 4-step phase 1 in Merge form (no W product, lazy hand-over), log_n1 in 5..8
+        // forward 4-step: first strided pass of the Merge plan with the transposed gather, k stages
         template <typename T, int LIMSEL>
-        void launch_fourstep_phase1_merge_lazy(int log_n1, const kern::LazyArgsT<T>& a, hipStream_t stream)
+        void launch_fourstep_first_lazy(int k, const kern::LazyArgsT<T>& a, hipStream_t stream)
         {
-            constexpr int TLOG = 12;
-            const unsigned grid = static_cast<unsigned>(a.total >> TLOG);
-            switch (log_n1)
+            const unsigned long long tiles = a.total >> 12;
+            if (tiles == 0)
+                return;
+            if (tiles > 0x7fffffffull)
+                throw std::invalid_argument("batch_size * N too large for one launch");
+            const unsigned grid = static_cast<unsigned>(tiles);
+            switch (k)
             {
-#define GPUNTT_CASE(KK)                                                                          \
-    case KK:                                                                                      \
-        hipLaunchKernelGGL((kern::fourstep_phase1_merge_lazy<T, TLOG, KK, LIMSEL>), dim3(grid),   \
-                           dim3(kern::LTile<TLOG>::NT), 0, stream, a);                            \
+#define GPUNTT_CASE(KK)                                                                                               \
+    case KK:                                                                                                           \
+        hipLaunchKernelGGL((kern::fourstep_first_lazy<T, KK, LIMSEL>), dim3(grid), dim3(kern::LTile<12>::NT), 0, stream, a); \
         break;
                 GPUNTT_CASE(5)
                 GPUNTT_CASE(6)
@@ -273,7 +276,7 @@ namespace gpuntt
                 GPUNTT_CASE(8)
 #undef GPUNTT_CASE
                 default:
-                    throw std::invalid_argument("internal: bad 4-step n1");
+                    throw std::invalid_argument("internal: bad 4-step first pass");
             }
             GPUNTT_HIP_CHECK(hipGetLastError());
         }
@@ -375,7 +378,7 @@ namespace gpuntt
             GPUNTT_HIP_CHECK(hipGetLastError());
         }
         // 4-step kernels for 64-bit words with a 61- / 62-bit modulus (LIMIT = 8 / 4): what = 0 phase 1 with the W
-        // product (inverse), 1 phase 1 in Merge form (forward), 2 the one-launch 2^12 ring
+        // product (inverse), 1 first pass of the forward Merge plan (log_n1 = its stage count), 2 the one-launch 2^12 ring
         template <bool INV, int LIMSEL>
         void launch_fourstep_lim(int what, int log_n1, const kern::LazyArgsT<uint64_t>& a, hipStream_t stream)
         {
@@ -384,7 +387,7 @@ namespace gpuntt
                     return launch_fourstep_phase1_lazy<uint64_t, true, LIMSEL>(log_n1, a, stream);
             if constexpr (!INV)
                 if (what == 1)
-                    return launch_fourstep_phase1_merge_lazy<uint64_t, LIMSEL>(log_n1, a, stream);
+                    return launch_fourstep_first_lazy<uint64_t, LIMSEL>(log_n1, a, stream);
             if (what == 2)
             {
                 const unsigned long long tiles = a.total >> 12;

@@ -254,11 +254,8 @@ namespace gpuntt
         // over the rows (length n1 = 2^K) of the n2 x n1 input, stored transposed into the n1 x n2
         // output with the W multiply fused; output canonical.  Blocks are ordered poly-minor so the
         // polynomials of a batch that share a slice of W run back to back (W stays in L2).
-        // FST = 3, forward 4-step in Merge form (rings larger than a tile): the same pass over the n1-long rows and the
-        // same transposed store, but NO W product and no normalisation -- the top log2 n1 stages of the Merge transform
-        // of the whole ring, handed over lazy to Merge passes that run the remaining stages from the ring's Merge table
-        // (prep.hip: prep_merge_from_fourstep).  One multiplication, one 16-byte W load and one normalisation per
-        // coefficient less than the reference's FourStepForwardCoreT* + W form.
+        // (inverse direction only: the forward 4-step is the ring's Merge plan with a transposed gather in its first
+        // strided pass, XP = 5 below / fourstep_first_lazy -- no W product, no W stream.)
         // FST = 2, natural-order 4-step, last forward pass: CONTIG stages on the same 2^K-column range
         // of 2^(TL-K) consecutive rows (lazy input from the strided row passes, or canonical input
         // when the rows fit one pass), canonical output stored transposed (no W product).
@@ -595,6 +592,48 @@ namespace gpuntt
                         pin_loaded(v);
                         __syncthreads(); // the exchanges below reuse the buffer in the e + (e >> 4) layout
                     }
+                    else if constexpr (XP == 5)
+                    {
+                        // forward 4-step, first pass in Merge form: an ordinary strided first pass of the ring's Merge
+                        // plan -- the tile is 2^K rows x 2^L columns of the natural layout, rows = the top K index
+                        // bits (r, c_top) with r the n1-index -- whose INPUT lies transposed: in[(c << l1) | r].
+                        // For a fixed c_top the tile's 2^L columns x n1 rows are ONE run of 2^(L + l1) words there,
+                        // so the tile is read as 2^(K - l1) such runs (coalesced), dropped into LDS at its natural
+                        // in-tile position (one pad word per r: the lanes of a run walk r first) and picked up in
+                        // the register window of the first round.  a.n2_log = log2 n1.
+                        static_assert(!CONTIG && !INV && DIRECT_IO && TL == 12 && K >= 5 && K <= 8, "strided forward first pass");
+                        constexpr int L = TL - K;
+                        const int l1 = a.n2_log;
+                        const int ch = TL - (K - l1); // log2 of a run: L + l1, 9 .. 12
+                        const unsigned long long in_base =
+                            ((map.base >> a.n) << a.n) + (static_cast<unsigned long long>((static_cast<unsigned>(map.base) & nmask) >> L) << ch);
+                        const unsigned rr = static_cast<unsigned>(t) & ((1u << l1) - 1u);
+                        const unsigned lds_t = (rr << (TL - l1)) + rr;
+                        T tmp[EPT];
+#pragma unroll
+                        for (int jj = 0; jj < EPT; jj++)
+                        {
+                            const unsigned ctop = static_cast<unsigned>(jj) >> (ch - 8);
+                            const unsigned within = (static_cast<unsigned>(jj) & ((1u << (ch - 8)) - 1u)) << 8;
+                            tmp[jj] = ld_stream<true>((src + (in_base + (static_cast<unsigned long long>(ctop) << (a.p_lo + l1)) + within)) + t);
+                        }
+#pragma unroll
+                        for (int jj = 0; jj < EPT; jj++)
+                        {
+                            const unsigned f = static_cast<unsigned>(t + NT * jj);
+                            const unsigned ctop = static_cast<unsigned>(jj) >> (ch - 8);
+                            lds[lds_t + (ctop << L) + ((f >> l1) & ((1u << L) - 1u))] = tmp[jj];
+                        }
+                        __syncthreads();
+#pragma unroll
+                        for (int j = 0; j < EPT; j++)
+                        {
+                            const unsigned e = static_cast<unsigned>(elem_of<WL>(t, j));
+                            v[j] = lds[e + (e >> (TL - l1))];
+                        }
+                        pin_loaded(v);
+                        __syncthreads(); // the exchanges below reuse the buffer in the e + (e >> 4) layout
+                    }
                     else if constexpr (DIRECT_IO)
                     {
                         if (plain_io)
@@ -886,7 +925,7 @@ namespace gpuntt
                                 const unsigned lane = (static_cast<unsigned>(t >> RB) << a.n2_log) + (t & ((1 << RB) - 1));
                                 const unsigned long long ubase =
                                     (static_cast<unsigned long long>((NT >> RB) * jr) << a.n2_log) + row0;
-                                if constexpr (!SEG && FST != 3)
+                                if constexpr (!SEG)
                                     wv[jj] = (a.w_pairs + ubase)[lane];
                                 x[jj] = lds[lds_pad_t<K>((jl << K) | i)];
                             }
@@ -899,8 +938,6 @@ namespace gpuntt
                                     (static_cast<unsigned long long>((NT >> RB) * jr) << a.n2_log) + row0;
                                 if constexpr (SEG)
                                     (a.out + ((fst_poly << a.poly_shift) + seg_base + ubase))[lane] = x[jj];
-                                else if constexpr (FST == 3) // Merge form: no W product here, lazy hand-over
-                                    (a.out + ((fst_poly << a.poly_shift) + ubase))[lane] = x[jj];
                                 else
                                     (a.out + ((fst_poly << a.poly_shift) + ubase))[lane] =
                                         lazy::normalize<M::TB>(m, m.mul(x[jj], wv[jj]));
@@ -1170,11 +1207,13 @@ namespace gpuntt
             pass_body<T, TLOG, false, true, true, K, 1, false, 2>(a, lds, a.q, a.q_bit, a.q_mu, 0, poly, rb, -1, seg);
         }
 
-        // forward 4-step phase 1 in Merge form (FST = 3); block order as fourstep_phase1_lazy
-        template <typename T, int TLOG, int K, int LIM = 0>
-        __global__ __launch_bounds__(LTile<TLOG>::NT, (LOcc<TLOG, T>::WAVES)) void fourstep_phase1_merge_lazy(LazyArgsT<T> a)
+        // forward 4-step, first pass in Merge form with the transposed gather (XP = 5): the first strided pass of the ring's
+        // Merge plan, K >= log2 n1 stages, reading the n2 x n1 input; everything behind it is the Merge plan itself.
+        // a.n = log2 N, a.p_lo = log2 N - K, a.n2_log = log2 n1; grid = batch * N / 4096 blocks in tile order
+        template <typename T, int K, int LIM = 0>
+        __global__ __launch_bounds__(LTile<12>::NT, (LOcc<12, T>::WAVES)) void fourstep_first_lazy(LazyArgsT<T> a)
         {
-            __shared__ T lds[LTile<TLOG>::LDS_ELEMS_FST];
+            __shared__ T lds[LTile<12>::LDS_ELEMS];
             if (a.go_flag != nullptr && *a.go_flag == 0u)
                 return;
             T qv = a.q, qb = a.q_bit, qm = a.q_mu;
@@ -1185,15 +1224,9 @@ namespace gpuntt
                 qb = md.bit;
                 qm = md.mu;
             }
-            // poly-minor order although there is no W slice to share: consecutive workgroups then store their 128-byte
-            // transposed runs into DIFFERENT polynomials.  In poly-major order neighbouring tiles write neighbouring runs
-            // of the same rows (one HBM channel for all eight XCDs): measured 4.24 against 3.90 ms at 2^24 x 64.
-            // F_REVERSE (host): walked backwards, so the first row pass starts on what this pass wrote last.
             const unsigned bx = (a.flags & F_REVERSE) ? (gridDim.x - 1u - blockIdx.x) : blockIdx.x;
-            unsigned poly, tile;
-            poly_minor_order(bx, static_cast<unsigned>(a.batch), a.poly_shift - TLOG, poly, tile, a.flags | F_PLAIN_ORDER);
-            pass_body<T, TLOG, false, false, true, K, 1, false, 3, LIM>(a, lds, qv, qb, qm, 0, uniform32(poly),
-                                                                                 uniform32(tile));
+            pass_body<T, 12, false, false, false, K, 1, false, 0, LIM, 5>(a, lds, qv, qb, qm, 0, 0, 0,
+                                                                          static_cast<long long>(bx));
         }
 
         // 4-step transform of a ring that fits one tile (2^12 .. 2^14): ONE contiguous Merge pass over the whole ring

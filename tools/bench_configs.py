@@ -228,9 +228,17 @@ def main():
             batch = max(1, 1 << (26 - logn))
             merge_case(g, bits, logn, batch, g.X_N_minus, max(3, args.iters // 2), "sweep-merge")
             merge_case(g, bits, logn, batch, g.X_N_minus, max(3, args.iters // 2), "sweep-merge-inv", inverse=True)
+    if args.what == "mergebig":  # three-sweep Merge rings, both directions (A/B of the stage split: GPUNTT_CONTIG_K)
+        for logn in range(23, 27):
+            batch = max(1, 1 << (27 - logn))
+            merge_case(g, 64, logn, batch, g.X_N_minus, max(3, args.iters // 2), "big-merge")
+            merge_case(g, 64, logn, batch, g.X_N_minus, max(3, args.iters // 2), "big-merge-inv", inverse=True)
+    if args.what == "4step64":  # forward / inverse of the reference layout, every ring size
+        for logn in range(12, 25):
+            fourstep_case(g, 64, logn, max(1, 1 << (26 - logn)), max(3, args.iters // 2), "sweep-4step", check=(logn <= 20))
     if args.what == "4step32":  # the 32-bit one-launch rings and their neighbours
-        for logn in range(12, 17):
-            fourstep_case(g, 32, logn, 1 << (26 - logn), max(3, args.iters // 2), "sweep-4step-u32")
+        for logn in range(12, 25):
+            fourstep_case(g, 32, logn, max(1, 1 << (26 - logn)), max(3, args.iters // 2), "sweep-4step-u32", check=(logn <= 20))
     if args.what in ("sweep", "all"):
         for bits in (64, 32):
             for logn in range(12, 25):
