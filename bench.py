@@ -38,6 +38,7 @@ sys.path.insert(0, ROOT)
 from __graft_entry__ import _load_pkg  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+E2E_TIMEOUT_S = 180  # multi-GPU runs: watchdog around the informational RCCL scatter / gather leg
 CPU_SECONDS = 5.0      # per CPU-baseline leg (1 thread, then all threads)
 
 CONFIGS = {
@@ -779,81 +780,104 @@ def main():
         except Exception as e:  # informational only
             power = {"error": repr(e)}
 
+    def finish(e2e):
+        """rank 0: assemble and print THE line (everything the timed region produced is already known here)"""
+        if rank == 0:
+            ms_per_step = wall * 1e3 / args.steps
+            call_ms = dev_ms / args.steps
+            per_step = case["transforms_per_step"]
+            alg_bytes = 2 * n * (bits // 8) * per_step  # every coefficient read once + written once per transform
+            achieved = alg_bytes / (call_ms * 1e-3) / 1e9
+            traffic, traffic_info = None, None
+            if world == 1 and not args.no_traffic:
+                traffic, traffic_info = measure_traffic(args.config, args.api, args.out_of_place)
+            quoted = False
+            if traffic is None:
+                reason = traffic_info
+                traffic, src = quoted_traffic() if args.config == "c2" else (None, None)
+                quoted = traffic is not None
+                traffic_info = {"quoted": quoted, "source": src, "why_not_measured": reason or "disabled / multi-GPU run"}
+            line = {
+                "metric": cfg["metric"],
+                "value": world * per_step * args.steps / wall,
+                "unit": "NTT/s",
+                "n_gpus": world,
+                "steps": args.steps,
+                "warmup": args.warmup,
+                "ms_per_step": ms_per_step,
+                "higher_is_better": True,
+                "scaling": cfg["scaling"],
+                "vs_baseline": None,
+                "dtype": "u%d" % bits,
+                "data": "synthetic",
+                "config": {"workload": cfg["workload"], "log2N": logn, "batch_per_gpu": case["batch"],
+                           "reduction_poly": "X_N_" + cfg["poly"], "modulus": int(case["modulus"]),
+                           "in_place": inplace, "api": args.api,
+                           "parallelism": "batch-shard x%d" % world},
+                "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_info": traffic_info,
+                             "algorithmic_bytes_per_call": alg_bytes,
+                             "call_ms_hip_events": call_ms,
+                             "note": "one call = every launch of one library call; achieved = algorithmic bytes "
+                                     "per call / HIP-event time per call; per-kernel averages in profiles/"},
+            }
+            if isinstance(other, float):
+                line["other_api_ms_per_call"] = {"api": "plan" if args.api == "dropin" else "dropin", "ms": other}
+            if power is not None and "ms_per_step_while_sampling" in power:
+                # the samples describe the timed regime only if the sampled loop ran at the timed rate
+                ratio = power["ms_per_step_while_sampling"] / ms_per_step
+                power["sampling_vs_timed_ms_ratio"] = ratio
+                power["same_regime_as_timed_steps"] = bool(0.9 <= ratio <= 1.1)
+            if power is not None:
+                if bits == 64 and isinstance(power.get("cap_w"), float) and traffic and power.get("same_regime_as_timed_steps"):
+                    # what the measured bytes and the butterflies of one step cost by the per-byte / per-butterfly energies
+                    # measured on this part (profiles/r02_power.txt: device copy 0.12 nJ per byte through L2 / fabric / HBM;
+                    # profiles/ubench_bfly_r02.txt: register-only 64-bit lazy butterflies 29 nJ per wave of 64; idle 261 W)
+                    wave_bfly = per_step * (n // 2) * logn / 64.0
+                    dyn_j = float(traffic) * 0.12e-9 + wave_bfly * 29e-9
+                    power["energy_model"] = {
+                        "dynamic_j_per_step": dyn_j,
+                        "ms_per_step_at_cap": dyn_j / (power["cap_w"] - 261.0) * 1e3,
+                        "inputs": {"hbm_bytes": float(traffic), "nj_per_byte": 0.12, "wave_butterflies": wave_bfly,
+                                   "nj_per_wave_butterfly": 29.0, "idle_w": 261.0},
+                        "note": "time the dynamic energy of one step takes at the socket cap: the bound these "
+                                "transforms run into (sustained loop: ms_per_step_while_sampling)"}
+                line["power"] = power
+            if e2e is not None:
+                line["end_to_end"] = e2e
+            if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only
+                case["x_sample"] = case["x"][:cpu_polys * n] if cfg["kind"] != "4step" else case["x"][:n]
+                line["cpu_baseline"] = cpu_baseline(cfg, case, y_first)
+            print(json.dumps(line), flush=True)
+
+    # The RCCL legs around the transform (table broadcast, scatter, gather) are informational and have never run on
+    # more than one physical GPU: a collective that hangs must not cost the run its line.  A watchdog prints the line
+    # without them and ends the rank.
     e2e = None
     if dist is not None and not args.no_e2e and case.get("run_shard") is not None:
+        import threading
+        done = threading.Event()
+
+        def on_timeout():
+            if done.is_set():
+                return
+            try:
+                finish({"error": "end-to-end leg did not finish within %d s; skipped" % E2E_TIMEOUT_S})
+            finally:
+                sys.stdout.flush()
+                os._exit(0)
+
+        wd = threading.Timer(E2E_TIMEOUT_S, on_timeout)
+        wd.daemon = True
+        wd.start()
         try:
             e2e = dist_mod.end_to_end_leg(dist, rank, world, dev, case["table"], case["d_in"], case["d_out"],
                                           case["run_shard"], case["batch"])
         except Exception as e:
             e2e = {"error": repr(e)}
-
-    if rank == 0:
-        ms_per_step = wall * 1e3 / args.steps
-        call_ms = dev_ms / args.steps
-        per_step = case["transforms_per_step"]
-        alg_bytes = 2 * n * (bits // 8) * per_step  # every coefficient read once + written once per transform
-        achieved = alg_bytes / (call_ms * 1e-3) / 1e9
-        traffic, traffic_info = None, None
-        if world == 1 and not args.no_traffic:
-            traffic, traffic_info = measure_traffic(args.config, args.api, args.out_of_place)
-        quoted = False
-        if traffic is None:
-            reason = traffic_info
-            traffic, src = quoted_traffic() if args.config == "c2" else (None, None)
-            quoted = traffic is not None
-            traffic_info = {"quoted": quoted, "source": src, "why_not_measured": reason or "disabled / multi-GPU run"}
-        line = {
-            "metric": cfg["metric"],
-            "value": world * per_step * args.steps / wall,
-            "unit": "NTT/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": ms_per_step,
-            "higher_is_better": True,
-            "scaling": cfg["scaling"],
-            "vs_baseline": None,
-            "dtype": "u%d" % bits,
-            "data": "synthetic",
-            "config": {"workload": cfg["workload"], "log2N": logn, "batch_per_gpu": case["batch"],
-                       "reduction_poly": "X_N_" + cfg["poly"], "modulus": int(case["modulus"]),
-                       "in_place": inplace, "api": args.api,
-                       "parallelism": "batch-shard x%d" % world},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_info": traffic_info,
-                         "algorithmic_bytes_per_call": alg_bytes,
-                         "call_ms_hip_events": call_ms,
-                         "note": "one call = every launch of one library call; achieved = algorithmic bytes "
-                                 "per call / HIP-event time per call; per-kernel averages in profiles/"},
-        }
-        if isinstance(other, float):
-            line["other_api_ms_per_call"] = {"api": "plan" if args.api == "dropin" else "dropin", "ms": other}
-        if power is not None and "ms_per_step_while_sampling" in power:
-            # the samples describe the timed regime only if the sampled loop ran at the timed rate
-            ratio = power["ms_per_step_while_sampling"] / ms_per_step
-            power["sampling_vs_timed_ms_ratio"] = ratio
-            power["same_regime_as_timed_steps"] = bool(0.9 <= ratio <= 1.1)
-        if power is not None:
-            if bits == 64 and isinstance(power.get("cap_w"), float) and traffic and power.get("same_regime_as_timed_steps"):
-                # what the measured bytes and the butterflies of one step cost by the per-byte / per-butterfly energies
-                # measured on this part (profiles/r02_power.txt: device copy 0.12 nJ per byte through L2 / fabric / HBM;
-                # profiles/ubench_bfly_r02.txt: register-only 64-bit lazy butterflies 29 nJ per wave of 64; idle 261 W)
-                wave_bfly = per_step * (n // 2) * logn / 64.0
-                dyn_j = float(traffic) * 0.12e-9 + wave_bfly * 29e-9
-                power["energy_model"] = {
-                    "dynamic_j_per_step": dyn_j,
-                    "ms_per_step_at_cap": dyn_j / (power["cap_w"] - 261.0) * 1e3,
-                    "inputs": {"hbm_bytes": float(traffic), "nj_per_byte": 0.12, "wave_butterflies": wave_bfly,
-                               "nj_per_wave_butterfly": 29.0, "idle_w": 261.0},
-                    "note": "time the dynamic energy of one step takes at the socket cap: the bound these "
-                            "transforms run into (sustained loop: ms_per_step_while_sampling)"}
-            line["power"] = power
-        if e2e is not None:
-            line["end_to_end"] = e2e
-        if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only
-            case["x_sample"] = case["x"][:cpu_polys * n] if cfg["kind"] != "4step" else case["x"][:n]
-            line["cpu_baseline"] = cpu_baseline(cfg, case, y_first)
-        print(json.dumps(line), flush=True)
+        done.set()
+        wd.cancel()
+    finish(e2e)
     if dist is not None:
         dist.destroy_process_group()
 
