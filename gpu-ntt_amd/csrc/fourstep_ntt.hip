@@ -339,6 +339,95 @@ namespace gpuntt
                     return true;
                 }
             }
+            // Inverse, rings from 2^17: the ring's inverse Merge plan with the transposition on its FIRST pass
+            // (kern::fourstep_inv_first_lazy: 12 contiguous Gentleman-Sande stages on the spectrum as it lies, stored
+            // transposed), then every remaining stage inside the n2-long rows of `out` -- strided inverse passes of an
+            // n2-point ring reading a prefix of the same table, n^-1 folded into its slot 1.  No W stream, no W product,
+            // 2^17 .. 2^20 in two sweeps instead of three.  (2^15 / 2^16 and 61- / 62-bit moduli keep the W form below.)
+            if constexpr (INV)
+            {
+                int k_a = 0, k_b = 0;
+                if (lim == 0 && host::fourstep_inv_merge_enabled() &&
+                    host::fourstep_inv_merge_split(n_power, log_n1, k_a, k_b))
+                {
+                    if (plan.mode != PLAN_EXECUTE)
+                        host::launch_prep_merge_from_fourstep<T>(n1_table, w_table, ws_w, log_n1, log_n2, 12, true, true,
+                                                                 mod.value, ninv, mods_dev, mods_dev ? ninv_dev : nullptr,
+                                                                 ws_ninv, go_flag, norm_arr, stream);
+                    if (go_flag_out != nullptr)
+                        *go_flag_out = go_flag;
+                    if (plan.mode == PLAN_PREPARE)
+                        return true;
+                    const int passes = k_b != 0 ? 3 : 2;
+                    const bool rev = host::lazy_reverse_passes();
+                    kern::LazyArgsT<T> f{};
+                    f.in = in;
+                    f.out = out;
+                    f.tw = ws_w;
+                    f.mods = mods_dev;
+                    f.q = mod.value;
+                    f.q_bit = mod.bit;
+                    f.q_mu = mod.mu;
+                    f.ninv = TW{0, 0};
+                    f.go_flag = go_flag;
+                    f.norm = lazy::make_norm_const(static_cast<uint64_t>(mod.value), static_cast<uint64_t>(mod.bit));
+                    f.norm_arr = norm_arr;
+                    f.n2_log = log_n2; // row stride of the transposed side
+                    f.total = static_cast<unsigned long long>(batch_size) << n_power;
+                    f.n = n_power;
+                    f.poly_shift = n_power;
+                    f.mod_count = 1;
+                    // from 2^20 the per-lane twiddles of the pass are tens of MiB per polynomial: poly-minor block order
+                    f.batch = (n_power >= 20 && batch_size >= 2) ? batch_size : 0;
+                    f.flags = host::lazy_order_flags();
+                    if (rev && ((passes - 1) & 1) != 0) // the last sweep walks the batch forwards, the one before it backwards, ...
+                        f.flags |= kern::F_REVERSE;
+                    bool wide32 = false;
+                    if constexpr (sizeof(T) == 4)
+                        wide32 = mods_dev == nullptr && host::lazy_lim31_enabled() && host::lazy_wide_modulus32(mod.value);
+                    if constexpr (sizeof(T) == 4)
+                    {
+                        if (wide32)
+                            host::launch_fourstep_inv_first_lazy<T, 8>(log_n1, f, stream);
+                        else
+                            host::launch_fourstep_inv_first_lazy<T, 0>(log_n1, f, stream);
+                    }
+                    else
+                        host::launch_fourstep_inv_first_lazy<T, 0>(log_n1, f, stream);
+
+                    kern::LazyArgsT<T> r = f;
+                    r.in = out;
+                    r.n = log_n2;
+                    r.poly_shift = log_n2;
+                    r.batch = 0;
+                    if (mods_dev == nullptr)
+                        r.ninv = TW{ninv, host::shoup_host(ninv, mod.value)};
+                    else
+                        r.ninv_arr = ws_ninv;
+                    const host::Pass pa{false, k_a, 12 - log_n1};
+                    const host::Pass pb{false, k_b, 12 - log_n1 + k_a};
+                    for (int i = 1; i < passes; i++)
+                    {
+                        kern::LazyArgsT<T> x = r;
+                        const host::Pass& p = (i == 1) ? pa : pb;
+                        x.p_lo = p.p_lo;
+                        x.flags = host::lazy_order_flags();
+                        if (rev && ((passes - 1 - i) & 1) != 0)
+                            x.flags |= kern::F_REVERSE;
+                        const bool last = (i == passes - 1);
+                        if constexpr (sizeof(T) == 4)
+                        {
+                            if (wide32)
+                                host::launch_pass_lazy_u32w<true>(p, 12, false, last, x, stream);
+                            else
+                                host::launch_pass_lazy<T, true>(p, 12, false, last, x, stream);
+                        }
+                        else
+                            host::launch_pass_lazy<T, true>(p, 12, false, last, x, stream);
+                    }
+                    return true;
+                }
+            }
             // one preparation launch; inverse: n^-1 rides on the last row stage (fold = 2)
             if (plan.mode != PLAN_EXECUTE)
                 host::launch_prep_fourstep<T>(n1_table, n2_table, w_table, ws_n1, ws_w, ws_n2, log_n1, log_n2,

@@ -140,6 +140,33 @@ namespace gpuntt
         void launch_fourstep_first_lazy(int k, const kern::LazyArgsT<T>& a, hipStream_t stream);
         extern template void launch_fourstep_first_lazy<uint64_t>(int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
         extern template void launch_fourstep_first_lazy<uint32_t>(int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
+        // inverse 4-step in Merge form (kern::fourstep_inv_first_lazy): the 12-stage contiguous first pass of the ring's
+        // inverse Merge plan, stored transposed (log_n1 = 5 .. 8); LIMSEL = 8: 32-bit words, moduli below 2^29
+        template <typename T, int LIMSEL = 0>
+        void launch_fourstep_inv_first_lazy(int log_n1, const kern::LazyArgsT<T>& a, hipStream_t stream);
+        extern template void launch_fourstep_inv_first_lazy<uint64_t, 0>(int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
+        extern template void launch_fourstep_inv_first_lazy<uint32_t, 0>(int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
+        extern template void launch_fourstep_inv_first_lazy<uint32_t, 8>(int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
+        // Stage split of the strided row passes behind it: s = n - 12 stages on the bits above the first pass, as one pass
+        // (s <= 8) or two; the first of them starts at row bit 12 - log_n1 and keeps 2^(12 - k) contiguous words per tile
+        // row, so k >= log_n1.  false: the shape has no such plan (2^15, 2^16: fewer stages left than log_n1)
+        inline bool fourstep_inv_merge_split(int n_power, int log_n1, int& k_a, int& k_b)
+        {
+            const int s = n_power - 12;
+            if (n_power < 17 || n_power > LAZY_MAX_N_POWER || s < log_n1 || s > 16)
+                return false;
+            if (s <= 8)
+            {
+                k_a = s;
+                k_b = 0;
+                return true;
+            }
+            k_a = (s + 1) / 2;
+            if (k_a < log_n1)
+                k_a = log_n1;
+            k_b = s - k_a;
+            return k_b >= 1 && k_a <= 8;
+        }
         // natural-order 4-step (extension) in Merge form: strided Merge passes + one transposing row pass
         template <typename T>
         void launch_fourstep_nat_last_lazy(int k, const kern::LazyArgsT<T>& a, hipStream_t stream);
@@ -224,6 +251,7 @@ namespace gpuntt
         int lazy_contig_k(int n);
 
         bool lazy_reverse_passes();
+        bool fourstep_inv_merge_enabled(); // option fourstep_inv_merge (A/B timing against the two-phase W form)
         // forward 4-step in Merge form: stages of the first pass (the one that reads the transposed input) -- the first
         // strided pass of the ring's Merge plan on tile `tl`, widened to log2 n1 where that is larger (5 .. 8)
         inline int fourstep_first_k(int n_power, int log_n1, int tl)

@@ -281,6 +281,33 @@ namespace gpuntt
             GPUNTT_HIP_CHECK(hipGetLastError());
         }
 
+        // inverse 4-step: first (contiguous, 12-stage) pass of the ring's inverse Merge plan with the transposed store
+        template <typename T, int LIMSEL>
+        void launch_fourstep_inv_first_lazy(int log_n1, const kern::LazyArgsT<T>& a, hipStream_t stream)
+        {
+            const unsigned long long tiles = a.total >> 12;
+            if (tiles == 0)
+                return;
+            if (tiles > 0x7fffffffull)
+                throw std::invalid_argument("batch_size * N too large for one launch");
+            const unsigned grid = static_cast<unsigned>(tiles);
+            switch (log_n1)
+            {
+#define GPUNTT_CASE(KK)                                                                                                   \
+    case KK:                                                                                                               \
+        hipLaunchKernelGGL((kern::fourstep_inv_first_lazy<T, KK, LIMSEL>), dim3(grid), dim3(kern::LTile<12>::NT), 0, stream, a); \
+        break;
+                GPUNTT_CASE(5)
+                GPUNTT_CASE(6)
+                GPUNTT_CASE(7)
+                GPUNTT_CASE(8)
+#undef GPUNTT_CASE
+                default:
+                    throw std::invalid_argument("internal: bad 4-step n1");
+            }
+            GPUNTT_HIP_CHECK(hipGetLastError());
+        }
+
         // 4-step transform of a ring that fits one tile: the whole transform in one launch (fourstep_small_lazy);
         // natural: the natural-order extension (spectrum side in NTT_4STEP_CPU order)
         template <typename T, bool INV, bool NAT>

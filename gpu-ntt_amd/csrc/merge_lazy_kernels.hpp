@@ -375,7 +375,7 @@ namespace gpuntt
             // <= 10 stages, the last exchange of every longer one (u64 K = 11, 12; u32 big tiles).  Full-tile
             // contiguous passes also enter / leave through the 64-contiguous window (512-byte runs per wave
             // instruction, WIO) with a wave-local transposition instead of the block-wide coalescing pass.
-            constexpr bool WIO_OK = CONTIG && !FST && !MULTI_POLY && !EXACT && (TL >= 10);
+            constexpr bool WIO_OK = CONTIG && (!FST || FST == 3) && !MULTI_POLY && !EXACT && (TL >= 10);
             constexpr int WIO = 6;
             const int t = threadIdx.x;
             constexpr bool SEG = (FST == 2);
@@ -896,18 +896,22 @@ namespace gpuntt
                     }
                     else if constexpr (FST && !(SEG && INV))
                     {
-                        static_assert(!FST || (CONTIG && K >= 4 && K <= 9), "4-step row runs are 16..512 long");
-                        constexpr int RB = TL - K; // log2 rows per tile
+                        // FST = 3: the tile is 2^(TL - TK) rows of 2^TK = n1 coefficients (TK = XP - 16), all TL stages of the
+                        // ring's inverse Merge plan done on it; FST = 1, 2: rows of 2^K, K stages
+                        constexpr int TK = (FST == 3) ? (XP - 16) : K;
+                        static_assert(!FST || (CONTIG && TK >= 4 && TK <= 9), "4-step row runs are 16..512 long");
+                        static_assert(FST != 3 || (INV && K == TL && !LAST), "Merge-form inverse first pass");
+                        constexpr int RB = TL - TK; // log2 rows per tile
                         pin_loaded(v);
                         __syncthreads();           // all gathers from the e + (e >> 4) layout are done
 #pragma unroll
                         for (int j = 0; j < EPT; j++)
-                            lds[lds_pad_t<K>(elem_of<WL>(t, j))] = v[j];
+                            lds[lds_pad_t<TK>(elem_of<WL>(t, j))] = v[j];
                         __syncthreads();
                         const unsigned row0 = fst_tile << RB;
                         // SEG: output row of tile column i is (seg << K) + i
                         const unsigned long long seg_base =
-                            SEG ? ((static_cast<unsigned long long>(fst_seg) << K) << a.n2_log) : 0ull;
+                            SEG ? ((static_cast<unsigned long long>(fst_seg) << TK) << a.n2_log) : 0ull;
                         // two halves of 8 keep {coefficient, W pair} in 48 VGPRs instead of 96
 #pragma unroll
                         for (int half = 0; half < 2; half++)
@@ -925,9 +929,9 @@ namespace gpuntt
                                 const unsigned lane = (static_cast<unsigned>(t >> RB) << a.n2_log) + (t & ((1 << RB) - 1));
                                 const unsigned long long ubase =
                                     (static_cast<unsigned long long>((NT >> RB) * jr) << a.n2_log) + row0;
-                                if constexpr (!SEG)
+                                if constexpr (FST == 1)
                                     wv[jj] = (a.w_pairs + ubase)[lane];
-                                x[jj] = lds[lds_pad_t<K>((jl << K) | i)];
+                                x[jj] = lds[lds_pad_t<TK>((jl << TK) | i)];
                             }
 #pragma unroll
                             for (int jj = 0; jj < EPT / 2; jj++)
@@ -936,7 +940,7 @@ namespace gpuntt
                                 const unsigned lane = (static_cast<unsigned>(t >> RB) << a.n2_log) + (t & ((1 << RB) - 1));
                                 const unsigned long long ubase =
                                     (static_cast<unsigned long long>((NT >> RB) * jr) << a.n2_log) + row0;
-                                if constexpr (SEG)
+                                if constexpr (SEG || FST == 3) // (FST = 3: lazy hand-over to the strided row passes)
                                     (a.out + ((fst_poly << a.poly_shift) + seg_base + ubase))[lane] = x[jj];
                                 else
                                     (a.out + ((fst_poly << a.poly_shift) + ubase))[lane] =
@@ -1227,6 +1231,42 @@ namespace gpuntt
             const unsigned bx = (a.flags & F_REVERSE) ? (gridDim.x - 1u - blockIdx.x) : blockIdx.x;
             pass_body<T, 12, false, false, false, K, 1, false, 0, LIM, 5>(a, lds, qv, qb, qm, 0, 0, 0,
                                                                           static_cast<long long>(bx));
+        }
+
+        // inverse 4-step, first pass in Merge form (FST = 3).  With e = (a << l1) | b the natural index of the result x =
+        // MergeINTT_w(in), GPU_4STEP_NTT stores out[(b << l2) | a] = x[e]: the LOW l1 index bits go to the top.  The first
+        // pass of the ring's inverse Merge plan -- 12 contiguous Gentleman-Sande stages on a tile that lies as it stands in
+        // the spectrum -- holds all of b and the low 12 - l1 bits of a, so it can store the tile transposed: 2^l1 rows
+        // (b) of 2^(12 - l1) consecutive words (128 B .. 1 KiB runs).  Behind it every remaining stage works on index bits
+        // of a, i.e. inside the n2-long rows of `out`: ordinary strided inverse passes of an n2-point ring (host side:
+        // fourstep_run_lazy), whose twiddle slots are a prefix of the ring's own table.  No W stream, no W product.
+        // a.n = log2 N, a.n2_log = log2 n2, a.poly_shift = log2 N; blocks in merge_pass_lazy's order.
+        template <typename T, int L1, int LIM = 0>
+        __global__ __launch_bounds__(LTile<12>::NT, (LOcc<12, T>::WAVES)) void fourstep_inv_first_lazy(LazyArgsT<T> a)
+        {
+            __shared__ T lds[LTile<12>::LDS_ELEMS_FST];
+            if (a.go_flag != nullptr && *a.go_flag == 0u)
+                return;
+            T qv = a.q, qb = a.q_bit, qm = a.q_mu;
+            if (a.mods != nullptr)
+            {
+                const Modulus<T> md = a.mods[0];
+                qv = md.value;
+                qb = md.bit;
+                qm = md.mu;
+            }
+            const unsigned bx = (a.flags & F_REVERSE) ? (gridDim.x - 1u - blockIdx.x) : blockIdx.x;
+            const int tiles_log = a.n - 12;
+            unsigned poly, tile;
+            if (a.batch > 1)
+                poly_minor_order(bx, static_cast<unsigned>(a.batch), tiles_log, poly, tile, a.flags);
+            else
+            {
+                poly = bx >> tiles_log;
+                tile = bx & ((1u << tiles_log) - 1u);
+            }
+            pass_body<T, 12, false, true, true, 12, 1, false, 3, LIM, 16 + L1>(a, lds, qv, qb, qm, 0, uniform32(poly),
+                                                                              uniform32(tile));
         }
 
         // 4-step transform of a ring that fits one tile (2^12 .. 2^14): ONE contiguous Merge pass over the whole ring

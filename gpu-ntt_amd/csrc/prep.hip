@@ -426,6 +426,7 @@ namespace gpuntt
                 std::atomic<int> big_tiles{14}; // largest 64-bit ring done in one big tile
                 std::atomic<int> u32_tile{0};   // 12 | 14: 32-bit tile above 2^14
                 std::atomic<int> no_scratch{0}; // test hook: behave as if the twiddle scratch could not be allocated
+                std::atomic<int> inv_merge{1};  // inverse 4-step above one tile in Merge form (0: the two-phase W form)
             } g_opt;
         } // namespace
 
@@ -457,6 +458,8 @@ namespace gpuntt
                 g_opt.u32_tile = (iv == 12 || iv == 14) ? iv : 0;
             else if (k == "no_scratch")
                 g_opt.no_scratch = iv != 0;
+            else if (k == "fourstep_inv_merge")
+                g_opt.inv_merge = iv != 0;
             else
                 return false;
             return true;
@@ -483,6 +486,7 @@ namespace gpuntt
         }
         bool lazy_lim31_enabled() { return g_opt.lim31.load(std::memory_order_relaxed) != 0; }
         bool lazy_reverse_passes() { return g_opt.reverse.load(std::memory_order_relaxed) != 0; }
+        bool fourstep_inv_merge_enabled() { return g_opt.inv_merge.load(std::memory_order_relaxed) != 0; }
         int lazy_u64_big_tiles() { return g_opt.big_tiles.load(std::memory_order_relaxed); }
         int lazy_u32_tile_override() { return g_opt.u32_tile.load(std::memory_order_relaxed); }
 

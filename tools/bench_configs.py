@@ -206,6 +206,33 @@ def fourstep_case(g, bits, logn, batch, iters, name, check=True):
     emit(name + "-inv-natural-fused", bits, "4step-inv-natural-fused", logn, batch, time_ms(invn, iters), ok3)
 
 
+def fourstep_inv_case(g, bits, logn, batch, iters, name):
+    """GPU_4STEP_NTT inverse alone, checked through the round trip with the forward call (polynomial 0 and the last one)."""
+    import torch
+    P = O.Port(bits)
+    p4 = g.NTTParameters4Step(logn, bits)
+    n = p4.n
+    x = P.splitmix(0x5EED0004, 0, batch * n, p4.modulus.value)
+    a = g.to_device(x)
+    b = torch.empty_like(a)
+    c = torch.empty_like(a)
+    tf = [g.to_device(t) for t in p4.tables["fwd"]]
+    ti = [g.to_device(t) for t in p4.tables["inv"]]
+    cf = g.ntt4step_configuration(n_power=logn, ntt_type=g.FORWARD)
+    ci = g.ntt4step_configuration(n_power=logn, ntt_type=g.INVERSE, mod_inverse=p4.n_inv)
+    g.GPU_4STEP_NTT(a, b, *tf, p4.modulus, cf, batch)   # a = x^T (n2 x n1)  ->  b = spectrum (n1 x n2)
+    g.GPU_4STEP_NTT(b, c, *ti, p4.modulus, ci, batch)   # -> c = x as n1 x n2, i.e. the transpose of a's layout
+    g.GPU_Transpose(c, a, p4.n1, p4.n2, logn, batch)    # n1 x n2 -> n2 x n1
+    torch.cuda.synchronize()
+    y = g.to_host(a)
+    # the forward call read `a` as the n2 x n1 transpose of the natural polynomial; the inverse returns it n1 x n2
+    # (low n1-index on top), which GPU_Transpose turned into natural order
+    nat = lambda v: v.reshape(p4.n2, p4.n1).T.reshape(-1)  # noqa: E731
+    ok = np.array_equal(y[:n], nat(x[:n])) and np.array_equal(y[-n:], nat(x[-n:]))
+    inv = lambda: g.GPU_4STEP_NTT(b, c, *ti, p4.modulus, ci, batch)  # noqa: E731
+    emit(name, bits, "4step-inv", logn, batch, time_ms(inv, iters), ok)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--what", default="all")
@@ -236,6 +263,11 @@ def main():
     if args.what == "4step64":  # forward / inverse of the reference layout, every ring size
         for logn in range(12, 25):
             fourstep_case(g, 64, logn, max(1, 1 << (26 - logn)), max(3, args.iters // 2), "sweep-4step", check=(logn <= 20))
+    if args.what == "4stepinv":  # inverse of the reference layout above one tile (A/B: GPUNTT_FOURSTEP_INV_MERGE=0|1)
+        for bits in (64, 32):
+            for logn in range(15, 25):
+                fourstep_inv_case(g, bits, logn, max(1, 1 << (26 - logn)), max(3, args.iters // 2), "4step-inv-u%d" % bits)
+        fourstep_inv_case(g, 64, 24, 64, 5, "C3 4-Step u64 2^24 x64-inv")
     if args.what == "4step32":  # the 32-bit one-launch rings and their neighbours
         for logn in range(12, 25):
             fourstep_case(g, 32, logn, max(1, 1 << (26 - logn)), max(3, args.iters // 2), "sweep-4step-u32", check=(logn <= 20))
