@@ -618,7 +618,7 @@ namespace gpuntt
             TW* ws_merge = ws + n1;
             const int small_tl = plan.mode != PLAN_NONE
                                      ? plan.small_tl
-                                     : host::fourstep_small_tile<T>(n_power, true, static_cast<unsigned long long>(batch_size));
+                                     : host::fourstep_small_tile<T>(n_power, true, static_cast<unsigned long long>(batch_size), true);
             // inverse Merge table of the ring, N^-1 folded into the single twiddle of the final stage (slot 1)
             if (plan.mode != PLAN_EXECUTE)
                 host::launch_prep_merge_from_fourstep<T>(n1_table, w_table, ws_merge, log_n1, log_n2, small_tl, true, true,
@@ -857,7 +857,8 @@ namespace gpuntt
                                       : host::lazy_tile_log<T>(p->n, false, static_cast<unsigned long long>(batch_hint));
                 p->use.first_k = host::fourstep_first_k(p->n, l1, p->use.tile_log);
             }
-            p->use.small_tl = host::fourstep_small_tile<T>(p->n, p->inverse, static_cast<unsigned long long>(batch_hint));
+            p->use.small_tl =
+                host::fourstep_small_tile<T>(p->n, p->inverse, static_cast<unsigned long long>(batch_hint), natural_order);
             // the eligibility checks of the fast paths decide (modulus width, n^-1 canonical, option "path")
             if (natural_order)
                 p->fast = p->inverse ? fourstep_natural_inverse_lazy<T>(nullptr, nullptr, p->n1_table, p->n2_table,

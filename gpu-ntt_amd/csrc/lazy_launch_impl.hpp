@@ -328,9 +328,9 @@ namespace gpuntt
                     GPUNTT_SMALL(12, 12);
                 else if (tile_log == 13 && n == 13)
                     GPUNTT_SMALL(13, 13);
-                else if (tile_log == 14 && n == 14 && !INV)
+                else if (tile_log == 14 && n == 14 && !(INV && NAT))
                 {
-                    if constexpr (!INV)
+                    if constexpr (!(INV && NAT))
                         GPUNTT_SMALL(14, 14);
                 }
                 else

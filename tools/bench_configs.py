@@ -265,7 +265,7 @@ def main():
             fourstep_case(g, 64, logn, max(1, 1 << (26 - logn)), max(3, args.iters // 2), "sweep-4step", check=(logn <= 20))
     if args.what == "4stepinv":  # inverse of the reference layout above one tile (A/B: GPUNTT_FOURSTEP_INV_MERGE=0|1)
         for bits in (64, 32):
-            for logn in range(15, 25):
+            for logn in range(14, 25):
                 fourstep_inv_case(g, bits, logn, max(1, 1 << (26 - logn)), max(3, args.iters // 2), "4step-inv-u%d" % bits)
         fourstep_inv_case(g, 64, 24, 64, 5, "C3 4-Step u64 2^24 x64-inv")
     if args.what == "4step32":  # the 32-bit one-launch rings and their neighbours
