@@ -339,11 +339,12 @@ namespace gpuntt
                     return true;
                 }
             }
-            // Inverse, rings from 2^17: the ring's inverse Merge plan with the transposition on its FIRST pass
+            // Inverse, rings from 2^15: the ring's inverse Merge plan with the transposition on its FIRST pass
             // (kern::fourstep_inv_first_lazy: 12 contiguous Gentleman-Sande stages on the spectrum as it lies, stored
             // transposed), then every remaining stage inside the n2-long rows of `out` -- strided inverse passes of an
-            // n2-point ring reading a prefix of the same table, n^-1 folded into its slot 1.  No W stream, no W product,
-            // 2^17 .. 2^20 in two sweeps instead of three.  (2^15 / 2^16 and 61- / 62-bit moduli keep the W form below.)
+            // n2-point ring reading a prefix of the same table (2^15 / 2^16, n2 = 512: one partial contiguous pass, eight
+            // rows per tile), n^-1 folded into its slot 1.  No W stream, no W product, 2^17 .. 2^20 in two sweeps instead
+            // of three.  (61- / 62-bit moduli keep the W form below.)
             if constexpr (INV)
             {
                 int k_a = 0, k_b = 0;
@@ -358,6 +359,7 @@ namespace gpuntt
                         *go_flag_out = go_flag;
                     if (plan.mode == PLAN_PREPARE)
                         return true;
+                    const bool rows512 = (k_a == 0); // 2^15 / 2^16: one partial contiguous pass over the 512-long rows
                     const int passes = k_b != 0 ? 3 : 2;
                     const bool rev = host::lazy_reverse_passes();
                     kern::LazyArgsT<T> f{};
@@ -404,6 +406,20 @@ namespace gpuntt
                         r.ninv = TW{ninv, host::shoup_host(ninv, mod.value)};
                     else
                         r.ninv_arr = ws_ninv;
+                    if (rows512)
+                    {
+                        r.flags = host::lazy_order_flags();
+                        if constexpr (sizeof(T) == 4)
+                        {
+                            if (wide32)
+                                host::launch_fourstep_inv_rows_lazy<T, 8>(12 - log_n1, r, stream);
+                            else
+                                host::launch_fourstep_inv_rows_lazy<T, 0>(12 - log_n1, r, stream);
+                        }
+                        else
+                            host::launch_fourstep_inv_rows_lazy<T, 0>(12 - log_n1, r, stream);
+                        return true;
+                    }
                     const host::Pass pa{false, k_a, 12 - log_n1};
                     const host::Pass pb{false, k_b, 12 - log_n1 + k_a};
                     for (int i = 1; i < passes; i++)

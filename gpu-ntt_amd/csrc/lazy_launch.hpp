@@ -154,12 +154,24 @@ namespace gpuntt
         extern template void launch_fourstep_inv_first_lazy<uint64_t, 0>(int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
         extern template void launch_fourstep_inv_first_lazy<uint32_t, 0>(int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
         extern template void launch_fourstep_inv_first_lazy<uint32_t, 8>(int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
+        // rings 2^15 / 2^16 (n2 = 512): the remaining 3 / 4 stages are the top stages of the 512-long rows -- one partial
+        // contiguous pass (kern::PassSched SKIP = 12 - log_n1 = 6 / 5), eight rows per tile
+        template <typename T, int LIMSEL = 0>
+        void launch_fourstep_inv_rows_lazy(int skip, const kern::LazyArgsT<T>& a, hipStream_t stream);
+        extern template void launch_fourstep_inv_rows_lazy<uint64_t, 0>(int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
+        extern template void launch_fourstep_inv_rows_lazy<uint32_t, 0>(int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
+        extern template void launch_fourstep_inv_rows_lazy<uint32_t, 8>(int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
         // Stage split of the strided row passes behind it: s = n - 12 stages on the bits above the first pass, as one pass
         // (s <= 8) or two; the first of them starts at row bit 12 - log_n1 and keeps 2^(12 - k) contiguous words per tile
         // row, so k >= log_n1.  false: the shape has no such plan (2^15, 2^16: fewer stages left than log_n1)
         inline bool fourstep_inv_merge_split(int n_power, int log_n1, int& k_a, int& k_b)
         {
             const int s = n_power - 12;
+            if ((n_power == 15 || n_power == 16) && n_power - log_n1 == 9)
+            {
+                k_a = k_b = 0; // one partial contiguous row pass (launch_fourstep_inv_rows_lazy)
+                return true;
+            }
             if (n_power < 17 || n_power > LAZY_MAX_N_POWER || s < log_n1 || s > 16)
                 return false;
             if (s <= 8)

@@ -308,6 +308,29 @@ namespace gpuntt
             GPUNTT_HIP_CHECK(hipGetLastError());
         }
 
+        // inverse 4-step of the rings 2^15 / 2^16 (n2 = 512): the stages the first pass left -- row bits [skip, 9) of the
+        // 512-long rows of `out`, eight rows per tile, one register round, no LDS; last pass of the transform
+        template <typename T, int LIMSEL>
+        void launch_fourstep_inv_rows_lazy(int skip, const kern::LazyArgsT<T>& a, hipStream_t stream)
+        {
+            constexpr int LIM = lazy::Mod<T, LIMSEL>::LIMIT;
+            const unsigned long long tiles = a.total >> 12;
+            if (tiles == 0)
+                return;
+            if (tiles > 0x7fffffffull)
+                throw std::invalid_argument("batch_size * N too large for one launch");
+            const unsigned grid = static_cast<unsigned>(tiles);
+            if (skip == 5)
+                hipLaunchKernelGGL((kern::merge_pass_lazy<T, 12, true, true, 9, LIM / 2, true, LIMSEL, 5>), dim3(grid),
+                                   dim3(kern::LTile<12>::NT), 0, stream, a);
+            else if (skip == 6)
+                hipLaunchKernelGGL((kern::merge_pass_lazy<T, 12, true, true, 9, LIM / 2, true, LIMSEL, 6>), dim3(grid),
+                                   dim3(kern::LTile<12>::NT), 0, stream, a);
+            else
+                throw std::invalid_argument("internal: bad 4-step row pass");
+            GPUNTT_HIP_CHECK(hipGetLastError());
+        }
+
         // 4-step transform of a ring that fits one tile: the whole transform in one launch (fourstep_small_lazy);
         // natural: the natural-order extension (spectrum side in NTT_4STEP_CPU order)
         template <typename T, bool INV, bool NAT>

@@ -137,11 +137,14 @@ namespace gpuntt
         };
 
         // ---- compile-time schedule of range corrections for one pass --------------------
-        template <int TLOG, bool INV, bool CONTIG, int K, int IN_BOUND, int LIMIT, int TB> struct PassSched
+        // SKIP (inverse contiguous passes only): the pass runs the stages on tile bits [SKIP, K) -- the low SKIP stages of
+        // the K-bit rows were done by the pass before it (inverse 4-step of the rings 2^15 / 2^16 in Merge form)
+        template <int TLOG, bool INV, bool CONTIG, int K, int IN_BOUND, int LIMIT, int TB, int SKIP = 0> struct PassSched
         {
             using G = LGeo<TLOG, CONTIG, K>;
+            static_assert(SKIP == 0 || (INV && CONTIG && SKIP < K), "partial passes: inverse, contiguous");
             static constexpr int TL = TLOG;
-            static constexpr int NR = G::NR;
+            static constexpr int NR = (K - SKIP + R - 1) / R;
             struct Data
             {
                 int ku[NR][R][EPT / 2];
@@ -158,7 +161,7 @@ namespace gpuntt
             // 16-contiguous-coefficient round always owns distances 1,2,4,8 and windows of STRIDED
             // passes never dip below the contiguous-run bits (lanes of a wave then differ only in
             // those bits and every twiddle of the pass is wave-uniform).
-            static constexpr int SHORT = K - R * (NR - 1);
+            static constexpr int SHORT = (K - SKIP) - R * (NR - 1);
             static constexpr int stages_of(int r)
             {
                 return INV ? ((r == NR - 1) ? SHORT : R) : ((r == 0) ? SHORT : R);
@@ -166,7 +169,7 @@ namespace gpuntt
             static constexpr int first_pos(int r)
             {
                 if (INV)
-                    return G::L + r * R;
+                    return G::L + SKIP + r * R;
                 return (r == 0) ? (G::L + K - 1) : (G::L + K - 1 - SHORT - (r - 1) * R);
             }
             static constexpr int wl_of(int r)
@@ -352,7 +355,7 @@ namespace gpuntt
         }
 
         template <typename T, int TLOG, bool EXACT, bool INV, bool CONTIG, int K, int IN_BOUND, bool LAST,
-                  int FST = 0, int LIM = 0, int XP = 0>
+                  int FST = 0, int LIM = 0, int XP = 0, int SKIP = 0>
         __device__ __forceinline__ void pass_body(const LazyArgsT<T>& a, T* lds, T q_value, T q_bit, T q_mu,
                                                   int mi, unsigned long long fst_poly = 0,
                                                   unsigned fst_tile = 0, long long blk_override = -1,
@@ -360,10 +363,11 @@ namespace gpuntt
         {
             using G = LGeo<TLOG, CONTIG, K>;
             using M = lazy::Mod<T, LIM>;
-            using SCH = PassSched<TLOG, INV, CONTIG, K, IN_BOUND, M::LIMIT, M::TB>;
+            using SCH = PassSched<TLOG, INV, CONTIG, K, IN_BOUND, M::LIMIT, M::TB, SKIP>;
             using TW = lazy::Tw<T>;
             constexpr int TL = TLOG;
             constexpr int NT = LTile<TLOG>::NT;
+            constexpr int NR_ = SCH::NR;
 
             // single-pass transforms of rings smaller than a tile: the tile holds several polynomials
             constexpr bool MULTI_POLY = CONTIG && (K < TL) && (IN_BOUND == 1) && (LAST || FST);
@@ -494,7 +498,7 @@ namespace gpuntt
             if constexpr (TW_AHEAD)
                 load_twiddles(std::integral_constant<int, 0>{}, tw_next);
 
-            static_for<G::NR>([&](auto r_) {
+            static_for<NR_>([&](auto r_) {
                 constexpr int r = decltype(r_)::value;
                 constexpr int STAGES = SCH::stages_of(r);
                 constexpr int FIRST_POS = SCH::first_pos(r);
@@ -816,7 +820,7 @@ namespace gpuntt
                             // final stage of an inverse transform: its twiddle was prepared as
                             // w * n^-1, so scaling the sum as well finishes the n^-1 product (the product
                             // takes any 64-bit value: no range correction of the sum there)
-                            if constexpr (LAST && r == G::NR - 1 && s == STAGES - 1)
+                            if constexpr (LAST && r == NR_ - 1 && s == STAGES - 1)
                                 v[j0] = m.template mul<true>(U + V, ninv);
                             else
                             {
@@ -833,7 +837,7 @@ namespace gpuntt
                 });
 
                 // ---- scatter ----------------------------------------------------------
-                if constexpr (r == G::NR - 1)
+                if constexpr (r == NR_ - 1)
                 {
                     constexpr bool PMUL_OK = LAST && !INV && !FST && !EXACT;
                     const T* mul_in = PMUL_OK ? a.mul_in : nullptr;
@@ -1080,7 +1084,7 @@ namespace gpuntt
 #pragma unroll
                     for (int j = 0; j < EPT; j++)
                         lw[lds_joff<WL>(j)] = v[j];
-                    if constexpr (!EXACT && WL <= 6 && SCH::wl_of(r + 1 < G::NR ? r + 1 : r) <= 6)
+                    if constexpr (!EXACT && WL <= 6 && SCH::wl_of(r + 1 < NR_ ? r + 1 : r) <= 6)
                         wave_sync(); // both windows inside the wave's sub-block
                     else
                         __syncthreads();
@@ -1113,14 +1117,13 @@ namespace gpuntt
             }
         }
 
-        template <typename T, int TLOG, bool INV, bool CONTIG, int K, int IN_BOUND, bool LAST, int LIM = 0>
+        template <typename T, int TLOG, bool INV, bool CONTIG, int K, int IN_BOUND, bool LAST, int LIM = 0, int SKIP = 0>
         __global__ __launch_bounds__(LTile<TLOG>::NT, (LOcc<TLOG, T>::WAVES)) void merge_pass_lazy(LazyArgsT<T> a)
         {
-            using G = LGeo<TLOG, CONTIG, K>;
             using M = lazy::Mod<T, LIM>;
-            using SCH = PassSched<TLOG, INV, CONTIG, K, IN_BOUND, M::LIMIT, M::TB>;
+            using SCH = PassSched<TLOG, INV, CONTIG, K, IN_BOUND, M::LIMIT, M::TB, SKIP>;
             // single-round passes with coalesced register windows never touch LDS
-            constexpr bool NEEDS_LDS = (G::NR > 1) || (SCH::wl_of(0) < 4);
+            constexpr bool NEEDS_LDS = (SCH::NR > 1) || (SCH::wl_of(0) < 4);
             __shared__ T lds[NEEDS_LDS ? LTile<TLOG>::LDS_ELEMS : 1];
 
             // RNS calls: the twiddle-prep kernel publishes whether every modulus has the lazy
@@ -1156,8 +1159,7 @@ namespace gpuntt
                 qb = md.bit;
                 qm = md.mu;
             }
-            pass_body<T, TLOG, false, INV, CONTIG, K, IN_BOUND, LAST, 0, LIM>(a, lds, qv, qb, qm, mi, 0,
-                                                                                                   0, blk);
+            pass_body<T, TLOG, false, INV, CONTIG, K, IN_BOUND, LAST, 0, LIM, 0, SKIP>(a, lds, qv, qb, qm, mi, 0, 0, blk);
         }
 
         // block -> (polynomial, tile of the polynomial) for the transposing row passes of the natural-order 4-step: tile =
