@@ -103,7 +103,7 @@ ENV_OPTIONS = {"GPUNTT_PATH": ("path", None), "GPUNTT_CONTIG_K": ("contig_k", No
                "GPUNTT_XCD_ORDER": ("xcd_order", None), "GPUNTT_LIM31": ("lim31", None),
                "GPUNTT_NO_REVERSE": ("reverse", lambda v: "0" if v not in ("", "0") else "1"),
                "GPUNTT_U64_BIG_TILES": ("u64_big_tiles", None), "GPUNTT_U32_TILE": ("u32_tile", None),
-               "GPUNTT_FOURSTEP_INV_MERGE": ("fourstep_inv_merge", None)}
+               }
 
 
 def set_option(name, value):

@@ -3,14 +3,17 @@
 // Replaces reference src/lib/ntt_4step/ntt_4step.cu:36-66 (transpose), :68-2291 (kernels),
 // :2293-3229 (hosts), :3292-3302 / :3606-3634 (exported instantiations).
 //
-// MI355X plan for N = n1 x n2 (shapes of NTTParameters4Step, nttparameters.cu:305-354):
-//   phase 1  one fused kernel: n1-point transform of every row of the n2 x n1 input inside a
-//            4096-coefficient tile, transposed store into the n1 x n2 output with the
-//            W[i*n2+j] multiply fused (merge_pass<..., FST=true>)
-//   phase 2  the n2-point row transforms are exactly a Merge transform of length n2 over
-//            batch*n1 rows with the n2 table -> the shared tile-pass planner (launch.hpp);
-//            the inverse applies cfg.mod_inverse (= N^-1) in its last pass.
-// => 2 sweeps for n2 <= 4096, 3 sweeps up to N = 2^24 (the reference also needs 2-3).
+// MI355X plan for N = n1 x n2 (shapes of NTTParameters4Step, nttparameters.cu:305-354): the 4-step transform IS the
+// Merge transform of the ring with a transposition on the natural-order side, so the fast path runs the
+// ring's own Merge plan from a Merge table rebuilt on the device out of the caller's n1 / W tables:
+//   forward  in = x^T (n2 x n1): the first strided pass gathers the transposed input (fourstep_first_lazy), the rest is
+//            the Merge plan as it stands; out = the bit-reversed Merge spectrum = the reference's n1 x n2 output;
+//   inverse  in = that spectrum: the first contiguous pass (12 Gentleman-Sande stages) stores transposed
+//            (fourstep_inv_first_lazy), the remaining stages are strided / partial row passes inside the n2-long rows;
+//   rings that fit one tile (2^12 .. 2^14) take ONE launch with the transposition in LDS (fourstep_small_lazy).
+// => 1 sweep to 2^14, 2 sweeps to 2^20 (2^22 forward), 3 sweeps to 2^24; no W stream, no W product.  The generic
+// (Barrett) fall-back keeps the reference's two-phase form: phase 1 with the fused W multiply (merge_pass<..., FST>),
+// phase 2 = the n2-point row transforms through the shared planner (launch.hpp).
 //
 // Extension GPU_4STEP_NTT_NaturalOrder: the reference examples' GPU_Transpose -> GPU_4STEP_NTT ->
 // GPU_Transpose pipeline as one call in three sweeps (fourstep_natural_forward_lazy /
@@ -204,17 +207,13 @@ namespace gpuntt
                                  host::lazy_workspace(stream, sizeof(TW) * pairs + 16 + sizeof(lazy::NormConst), true));
             if (ws == nullptr)
                 return false; // no device memory for the scratch: the generic kernels need none
-            TW* ws_n1 = ws;
+            // (the n1 / n2 regions held the stage tables of the two-phase W form of rounds 1-3; every plan now reads the
+            // ring's Merge table in the W region -- the layout stays so that FourStepPlan::workspace_bytes does)
             TW* ws_w = ws + n1;
-            TW* ws_n2 = ws + n1 + n;
             TW* ws_ninv = ws + n1 + n + n2;
             unsigned char* tail = reinterpret_cast<unsigned char*>(ws + pairs);
             unsigned* go_flag = mods_dev ? reinterpret_cast<unsigned*>(tail) : nullptr;
             auto* norm_arr = mods_dev ? reinterpret_cast<lazy::NormConst*>(tail + 16) : nullptr;
-            const int tl2 = lim != 0 ? 12 // the LIMIT = 8 / 4 kernels exist for 4096-coefficient tiles only
-                            : plan.mode != PLAN_NONE
-                                ? plan.tile_log
-                                : host::lazy_tile_log<T>(log_n2, INV, static_cast<unsigned long long>(batch_size) << log_n1);
             // Rings that fit one tile (2^12 .. 2^14): the 4-step transform is the Merge transform of the ring with its
             // natural-order side transposed, so ONE contiguous pass does it -- Merge table rebuilt from the caller's
             // tables into the W region of the workspace, transposition in LDS (kern::fourstep_small_lazy)
@@ -348,8 +347,7 @@ namespace gpuntt
             if constexpr (INV)
             {
                 int k_a = 0, k_b = 0;
-                if (lim == 0 && host::fourstep_inv_merge_enabled() &&
-                    host::fourstep_inv_merge_split(n_power, log_n1, k_a, k_b))
+                if (host::fourstep_inv_merge_split(n_power, log_n1, k_a, k_b))
                 {
                     if (plan.mode != PLAN_EXECUTE)
                         host::launch_prep_merge_from_fourstep<T>(n1_table, w_table, ws_w, log_n1, log_n2, 12, true, true,
@@ -395,7 +393,14 @@ namespace gpuntt
                             host::launch_fourstep_inv_first_lazy<T, 0>(log_n1, f, stream);
                     }
                     else
-                        host::launch_fourstep_inv_first_lazy<T, 0>(log_n1, f, stream);
+                    {
+                        if (lim == 8)
+                            host::launch_fourstep_inv_first_lazy<T, 8>(log_n1, f, stream);
+                        else if (lim == 4)
+                            host::launch_fourstep_inv_first_lazy<T, 4>(log_n1, f, stream);
+                        else
+                            host::launch_fourstep_inv_first_lazy<T, 0>(log_n1, f, stream);
+                    }
 
                     kern::LazyArgsT<T> r = f;
                     r.in = out;
@@ -412,12 +417,19 @@ namespace gpuntt
                         if constexpr (sizeof(T) == 4)
                         {
                             if (wide32)
-                                host::launch_fourstep_inv_rows_lazy<T, 8>(12 - log_n1, r, stream);
+                                host::launch_fourstep_inv_rows_lazy<T, 8>(log_n2, 12 - log_n1, r, stream);
                             else
-                                host::launch_fourstep_inv_rows_lazy<T, 0>(12 - log_n1, r, stream);
+                                host::launch_fourstep_inv_rows_lazy<T, 0>(log_n2, 12 - log_n1, r, stream);
                         }
                         else
-                            host::launch_fourstep_inv_rows_lazy<T, 0>(12 - log_n1, r, stream);
+                        {
+                            if (lim == 8)
+                                host::launch_fourstep_inv_rows_lazy<T, 8>(log_n2, 12 - log_n1, r, stream);
+                            else if (lim == 4)
+                                host::launch_fourstep_inv_rows_lazy<T, 4>(log_n2, 12 - log_n1, r, stream);
+                            else
+                                host::launch_fourstep_inv_rows_lazy<T, 0>(log_n2, 12 - log_n1, r, stream);
+                        }
                         return true;
                     }
                     const host::Pass pa{false, k_a, 12 - log_n1};
@@ -439,81 +451,20 @@ namespace gpuntt
                                 host::launch_pass_lazy<T, true>(p, 12, false, last, x, stream);
                         }
                         else
-                            host::launch_pass_lazy<T, true>(p, 12, false, last, x, stream);
+                        {
+                            if (lim == 8)
+                                host::launch_pass_lazy_lim<true, 8>(p, false, last, x, stream);
+                            else if (lim == 4)
+                                host::launch_pass_lazy_lim<true, 4>(p, false, last, x, stream);
+                            else
+                                host::launch_pass_lazy<T, true>(p, 12, false, last, x, stream);
+                        }
                     }
                     return true;
                 }
             }
-            // one preparation launch; inverse: n^-1 rides on the last row stage (fold = 2)
-            if (plan.mode != PLAN_EXECUTE)
-                host::launch_prep_fourstep<T>(n1_table, n2_table, w_table, ws_n1, ws_w, ws_n2, log_n1, log_n2,
-                                              (log_n2 >= tl2) ? tl2 : 0, INV ? 2 : 0, mod.value, ninv, mods_dev,
-                                              (INV && mods_dev) ? ninv_dev : nullptr, ws_ninv, go_flag, norm_arr,
-                                              stream);
-            if (go_flag_out != nullptr)
-                *go_flag_out = go_flag;
-            if (plan.mode == PLAN_PREPARE)
-                return true;
-
-            kern::LazyArgsT<T> a{};
-            a.in = in;
-            a.out = out;
-            a.tw = ws_n1;
-            a.mods = mods_dev;
-            a.q = mod.value;
-            a.q_bit = mod.bit;
-            a.q_mu = mod.mu;
-            a.ninv_arr = nullptr;
-            a.ninv = TW{0, 0};
-            a.go_flag = go_flag;
-            a.norm = lazy::make_norm_const(static_cast<uint64_t>(mod.value), static_cast<uint64_t>(mod.bit));
-            a.norm_arr = norm_arr;
-            a.w_pairs = ws_w;
-            a.n2_log = log_n2;
-            a.batch = batch_size;
-            a.total = static_cast<unsigned long long>(batch_size) << n_power;
-            a.n = log_n1;
-            a.poly_shift = n_power;
-            a.mod_count = 1;
-            a.p_lo = 0;
-            a.flags = host::lazy_order_flags();
-            if constexpr (INV) // (the forward direction returned above)
-            {
-                if constexpr (sizeof(T) == 8)
-                {
-                    if (lim == 8)
-                        host::launch_fourstep_lim<true, 8>(0, log_n1, a, stream);
-                    else if (lim == 4)
-                        host::launch_fourstep_lim<true, 4>(0, log_n1, a, stream);
-                    else
-                        host::launch_fourstep_phase1_lazy<T, true>(log_n1, a, stream);
-                }
-                else
-                    host::launch_fourstep_phase1_lazy<T, true>(log_n1, a, stream);
-            }
-
-            // phase 2: n2-point transforms of the batch * n1 rows of `out`, in place
-            kern::LazyArgsT<T> b = a;
-            b.in = out;
-            b.tw = ws_n2;
-            b.w_pairs = nullptr;
-            b.n = log_n2;
-            b.poly_shift = log_n2;
-            if (INV && mods_dev == nullptr)
-                b.ninv = TW{ninv, host::shoup_host(ninv, mod.value)};
-            if (INV && mods_dev != nullptr)
-                b.ninv_arr = ws_ninv;
-            b.lim = lim;
-            // forward row passes of a modulus with 31 q < 2^64: the LIMIT = 31 kernels
-            if constexpr (sizeof(T) == 8 && !INV)
-                if (mods_dev == nullptr && host::lazy_lim31_enabled() &&
-                    host::lazy_lim31_modulus(mod.value))
-                    b.lim = 31;
-            if constexpr (sizeof(T) == 4)
-                if (mods_dev == nullptr && host::lazy_lim31_enabled() && host::lazy_wide_modulus32(mod.value))
-                    b.lim = 8;
-            host::run_transform_lazy<T, INV>(b, 0u, 0u, stream, (plan.mode != PLAN_NONE || lim != 0) ? tl2 : 0);
-            return true;
+            // (every ring of the reference's range, 2^12 .. 2^24, has one of the plans above)
+            return false;
         }
 
         // Natural-order transforms (extension) in Merge form.  With x the natural-order polynomial,
@@ -541,7 +492,6 @@ namespace gpuntt
             a.go_flag = nullptr;
             a.norm = lazy::make_norm_const(static_cast<uint64_t>(mod.value), static_cast<uint64_t>(mod.bit));
             a.norm_arr = nullptr;
-            a.w_pairs = nullptr;
             a.n2_log = log_n1;  // row stride of the column-major (n2 x n1) side
             a.row_log = log_n2; // row stride of the row-major (n1 x n2) side
             a.batch = 0;        // plain block order

@@ -107,13 +107,6 @@ namespace gpuntt
         extern template void launch_prep_pairs<uint32_t>(const uint32_t*, lazy::Tw32*, unsigned long long,
                                                          uint32_t, hipStream_t, const Modulus<uint32_t>*);
 
-        // 4-step phase 1 with the W product (fused n1-point transform + W multiply + transposed store), log_n1 in 5..8:
-        // the inverse direction (the forward one is the ring's Merge plan, launch_fourstep_first_lazy)
-        template <typename T, bool INV, int LIMSEL = 0>
-        void launch_fourstep_phase1_lazy(int log_n1, const kern::LazyArgsT<T>& a, hipStream_t stream);
-        extern template void launch_fourstep_phase1_lazy<uint64_t, true>(int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
-        extern template void launch_fourstep_phase1_lazy<uint32_t, true>(int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
-
         // 4-step transform of a ring that fits one tile in one launch: 64-bit 2^12 (tile 12), 2^13 (tile 13), 2^14 forward
         // (tile 14); 32-bit 2^12 (tile 12), 2^13 (tile 13), 2^14 (tile 14).  a.tw = Merge table of the ring
         // (launch_prep_merge_from_fourstep).  fourstep_small_tile: the tile such a call runs on, 0 = ring too large
@@ -154,20 +147,25 @@ namespace gpuntt
         extern template void launch_fourstep_inv_first_lazy<uint64_t, 0>(int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
         extern template void launch_fourstep_inv_first_lazy<uint32_t, 0>(int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
         extern template void launch_fourstep_inv_first_lazy<uint32_t, 8>(int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
-        // rings 2^15 / 2^16 (n2 = 512): the remaining 3 / 4 stages are the top stages of the 512-long rows -- one partial
-        // contiguous pass (kern::PassSched SKIP = 12 - log_n1 = 6 / 5), eight rows per tile
+        extern template void launch_fourstep_inv_first_lazy<uint64_t, 8>(int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
+        extern template void launch_fourstep_inv_first_lazy<uint64_t, 4>(int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
+        // rings 2^13 .. 2^16 (n2 = 256 / 512): the remaining 1 .. 4 stages are the top stages of the n2-long rows -- one
+        // partial contiguous pass (kern::PassSched SKIP = 12 - log_n1 = 7 / 6 / 5), 16 / 8 rows per tile
         template <typename T, int LIMSEL = 0>
-        void launch_fourstep_inv_rows_lazy(int skip, const kern::LazyArgsT<T>& a, hipStream_t stream);
-        extern template void launch_fourstep_inv_rows_lazy<uint64_t, 0>(int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
-        extern template void launch_fourstep_inv_rows_lazy<uint32_t, 0>(int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
-        extern template void launch_fourstep_inv_rows_lazy<uint32_t, 8>(int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
+        void launch_fourstep_inv_rows_lazy(int log_n2, int skip, const kern::LazyArgsT<T>& a, hipStream_t stream);
+        extern template void launch_fourstep_inv_rows_lazy<uint64_t, 0>(int, int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
+        extern template void launch_fourstep_inv_rows_lazy<uint32_t, 0>(int, int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
+        extern template void launch_fourstep_inv_rows_lazy<uint32_t, 8>(int, int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
+        extern template void launch_fourstep_inv_rows_lazy<uint64_t, 8>(int, int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
+        extern template void launch_fourstep_inv_rows_lazy<uint64_t, 4>(int, int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
         // Stage split of the strided row passes behind it: s = n - 12 stages on the bits above the first pass, as one pass
         // (s <= 8) or two; the first of them starts at row bit 12 - log_n1 and keeps 2^(12 - k) contiguous words per tile
         // row, so k >= log_n1.  false: the shape has no such plan (2^15, 2^16: fewer stages left than log_n1)
         inline bool fourstep_inv_merge_split(int n_power, int log_n1, int& k_a, int& k_b)
         {
             const int s = n_power - 12;
-            if ((n_power == 15 || n_power == 16) && n_power - log_n1 == 9)
+            const int l2 = n_power - log_n1, skip = 12 - log_n1;
+            if (n_power >= 13 && n_power <= 16 && ((l2 == 9 && skip >= 5 && skip <= 7) || (l2 == 8 && skip == 7)))
             {
                 k_a = k_b = 0; // one partial contiguous row pass (launch_fourstep_inv_rows_lazy)
                 return true;
@@ -195,20 +193,6 @@ namespace gpuntt
         void launch_fourstep_nat_first_inv_lazy(int k, const kern::LazyArgsT<T>& a, hipStream_t stream);
         extern template void launch_fourstep_nat_first_inv_lazy<uint64_t>(int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
         extern template void launch_fourstep_nat_first_inv_lazy<uint32_t>(int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
-        // everything a 4-step call prepares, in one launch (prep.hip: prep_fourstep)
-        template <typename T>
-        void launch_prep_fourstep(const T* n1_table, const T* n2_table, const T* w_table, lazy::Tw<T>* ws_n1,
-                                  lazy::Tw<T>* ws_w, lazy::Tw<T>* ws_n2, int log_n1, int log_n2, int perm2,
-                                  int fold, T q, T ninv, const Modulus<T>* mods, const T* ninv_dev, lazy::Tw<T>* ws_ninv,
-                                  unsigned* go_flag, lazy::NormConst* norm_arr, hipStream_t stream);
-        extern template void launch_prep_fourstep<uint64_t>(const uint64_t*, const uint64_t*, const uint64_t*, lazy::Tw64*,
-                                                            lazy::Tw64*, lazy::Tw64*, int, int, int, int, uint64_t,
-                                                            uint64_t, const Modulus<uint64_t>*, const uint64_t*, lazy::Tw64*,
-                                                            unsigned*, lazy::NormConst*, hipStream_t);
-        extern template void launch_prep_fourstep<uint32_t>(const uint32_t*, const uint32_t*, const uint32_t*, lazy::Tw32*,
-                                                            lazy::Tw32*, lazy::Tw32*, int, int, int, int, uint32_t,
-                                                            uint32_t, const Modulus<uint32_t>*, const uint32_t*, lazy::Tw32*,
-                                                            unsigned*, lazy::NormConst*, hipStream_t);
         // Merge table of the 4-step ring (bit-reversed powers of its root), rebuilt from the caller's 4-step tables
         // straight into the Merge kernels' stage layout (prep.hip: prep_merge_from_fourstep)
         template <typename T>
@@ -270,7 +254,6 @@ namespace gpuntt
         int lazy_contig_k(int n);
 
         bool lazy_reverse_passes();
-        bool fourstep_inv_merge_enabled(); // option fourstep_inv_merge (A/B timing against the two-phase W form)
         // forward 4-step in Merge form: stages of the first pass (the one that reads the transposed input) -- the first
         // strided pass of the ring's Merge plan on tile `tl`, widened to log2 n1 where that is larger (5 .. 8)
         inline int fourstep_first_k(int n_power, int log_n1, int tl)

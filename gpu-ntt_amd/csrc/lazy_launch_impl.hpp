@@ -231,29 +231,6 @@ namespace gpuntt
 #undef GPUNTT_ONE
         }
 
-        template <typename T, bool INV, int LIMSEL>
-        void launch_fourstep_phase1_lazy(int log_n1, const kern::LazyArgsT<T>& a, hipStream_t stream)
-        {
-            constexpr int TLOG = 12;
-            const unsigned grid = static_cast<unsigned>(a.total >> TLOG);
-            switch (log_n1)
-            {
-#define GPUNTT_CASE(KK)                                                                          \
-    case KK:                                                                                      \
-        hipLaunchKernelGGL((kern::fourstep_phase1_lazy<T, TLOG, INV, KK, LIMSEL>), dim3(grid),    \
-                           dim3(kern::LTile<TLOG>::NT), 0, stream, a);                            \
-        break;
-                GPUNTT_CASE(5)
-                GPUNTT_CASE(6)
-                GPUNTT_CASE(7)
-                GPUNTT_CASE(8)
-#undef GPUNTT_CASE
-                default:
-                    throw std::invalid_argument("internal: bad 4-step n1");
-            }
-            GPUNTT_HIP_CHECK(hipGetLastError());
-        }
-
         // forward 4-step: first strided pass of the Merge plan with the transposed gather, k stages
         template <typename T, int LIMSEL>
         void launch_fourstep_first_lazy(int k, const kern::LazyArgsT<T>& a, hipStream_t stream)
@@ -308,10 +285,10 @@ namespace gpuntt
             GPUNTT_HIP_CHECK(hipGetLastError());
         }
 
-        // inverse 4-step of the rings 2^15 / 2^16 (n2 = 512): the stages the first pass left -- row bits [skip, 9) of the
-        // 512-long rows of `out`, eight rows per tile, one register round, no LDS; last pass of the transform
+        // inverse 4-step of the rings 2^13 .. 2^16 (n2 = 256 / 512): the stages the first pass left -- row bits
+        // [skip, log2 n2) of the rows of `out`, 16 / 8 rows per tile, one register round, no LDS; last pass of the transform
         template <typename T, int LIMSEL>
-        void launch_fourstep_inv_rows_lazy(int skip, const kern::LazyArgsT<T>& a, hipStream_t stream)
+        void launch_fourstep_inv_rows_lazy(int log_n2, int skip, const kern::LazyArgsT<T>& a, hipStream_t stream)
         {
             constexpr int LIM = lazy::Mod<T, LIMSEL>::LIMIT;
             const unsigned long long tiles = a.total >> 12;
@@ -320,14 +297,20 @@ namespace gpuntt
             if (tiles > 0x7fffffffull)
                 throw std::invalid_argument("batch_size * N too large for one launch");
             const unsigned grid = static_cast<unsigned>(tiles);
-            if (skip == 5)
-                hipLaunchKernelGGL((kern::merge_pass_lazy<T, 12, true, true, 9, LIM / 2, true, LIMSEL, 5>), dim3(grid),
-                                   dim3(kern::LTile<12>::NT), 0, stream, a);
-            else if (skip == 6)
-                hipLaunchKernelGGL((kern::merge_pass_lazy<T, 12, true, true, 9, LIM / 2, true, LIMSEL, 6>), dim3(grid),
-                                   dim3(kern::LTile<12>::NT), 0, stream, a);
+#define GPUNTT_ROWS(K_, S_)                                                                                                \
+    hipLaunchKernelGGL((kern::merge_pass_lazy<T, 12, true, true, K_, LIM / 2, true, LIMSEL, S_>), dim3(grid),               \
+                       dim3(kern::LTile<12>::NT), 0, stream, a)
+            if (log_n2 == 9 && skip == 5)
+                GPUNTT_ROWS(9, 5);
+            else if (log_n2 == 9 && skip == 6)
+                GPUNTT_ROWS(9, 6);
+            else if (log_n2 == 9 && skip == 7)
+                GPUNTT_ROWS(9, 7);
+            else if (log_n2 == 8 && skip == 7)
+                GPUNTT_ROWS(8, 7);
             else
                 throw std::invalid_argument("internal: bad 4-step row pass");
+#undef GPUNTT_ROWS
             GPUNTT_HIP_CHECK(hipGetLastError());
         }
 
@@ -427,14 +410,11 @@ namespace gpuntt
             }
             GPUNTT_HIP_CHECK(hipGetLastError());
         }
-        // 4-step kernels for 64-bit words with a 61- / 62-bit modulus (LIMIT = 8 / 4): what = 0 phase 1 with the W
-        // product (inverse), 1 first pass of the forward Merge plan (log_n1 = its stage count), 2 the one-launch 2^12 ring
+        // 4-step kernels for 64-bit words with a 61- / 62-bit modulus (LIMIT = 8 / 4): what = 1 first pass of the forward
+        // Merge plan (log_n1 = its stage count), 2 the one-launch 2^12 ring
         template <bool INV, int LIMSEL>
         void launch_fourstep_lim(int what, int log_n1, const kern::LazyArgsT<uint64_t>& a, hipStream_t stream)
         {
-            if constexpr (INV)
-                if (what == 0)
-                    return launch_fourstep_phase1_lazy<uint64_t, true, LIMSEL>(log_n1, a, stream);
             if constexpr (!INV)
                 if (what == 1)
                     return launch_fourstep_first_lazy<uint64_t, LIMSEL>(log_n1, a, stream);

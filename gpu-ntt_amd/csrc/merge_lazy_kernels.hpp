@@ -35,9 +35,8 @@ namespace gpuntt
             const int* mod_order;            // *_Modulus_Ordered: prime of slot mi is mod_order[mi]
             const int* poly_order;           // *_Poly_Ordered: polynomial p lives in slot poly_order[p]
             const T* mul_in;                 // GPU_PolyMul: canonical operand multiplied into the final forward store, or nullptr
-            const lazy::Tw<T>* w_pairs;      // 4-step phase 1: prepared W matrix (N pairs)
             int lim;                         // 64-bit words: 0, or 8 / 4 = a 61- / 62-bit modulus in the call -> the LIMIT = 8 / 4 kernels (host-side switch)
-            int n2_log;                      // 4-step phase 1: log2 n2
+            int n2_log;                      // 4-step transposing passes: log2 of the row stride of the transposed side
             int row_log;                     // natural-order 4-step row passes (FST = 2): log2 of the row stride of the row-major side (n2); a.n stays the ring (twiddle indices)
             int batch;                       // > 1: polynomials of the call, blocks are ordered poly-minor (4-step phase 1; big-ring passes)
             unsigned long long total;
@@ -252,13 +251,12 @@ namespace gpuntt
         //                served by the generic kernels (merge_kernels.hpp) instead
         // EXACT = true : canonical residues with the reference's Barrett contract on the same
         //                data movement (kept for experiments)
-        // FST = 4-step phase 1 (reference FourStepForwardCoreT1..4 / FourStepInverseCoreT1..4 plus
-        // the W product, src/lib/ntt_4step/ntt_4step.cu:68-743, 1049-1058, 1177-1872): CONTIG pass
-        // over the rows (length n1 = 2^K) of the n2 x n1 input, stored transposed into the n1 x n2
-        // output with the W multiply fused; output canonical.  Blocks are ordered poly-minor so the
-        // polynomials of a batch that share a slice of W run back to back (W stays in L2).
-        // (inverse direction only: the forward 4-step is the ring's Merge plan with a transposed gather in its first
-        // strided pass, XP = 5 below / fourstep_first_lazy -- no W product, no W stream.)
+        // FST: the transposing passes of the 4-step entry points (reference FourStepForwardCoreT1..4 /
+        // FourStepInverseCoreT1..4 + FourStepPartial*Core, src/lib/ntt_4step/ntt_4step.cu:68-743, 1049-1058, 1177-1872).
+        // Every 4-step transform is the ring's own Merge plan with a transposition on the natural-order side (DESIGN.md
+        // 3.5): the forward one gathers the transposed input in its first strided pass (XP = 5 below /
+        // fourstep_first_lazy), the inverse one stores transposed from its first contiguous pass (FST = 3 /
+        // fourstep_inv_first_lazy); no W product, no W stream.  (FST = 1 was the W-multiplying phase 1 of rounds 1-3.)
         // FST = 2, natural-order 4-step, last forward pass: CONTIG stages on the same 2^K-column range
         // of 2^(TL-K) consecutive rows (lazy input from the strided row passes, or canonical input
         // when the rows fit one pass), canonical output stored transposed (no W product).
@@ -901,9 +899,10 @@ namespace gpuntt
                     else if constexpr (FST && !(SEG && INV))
                     {
                         // FST = 3: the tile is 2^(TL - TK) rows of 2^TK = n1 coefficients (TK = XP - 16), all TL stages of the
-                        // ring's inverse Merge plan done on it; FST = 1, 2: rows of 2^K, K stages
+                        // ring's inverse Merge plan done on it; FST = 2: rows of 2^K, K stages
                         constexpr int TK = (FST == 3) ? (XP - 16) : K;
-                        static_assert(!FST || (CONTIG && TK >= 4 && TK <= 9), "4-step row runs are 16..512 long");
+                        static_assert(FST == 2 || FST == 3, "transposing store: natural-order last pass / inverse first pass");
+                        static_assert(CONTIG && TK >= 4 && TK <= 9, "4-step row runs are 16..512 long");
                         static_assert(FST != 3 || (INV && K == TL && !LAST), "Merge-form inverse first pass");
                         constexpr int RB = TL - TK; // log2 rows per tile
                         pin_loaded(v);
@@ -916,12 +915,10 @@ namespace gpuntt
                         // SEG: output row of tile column i is (seg << K) + i
                         const unsigned long long seg_base =
                             SEG ? ((static_cast<unsigned long long>(fst_seg) << TK) << a.n2_log) : 0ull;
-                        // two halves of 8 keep {coefficient, W pair} in 48 VGPRs instead of 96
 #pragma unroll
                         for (int half = 0; half < 2; half++)
                         {
                             T x[EPT / 2];
-                            TW wv[EPT / 2];
 #pragma unroll
                             for (int jj = 0; jj < EPT / 2; jj++)
                             {
@@ -933,8 +930,6 @@ namespace gpuntt
                                 const unsigned lane = (static_cast<unsigned>(t >> RB) << a.n2_log) + (t & ((1 << RB) - 1));
                                 const unsigned long long ubase =
                                     (static_cast<unsigned long long>((NT >> RB) * jr) << a.n2_log) + row0;
-                                if constexpr (FST == 1)
-                                    wv[jj] = (a.w_pairs + ubase)[lane];
                                 x[jj] = lds[lds_pad_t<TK>((jl << TK) | i)];
                             }
 #pragma unroll
@@ -944,11 +939,8 @@ namespace gpuntt
                                 const unsigned lane = (static_cast<unsigned>(t >> RB) << a.n2_log) + (t & ((1 << RB) - 1));
                                 const unsigned long long ubase =
                                     (static_cast<unsigned long long>((NT >> RB) * jr) << a.n2_log) + row0;
-                                if constexpr (SEG || FST == 3) // (FST = 3: lazy hand-over to the strided row passes)
-                                    (a.out + ((fst_poly << a.poly_shift) + seg_base + ubase))[lane] = x[jj];
-                                else
-                                    (a.out + ((fst_poly << a.poly_shift) + ubase))[lane] =
-                                        lazy::normalize<M::TB>(m, m.mul(x[jj], wv[jj]));
+                                // (FST = 2: canonical; FST = 3: lazy hand-over to the row passes)
+                                (a.out + ((fst_poly << a.poly_shift) + seg_base + ubase))[lane] = x[jj];
                             }
                         }
                     }
@@ -1292,27 +1284,6 @@ namespace gpuntt
             }
             pass_body<T, TLOG, false, INV, true, K, 1, true, 0, LIM, NAT ? (INV ? 4 : 3) : (INV ? 2 : 1)>(
                 a, lds, qv, qb, qm, 0, 0, 0, static_cast<long long>(blockIdx.x));
-        }
-
-        // 4-step phase 1 kernel; grid = batch * N / TILE blocks, block b -> (tile b / batch, poly b % batch)
-        template <typename T, int TLOG, bool INV, int K, int LIM = 0>
-        __global__ __launch_bounds__(LTile<TLOG>::NT, (LOcc<TLOG, T>::WAVES)) void fourstep_phase1_lazy(LazyArgsT<T> a)
-        {
-            __shared__ T lds[LTile<TLOG>::LDS_ELEMS_FST];
-            // RNS overload with one device-side modulus: go-flag + modulus from memory (see merge_pass_lazy)
-            if (a.go_flag != nullptr && *a.go_flag == 0u)
-                return;
-            T qv = a.q, qb = a.q_bit, qm = a.q_mu;
-            if (a.mods != nullptr)
-            {
-                const Modulus<T> md = a.mods[0];
-                qv = md.value;
-                qb = md.bit;
-                qm = md.mu;
-            }
-            unsigned poly, tile;
-            poly_minor_order(blockIdx.x, static_cast<unsigned>(a.batch), a.poly_shift - TLOG, poly, tile, a.flags);
-            pass_body<T, TLOG, false, INV, true, K, 1, false, 1, LIM>(a, lds, qv, qb, qm, 0, poly, tile);
         }
 
     } // namespace kern

@@ -188,91 +188,6 @@ namespace gpuntt
             const T w = src[gid];
             dst[gid] = lazy::Tw<T>{w, shoup_quotient_r<T>(w, q, rinv)};
         }
-        // One launch for everything a 4-step call prepares (single modulus; cyclic tables):
-        //   ws_n1[0, n1)  stage layout of the n1 table | ws_w[0, N)  W pairs (optionally with both
-        //   matrix indices bit-reversed, see prep_pairs_brev) | ws_n2[0, n2)  stage layout of the n2
-        //   table (perm2 = tile size of the contiguous row pass or 0).
-        // fold: 0 none, 1 = n^-1 into the last-stage twiddle of the n1 table, 2 = of the n2 table.
-        // mods != nullptr: the modulus (and ninv_dev[0]) live in device memory; thread 0 classifies it
-        // (go_flag, norm_arr) and publishes the n^-1 pair in ws_ninv.
-        template <typename T>
-        __device__ __forceinline__ void prep_table_entry(const T* __restrict__ roots, lazy::Tw<T>* __restrict__ ws,
-                                                         unsigned slot, int n, int perm_tile_log, T q, T rinv,
-                                                         bool fold, T ninv)
-        {
-            if (slot == 0)
-            {
-                ws[0] = lazy::Tw<T>{0, 0};
-                return;
-            }
-            const int S = 31 - __clz(slot);
-            unsigned i = slot - (1u << S);
-            const int P = n - 1 - S;
-            if (perm_tile_log > 0 && P <= 2)
-            {
-                const int nt_log = perm_tile_log - 4;
-                const int rp_log = 3 - P;
-                const unsigned tile = i >> (rp_log + nt_log), rem = i & ((1u << (rp_log + nt_log)) - 1u);
-                const unsigned kk = rem >> nt_log, t = rem & ((1u << nt_log) - 1u);
-                i = (tile << (rp_log + nt_log)) + (t << rp_log) + kk;
-            }
-            T w = roots[i];
-            if (fold && slot == 1)
-                w = mulmod_r<T>(w, ninv, q, rinv);
-            ws[slot] = lazy::Tw<T>{w, shoup_quotient_r<T>(w, q, rinv)};
-        }
-
-        template <typename T>
-        __global__ __launch_bounds__(256) void prep_fourstep(const T* __restrict__ n1_table, const T* __restrict__ n2_table,
-                                                             const T* __restrict__ w_table, lazy::Tw<T>* __restrict__ ws_n1,
-                                                             lazy::Tw<T>* __restrict__ ws_w, lazy::Tw<T>* __restrict__ ws_n2,
-                                                             int log_n1, int log_n2, int perm2, int fold,
-                                                             T q_single, T rinv_single, T ninv_single,
-                                                             const Modulus<T>* __restrict__ mods,
-                                                             const T* __restrict__ ninv_dev, lazy::Tw<T>* __restrict__ ws_ninv,
-                                                             unsigned* __restrict__ go_flag,
-                                                             lazy::NormConst* __restrict__ norm_arr)
-        {
-            const unsigned long long gid = blockIdx.x * 256ull + threadIdx.x;
-            __shared__ T s_rinv;
-            T q = q_single, rinv = rinv_single;
-            if (mods != nullptr)
-            {
-                const Modulus<T> md = mods[0];
-                q = md.value;
-                if (threadIdx.x == 0)
-                    s_rinv = recip_norm<T>(q);
-                __syncthreads();
-                rinv = s_rinv;
-                if (gid == 0)
-                {
-                    if (go_flag != nullptr)
-                        *go_flag = (md.bit > static_cast<T>(lazy::Mod<T>::MAX_BIT) || md.value < 3) ? 0u : 1u;
-                    if (norm_arr != nullptr)
-                        norm_arr[0] = lazy::make_norm_const(md.value, md.bit);
-                }
-            }
-            const T ninv = (ninv_dev != nullptr) ? ninv_dev[0] : ninv_single;
-            if (gid == 0 && ninv_dev != nullptr && ws_ninv != nullptr)
-                ws_ninv[0] = lazy::Tw<T>{ninv, shoup_quotient_r<T>(ninv, q, rinv)};
-            const unsigned long long n1 = 1ull << log_n1, n2 = 1ull << log_n2, n = 1ull << (log_n1 + log_n2);
-            if (gid < n1)
-            {
-                prep_table_entry<T>(n1_table, ws_n1, static_cast<unsigned>(gid), log_n1, 0, q, rinv, fold == 1, ninv);
-            }
-            else if (gid < n1 + n)
-            {
-                const unsigned long long e = gid - n1;
-                const T w = w_table[e];
-                ws_w[e] = lazy::Tw<T>{w, shoup_quotient_r<T>(w, q, rinv)};
-            }
-            else if (gid < n1 + n + n2)
-            {
-                prep_table_entry<T>(n2_table, ws_n2, static_cast<unsigned>(gid - n1 - n), log_n2, perm2, q, rinv,
-                                    fold == 2, ninv);
-            }
-        }
-
         // The 4-step transform IS the Merge transform of the same ring with one transposition on the natural-order
         // side (forward: GPU_4STEP_NTT(in) = MergeNTT(in read as the n2 x n1 transpose of x); inverse: the output is
         // stored transposed), so the Merge kernels can run it from a MERGE table of the ring -- bit-reversed powers of
@@ -282,7 +197,7 @@ namespace gpuntt
         //   forward  Wrow(j) = W[(n1 / 2) * n2 + j]          (W[r * n2 + j] = w^(brev(r, log n1) * j))
         //   inverse  Wrow(j) = W[n2 + brev(j, log n2)]       (W[r * n2 + c] = w^-(r * brev(c, log n2)))
         // (reference table generators: src/lib/common/nttparameters.cu:356-444).  fold: n^-1 into the single twiddle of
-        // the final inverse stage (slot 1).  mods != nullptr: one device-side modulus, classified like prep_fourstep.
+        // the final inverse stage (slot 1).  mods != nullptr: one device-side modulus, classified like prep_twiddles does for an RNS stack.
         template <typename T>
         __global__ __launch_bounds__(256) void prep_merge_from_fourstep(
             const T* __restrict__ n1_table, const T* __restrict__ w_table, lazy::Tw<T>* __restrict__ ws, int log_n1,
@@ -426,7 +341,6 @@ namespace gpuntt
                 std::atomic<int> big_tiles{14}; // largest 64-bit ring done in one big tile
                 std::atomic<int> u32_tile{0};   // 12 | 14: 32-bit tile above 2^14
                 std::atomic<int> no_scratch{0}; // test hook: behave as if the twiddle scratch could not be allocated
-                std::atomic<int> inv_merge{1};  // inverse 4-step above one tile in Merge form (0: the two-phase W form)
             } g_opt;
         } // namespace
 
@@ -458,8 +372,6 @@ namespace gpuntt
                 g_opt.u32_tile = (iv == 12 || iv == 14) ? iv : 0;
             else if (k == "no_scratch")
                 g_opt.no_scratch = iv != 0;
-            else if (k == "fourstep_inv_merge")
-                g_opt.inv_merge = iv != 0;
             else
                 return false;
             return true;
@@ -486,7 +398,6 @@ namespace gpuntt
         }
         bool lazy_lim31_enabled() { return g_opt.lim31.load(std::memory_order_relaxed) != 0; }
         bool lazy_reverse_passes() { return g_opt.reverse.load(std::memory_order_relaxed) != 0; }
-        bool fourstep_inv_merge_enabled() { return g_opt.inv_merge.load(std::memory_order_relaxed) != 0; }
         int lazy_u64_big_tiles() { return g_opt.big_tiles.load(std::memory_order_relaxed); }
         int lazy_u32_tile_override() { return g_opt.u32_tile.load(std::memory_order_relaxed); }
 
@@ -565,29 +476,6 @@ namespace gpuntt
                                mods ? static_cast<T>(0) : recip_norm_host<T>(q), mods);
             GPUNTT_HIP_CHECK(hipGetLastError());
         }
-        template <typename T>
-        void launch_prep_fourstep(const T* n1_table, const T* n2_table, const T* w_table, lazy::Tw<T>* ws_n1,
-                                  lazy::Tw<T>* ws_w, lazy::Tw<T>* ws_n2, int log_n1, int log_n2, int perm2,
-                                  int fold, T q, T ninv, const Modulus<T>* mods, const T* ninv_dev, lazy::Tw<T>* ws_ninv,
-                                  unsigned* go_flag, lazy::NormConst* norm_arr, hipStream_t stream)
-        {
-            const unsigned long long count = (1ull << log_n1) + (1ull << (log_n1 + log_n2)) + (1ull << log_n2);
-            const unsigned grid = static_cast<unsigned>((count + 255) / 256);
-            hipLaunchKernelGGL((kern::prep_fourstep<T>), dim3(grid), dim3(256), 0, stream, n1_table, n2_table, w_table,
-                               ws_n1, ws_w, ws_n2, log_n1, log_n2, perm2, fold, q,
-                               mods ? static_cast<T>(0) : recip_norm_host<T>(q), ninv, mods, ninv_dev, ws_ninv, go_flag,
-                               norm_arr);
-            GPUNTT_HIP_CHECK(hipGetLastError());
-        }
-        template void launch_prep_fourstep<uint64_t>(const uint64_t*, const uint64_t*, const uint64_t*, lazy::Tw64*,
-                                                     lazy::Tw64*, lazy::Tw64*, int, int, int, int, uint64_t, uint64_t,
-                                                     const Modulus<uint64_t>*, const uint64_t*, lazy::Tw64*, unsigned*,
-                                                     lazy::NormConst*, hipStream_t);
-        template void launch_prep_fourstep<uint32_t>(const uint32_t*, const uint32_t*, const uint32_t*, lazy::Tw32*,
-                                                     lazy::Tw32*, lazy::Tw32*, int, int, int, int, uint32_t, uint32_t,
-                                                     const Modulus<uint32_t>*, const uint32_t*, lazy::Tw32*, unsigned*,
-                                                     lazy::NormConst*, hipStream_t);
-
         template <typename T>
         void launch_prep_merge_from_fourstep(const T* n1_table, const T* w_table, lazy::Tw<T>* ws, int log_n1, int log_n2,
                                              int perm_tile_log, bool inverse, bool fold, T q, T ninv,

@@ -366,3 +366,38 @@ def test_one_launch_rings_every_polynomial_repeatedly(g, bits, logn, batch):
         g.GPU_4STEP_NTT_NaturalOrder(d_out, d_back, *ti, p4.modulus, ci, batch)
         torch.cuda.synchronize()
         assert np.array_equal(g.to_host(d_back), x), ("natural inverse", bits, logn, it)
+
+
+@pytest.mark.parametrize("bits,logn,batch", [(64, 13, 5), (64, 14, 7), (64, 15, 40), (32, 16, 24), (64, 16, 9), (64, 17, 12),
+                                             (32, 20, 5), (64, 21, 3), (32, 22, 2)])
+def test_inverse_in_merge_form_every_polynomial_repeatedly(g, bits, logn, batch):
+    """The inverse 4-step above one tile is the ring's inverse Merge plan with the transposition on its FIRST pass
+    (kern::fourstep_inv_first_lazy) and the remaining stages inside the n2-long rows: one partial contiguous pass for
+    n2 = 256 / 512 (2^13 .. 2^16), one or two strided passes from 2^17.  Every polynomial of multi-tile batches, three
+    times over, both overloads; FourStepPlan must agree with the drop-in call bit for bit."""
+    import torch
+    P = O.Port(bits)
+    p4 = g.NTTParameters4Step(logn, bits)
+    oprm = P.fourstep_params(logn)
+    n = p4.n
+    x = P.splitmix(2300 + logn + batch, 0, batch * n, p4.modulus.value)
+    want = np.concatenate([P.fourstep_ntt(x[p * n:(p + 1) * n], oprm) for p in range(batch)])
+    xin = np.concatenate([P.fourstep_intt_first_transpose(want[p * n:(p + 1) * n], oprm) for p in range(batch)])
+    g.set_option("path", "fast-strict")
+    try:
+        for it in range(3):
+            back = run_fourstep(g, p4, xin, batch, inverse=True, rns=bool(it & 1))
+            assert np.array_equal(back, x), ("inverse", bits, logn, it)
+        ti = [g.to_device(t) for t in p4.tables["inv"]]
+        ci = g.ntt4step_configuration(n_power=logn, ntt_type=g.INVERSE, mod_inverse=p4.n_inv)
+        d_in = g.to_device(xin)
+        d_a, d_b = torch.zeros_like(d_in), torch.zeros_like(d_in)
+        g.GPU_4STEP_NTT(d_in, d_a, *ti, p4.modulus, ci, batch)
+        plan = g.FourStepPlan(*ti, p4.modulus, ci, batch_hint=batch)
+        assert plan.fast_path
+        plan.execute(d_in, d_b, batch)
+        torch.cuda.synchronize()
+        assert torch.equal(d_a, d_b), ("plan == drop-in", bits, logn)
+        plan.close()
+    finally:
+        g.set_option("path", "default")

@@ -263,7 +263,7 @@ def main():
     if args.what == "4step64":  # forward / inverse of the reference layout, every ring size
         for logn in range(12, 25):
             fourstep_case(g, 64, logn, max(1, 1 << (26 - logn)), max(3, args.iters // 2), "sweep-4step", check=(logn <= 20))
-    if args.what == "4stepinv":  # inverse of the reference layout above one tile (A/B: GPUNTT_FOURSTEP_INV_MERGE=0|1)
+    if args.what == "4stepinv":  # inverse of the reference layout above one tile
         for bits in (64, 32):
             for logn in range(14, 25):
                 fourstep_inv_case(g, bits, logn, max(1, 1 << (26 - logn)), max(3, args.iters // 2), "4step-inv-u%d" % bits)
