@@ -347,10 +347,11 @@ namespace gpuntt
             if constexpr (INV)
             {
                 int k_a = 0, k_b = 0;
-                if (host::fourstep_inv_merge_split(n_power, log_n1, k_a, k_b))
+                const int tli = host::fourstep_inv_tile<T>(n_power, lim);
+                if (host::fourstep_inv_merge_split(n_power, log_n1, k_a, k_b, tli))
                 {
                     if (plan.mode != PLAN_EXECUTE)
-                        host::launch_prep_merge_from_fourstep<T>(n1_table, w_table, ws_w, log_n1, log_n2, 12, true, true,
+                        host::launch_prep_merge_from_fourstep<T>(n1_table, w_table, ws_w, log_n1, log_n2, tli, true, true,
                                                                  mod.value, ninv, mods_dev, mods_dev ? ninv_dev : nullptr,
                                                                  ws_ninv, go_flag, norm_arr, stream);
                     if (go_flag_out != nullptr)
@@ -390,7 +391,7 @@ namespace gpuntt
                         if (wide32)
                             host::launch_fourstep_inv_first_lazy<T, 8>(log_n1, f, stream);
                         else
-                            host::launch_fourstep_inv_first_lazy<T, 0>(log_n1, f, stream);
+                            host::launch_fourstep_inv_first_lazy<T, 0>(log_n1, f, stream, tli);
                     }
                     else
                     {
@@ -399,7 +400,7 @@ namespace gpuntt
                         else if (lim == 4)
                             host::launch_fourstep_inv_first_lazy<T, 4>(log_n1, f, stream);
                         else
-                            host::launch_fourstep_inv_first_lazy<T, 0>(log_n1, f, stream);
+                            host::launch_fourstep_inv_first_lazy<T, 0>(log_n1, f, stream, tli);
                     }
 
                     kern::LazyArgsT<T> r = f;
@@ -432,8 +433,8 @@ namespace gpuntt
                         }
                         return true;
                     }
-                    const host::Pass pa{false, k_a, 12 - log_n1};
-                    const host::Pass pb{false, k_b, 12 - log_n1 + k_a};
+                    const host::Pass pa{false, k_a, tli - log_n1};
+                    const host::Pass pb{false, k_b, tli - log_n1 + k_a};
                     for (int i = 1; i < passes; i++)
                     {
                         kern::LazyArgsT<T> x = r;

@@ -143,12 +143,12 @@ namespace gpuntt
         // inverse 4-step in Merge form (kern::fourstep_inv_first_lazy): the 12-stage contiguous first pass of the ring's
         // inverse Merge plan, stored transposed (log_n1 = 5 .. 8); LIMSEL = 8: 32-bit words, moduli below 2^29
         template <typename T, int LIMSEL = 0>
-        void launch_fourstep_inv_first_lazy(int log_n1, const kern::LazyArgsT<T>& a, hipStream_t stream);
-        extern template void launch_fourstep_inv_first_lazy<uint64_t, 0>(int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
-        extern template void launch_fourstep_inv_first_lazy<uint32_t, 0>(int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
-        extern template void launch_fourstep_inv_first_lazy<uint32_t, 8>(int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
-        extern template void launch_fourstep_inv_first_lazy<uint64_t, 8>(int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
-        extern template void launch_fourstep_inv_first_lazy<uint64_t, 4>(int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
+        void launch_fourstep_inv_first_lazy(int log_n1, const kern::LazyArgsT<T>& a, hipStream_t stream, int tile_log = 12);
+        extern template void launch_fourstep_inv_first_lazy<uint64_t, 0>(int, const kern::LazyArgsT<uint64_t>&, hipStream_t, int);
+        extern template void launch_fourstep_inv_first_lazy<uint32_t, 0>(int, const kern::LazyArgsT<uint32_t>&, hipStream_t, int);
+        extern template void launch_fourstep_inv_first_lazy<uint32_t, 8>(int, const kern::LazyArgsT<uint32_t>&, hipStream_t, int);
+        extern template void launch_fourstep_inv_first_lazy<uint64_t, 8>(int, const kern::LazyArgsT<uint64_t>&, hipStream_t, int);
+        extern template void launch_fourstep_inv_first_lazy<uint64_t, 4>(int, const kern::LazyArgsT<uint64_t>&, hipStream_t, int);
         // rings 2^13 .. 2^16 (n2 = 256 / 512): the remaining 1 .. 4 stages are the top stages of the n2-long rows -- one
         // partial contiguous pass (kern::PassSched SKIP = 12 - log_n1 = 7 / 6 / 5), 16 / 8 rows per tile
         template <typename T, int LIMSEL = 0>
@@ -161,8 +161,16 @@ namespace gpuntt
         // Stage split of the strided row passes behind it: s = n - 12 stages on the bits above the first pass, as one pass
         // (s <= 8) or two; the first of them starts at row bit 12 - log_n1 and keeps 2^(12 - k) contiguous words per tile
         // row, so k >= log_n1.  false: the shape has no such plan (2^15, 2^16: fewer stages left than log_n1)
-        inline bool fourstep_inv_merge_split(int n_power, int log_n1, int& k_a, int& k_b)
+        // tl: tile of the first pass (12; 13 for the 64-bit ring 2^21, fourstep_inv_tile)
+        inline bool fourstep_inv_merge_split(int n_power, int log_n1, int& k_a, int& k_b, int tl = 12)
         {
+            if (tl == 13)
+            {
+                // one strided pass of 8 at row bit 13 - log_n1 keeps 2^4 contiguous words: 13 - log_n1 >= 4
+                k_a = n_power - 13;
+                k_b = 0;
+                return n_power == 21 && log_n1 <= 9 && k_a == 8;
+            }
             const int s = n_power - 12;
             const int l2 = n_power - log_n1, skip = 12 - log_n1;
             if (n_power >= 13 && n_power <= 16 && ((l2 == 9 && skip >= 5 && skip <= 7) || (l2 == 8 && skip == 7)))
@@ -183,6 +191,12 @@ namespace gpuntt
                 k_a = log_n1;
             k_b = s - k_a;
             return k_b >= 1 && k_a <= 8;
+        }
+        // tile of the inverse 4-step's first pass: the 64-bit ring 2^21 takes the 8192-coefficient tile (two sweeps, like
+        // its Merge plan: lazy_tile_log), everything else 4096
+        template <typename T> inline int fourstep_inv_tile(int n_power, int lim)
+        {
+            return (sizeof(T) == 8 && n_power == 21 && lim == 0 && lazy_u64_big_tiles() >= 13) ? 13 : 12;
         }
         // natural-order 4-step (extension) in Merge form: strided Merge passes + one transposing row pass
         template <typename T>

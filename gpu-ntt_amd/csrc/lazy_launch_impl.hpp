@@ -260,14 +260,24 @@ namespace gpuntt
 
         // inverse 4-step: first (contiguous, 12-stage) pass of the ring's inverse Merge plan with the transposed store
         template <typename T, int LIMSEL>
-        void launch_fourstep_inv_first_lazy(int log_n1, const kern::LazyArgsT<T>& a, hipStream_t stream)
+        void launch_fourstep_inv_first_lazy(int log_n1, const kern::LazyArgsT<T>& a, hipStream_t stream, int tile_log)
         {
-            const unsigned long long tiles = a.total >> 12;
+            const unsigned long long tiles = a.total >> tile_log;
             if (tiles == 0)
                 return;
             if (tiles > 0x7fffffffull)
                 throw std::invalid_argument("batch_size * N too large for one launch");
             const unsigned grid = static_cast<unsigned>(tiles);
+            if constexpr (sizeof(T) == 8 && LIMSEL == 0)
+                if (tile_log == 13 && log_n1 == 6)
+                {
+                    hipLaunchKernelGGL((kern::fourstep_inv_first_lazy<T, 6, 0, 13>), dim3(grid), dim3(kern::LTile<13>::NT), 0,
+                                       stream, a);
+                    GPUNTT_HIP_CHECK(hipGetLastError());
+                    return;
+                }
+            if (tile_log != 12)
+                throw std::invalid_argument("internal: bad 4-step tile");
             switch (log_n1)
             {
 #define GPUNTT_CASE(KK)                                                                                                   \

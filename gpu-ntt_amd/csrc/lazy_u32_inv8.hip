@@ -11,6 +11,6 @@ void launch_pass_lazy_u32w<true>(const Pass& p, int tile_log, bool in_first, boo
         return dispatch_tl<uint32_t, 14, true, 8>(p, in_first, last, a, stream);
     throw std::invalid_argument("internal: unsupported tile size in the fast path");
 }
-template void launch_fourstep_inv_first_lazy<uint32_t, 8>(int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
+template void launch_fourstep_inv_first_lazy<uint32_t, 8>(int, const kern::LazyArgsT<uint32_t>&, hipStream_t, int);
 template void launch_fourstep_inv_rows_lazy<uint32_t, 8>(int, int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
 } }

@@ -1235,10 +1235,12 @@ namespace gpuntt
         // of a, i.e. inside the n2-long rows of `out`: ordinary strided inverse passes of an n2-point ring (host side:
         // fourstep_run_lazy), whose twiddle slots are a prefix of the ring's own table.  No W stream, no W product.
         // a.n = log2 N, a.n2_log = log2 n2, a.poly_shift = log2 N; blocks in merge_pass_lazy's order.
-        template <typename T, int L1, int LIM = 0>
-        __global__ __launch_bounds__(LTile<12>::NT, (LOcc<12, T>::WAVES)) void fourstep_inv_first_lazy(LazyArgsT<T> a)
+        // TLOG = 13 (64-bit ring 2^21): the 8192-coefficient tile does 13 stages, which leaves one strided pass of 8 --
+        // two sweeps, like the Merge plan of that ring
+        template <typename T, int L1, int LIM = 0, int TLOG = 12>
+        __global__ __launch_bounds__(LTile<TLOG>::NT, (LOcc<TLOG, T>::WAVES)) void fourstep_inv_first_lazy(LazyArgsT<T> a)
         {
-            __shared__ T lds[LTile<12>::LDS_ELEMS_FST];
+            __shared__ T lds[LTile<TLOG>::LDS_ELEMS_FST];
             if (a.go_flag != nullptr && *a.go_flag == 0u)
                 return;
             T qv = a.q, qb = a.q_bit, qm = a.q_mu;
@@ -1250,7 +1252,7 @@ namespace gpuntt
                 qm = md.mu;
             }
             const unsigned bx = (a.flags & F_REVERSE) ? (gridDim.x - 1u - blockIdx.x) : blockIdx.x;
-            const int tiles_log = a.n - 12;
+            const int tiles_log = a.n - TLOG;
             unsigned poly, tile;
             if (a.batch > 1)
                 poly_minor_order(bx, static_cast<unsigned>(a.batch), tiles_log, poly, tile, a.flags);
@@ -1259,8 +1261,8 @@ namespace gpuntt
                 poly = bx >> tiles_log;
                 tile = bx & ((1u << tiles_log) - 1u);
             }
-            pass_body<T, 12, false, true, true, 12, 1, false, 3, LIM, 16 + L1>(a, lds, qv, qb, qm, 0, uniform32(poly),
-                                                                              uniform32(tile));
+            pass_body<T, TLOG, false, true, true, TLOG, 1, false, 3, LIM, 16 + L1>(a, lds, qv, qb, qm, 0, uniform32(poly),
+                                                                                  uniform32(tile));
         }
 
         // 4-step transform of a ring that fits one tile (2^12 .. 2^14): ONE contiguous Merge pass over the whole ring
