@@ -162,7 +162,7 @@ namespace gpuntt
         {
             PlanMode mode = PLAN_NONE;
             lazy::Tw<T>* ws = nullptr;
-            int tile_log = 0; // row-pass tile the n2 table was laid out for (reference-layout plans)
+            int tile_log = 0; // forward reference-layout plans: tile of the ring's Merge plan the table was laid out for
             int small_tl = 0; // reference-layout plans of one-tile rings: tile of the one-launch path (0: two-phase path)
             int first_k = 0;  // forward reference-layout plans: stages of the first Merge pass (the one that reads the
                               // transposed input); tile_log is then the tile of the RING's Merge plan
@@ -814,8 +814,6 @@ namespace gpuntt
                 p->owns_ws = true;
             }
             p->use.mode = PLAN_PREPARE;
-            p->use.tile_log =
-                host::lazy_tile_log<T>(l2, p->inverse, static_cast<unsigned long long>(batch_hint) << l1);
             if (!p->inverse && !natural_order)
             {
                 // forward: the Merge plan of the ring, first pass with the transposed gather
