@@ -401,3 +401,25 @@ def test_inverse_in_merge_form_every_polynomial_repeatedly(g, bits, logn, batch)
         plan.close()
     finally:
         g.set_option("path", "default")
+
+
+def test_fourstep_seeded_random_shapes_both_directions(g):
+    """seeded random sweep of the 4-step entry points in Merge form: ring 2^12 .. 2^23, odd batch sizes (poly-minor block
+    order from 2^20, reversed sweeps, ragged one-tile batches), u32 / u64, plain and RNS(1) overloads, forward and inverse,
+    every polynomial against the oracle"""
+    rng = np.random.default_rng(20260930)
+    cases = [(int(rng.choice([32, 64])), int(logn), int(rng.integers(1, 8 if logn < 20 else 4)))
+             for logn in list(range(12, 24)) + [14, 16, 18, 20, 21, 22]]
+    for bits, logn, batch in cases:
+        P = O.Port(bits)
+        p4 = g.NTTParameters4Step(logn, bits)
+        oprm = P.fourstep_params(logn)
+        n = p4.n
+        x = P.splitmix(9000 + 31 * logn + batch + bits, 0, batch * n, p4.modulus.value)
+        want = np.concatenate([P.fourstep_ntt(x[p * n:(p + 1) * n], oprm) for p in range(batch)])
+        rns = bool(rng.integers(0, 2))
+        got = run_fourstep(g, p4, x, batch, inverse=False, rns=rns)
+        assert np.array_equal(got, want), ("forward", bits, logn, batch, rns)
+        xin = np.concatenate([P.fourstep_intt_first_transpose(want[p * n:(p + 1) * n], oprm) for p in range(batch)])
+        back = run_fourstep(g, p4, xin, batch, inverse=True, rns=not rns)
+        assert np.array_equal(back, x), ("inverse", bits, logn, batch, rns)
