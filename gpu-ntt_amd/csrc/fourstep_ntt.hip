@@ -169,7 +169,7 @@ namespace gpuntt
         };
 
         // fast path: single modulus with lazy headroom.  Workspace layout (Shoup pairs):
-        //   [0, n1)  n1 table by stage | [n1, n1 + N)  W matrix | [.., + n2)  n2 table by stage
+        //   [0, n1)  unused | [n1, n1 + N)  the ring's Merge table | [.., + n2)  unused  (layout of rounds 1-3 kept)
         // mods_dev != nullptr: the RNS overload with ONE modulus (how the reference's own example calls
         // the 4-step, test_4step_ntt.cu:126-146): modulus and n^-1 live in device memory, so the first
         // preparation kernel classifies the modulus and publishes the go-flag that the fast kernels and

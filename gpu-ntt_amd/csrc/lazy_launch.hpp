@@ -99,14 +99,6 @@ namespace gpuntt
                                                    lazy::Tw32*, unsigned*, lazy::NormConst*, hipStream_t, const int*,
                                                    const uint32_t*, bool);
 
-        template <typename T>
-        void launch_prep_pairs(const T* src, lazy::Tw<T>* dst, unsigned long long count, T q, hipStream_t stream,
-                               const Modulus<T>* mods = nullptr); // mods: one device-side modulus instead of q
-        extern template void launch_prep_pairs<uint64_t>(const uint64_t*, lazy::Tw64*, unsigned long long,
-                                                         uint64_t, hipStream_t, const Modulus<uint64_t>*);
-        extern template void launch_prep_pairs<uint32_t>(const uint32_t*, lazy::Tw32*, unsigned long long,
-                                                         uint32_t, hipStream_t, const Modulus<uint32_t>*);
-
         // 4-step transform of a ring that fits one tile in one launch: 64-bit 2^12 (tile 12), 2^13 (tile 13), 2^14 forward
         // (tile 14); 32-bit 2^12 (tile 12), 2^13 (tile 13), 2^14 (tile 14).  a.tw = Merge table of the ring
         // (launch_prep_merge_from_fourstep).  fourstep_small_tile: the tile such a call runs on, 0 = ring too large
@@ -350,7 +342,7 @@ namespace gpuntt
 
         // forced_tl: tile size the twiddle table was prepared for (NTTPlan); 0 = choose from the batch
         // low_stages > 0 (forward only): run only the stages on the low `low_stages` index bits of the ring -- the
-        // values come lazy (below 16 q) from a pass that did the stages above them (4-step phase 1 in Merge form)
+        // values come lazy (below 16 q) from a pass that did the stages above them (forward 4-step: the gather pass, fourstep_first_lazy)
         template <typename T, bool INV>
         inline void run_transform_lazy(kern::LazyArgsT<T> base, unsigned first_in_flags,
                                        unsigned last_out_flags, hipStream_t stream, int forced_tl = 0, int low_stages = 0)

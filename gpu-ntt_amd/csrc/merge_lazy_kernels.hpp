@@ -38,7 +38,7 @@ namespace gpuntt
             int lim;                         // 64-bit words: 0, or 8 / 4 = a 61- / 62-bit modulus in the call -> the LIMIT = 8 / 4 kernels (host-side switch)
             int n2_log;                      // 4-step transposing passes: log2 of the row stride of the transposed side
             int row_log;                     // natural-order 4-step row passes (FST = 2): log2 of the row stride of the row-major side (n2); a.n stays the ring (twiddle indices)
-            int batch;                       // > 1: polynomials of the call, blocks are ordered poly-minor (4-step phase 1; big-ring passes)
+            int batch;                       // > 1: polynomials of the call, blocks are ordered poly-minor (big-ring contiguous passes)
             unsigned long long total;
             int n;
             int poly_shift;
@@ -76,7 +76,7 @@ namespace gpuntt
         {
             unsigned long long base;
             int p_lo; // STRIDED: first stage bit of the pass; SEG: log2 of the row stride
-            // CONTIG tile at an explicit flat base (4-step phase 1 orders its blocks poly-minor)
+            // CONTIG tile at an explicit flat base (the transposing 4-step passes order their blocks themselves)
             __device__ __forceinline__ explicit LTileMap(unsigned long long flat_base, int row_shift = 0)
                 : base(flat_base), p_lo(row_shift)
             {
@@ -1087,7 +1087,7 @@ namespace gpuntt
         // Poly-minor block order (the polynomials of a batch that share a slice of the twiddle / W table run back
         // to back), XCD-aware: the dispatcher sends workgroup b to XCD b % 8 and every XCD has its own L2, so a
         // slice shared by consecutive block indices is fetched from the fabric once per XCD -- up to 8 times
-        // (PMC, C3 phase 1: 2.15 GB of W fetched for a 256 MiB table).  With 8 | tiles the tile index takes its
+        // (PMC, round 2, the W-streaming phase 1 of C3: 2.15 GB fetched for a 256 MiB table).  With 8 | tiles the tile index takes its
         // TOP three bits from b % 8, so all polynomials of a tile position run on ONE XCD and its slice crosses the
         // fabric once, and the eight tiles in flight at a time lie an eighth of the ring apart (in the low bits
         // they would be neighbouring 512-byte runs of the same rows in a strided pass -- one HBM channel for all

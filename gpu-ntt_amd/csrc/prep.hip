@@ -171,28 +171,6 @@ namespace gpuntt
             ws[dst] = lazy::Tw<T>{w, shoup_quotient_r<T>(w, q, rinv)};
         }
 
-        // plain residues -> Shoup pairs, same order (4-step W matrix)
-        template <typename T>
-        __global__ __launch_bounds__(256) void prep_pairs(const T* __restrict__ src, lazy::Tw<T>* __restrict__ dst,
-                                                          unsigned long long count, T q, T rinv,
-                                                          const Modulus<T>* __restrict__ mods)
-        {
-            const unsigned long long gid = blockIdx.x * 256ull + threadIdx.x;
-            __shared__ T s_rinv;
-            if (mods != nullptr)
-            {
-                // one device-side modulus (4-step RNS overload): reciprocal once per block
-                q = mods[0].value;
-                if (threadIdx.x == 0)
-                    s_rinv = recip_norm<T>(q);
-                __syncthreads();
-                rinv = s_rinv;
-            }
-            if (gid >= count)
-                return;
-            const T w = src[gid];
-            dst[gid] = lazy::Tw<T>{w, shoup_quotient_r<T>(w, q, rinv)};
-        }
         // The 4-step transform IS the Merge transform of the same ring with one transposition on the natural-order
         // side (forward: GPU_4STEP_NTT(in) = MergeNTT(in read as the n2 x n1 transpose of x); inverse: the output is
         // stored transposed), so the Merge kernels can run it from a MERGE table of the ring -- bit-reversed powers of
@@ -473,15 +451,6 @@ namespace gpuntt
             GPUNTT_HIP_CHECK(hipGetLastError());
         }
         template <typename T>
-        void launch_prep_pairs(const T* src, lazy::Tw<T>* dst, unsigned long long count, T q, hipStream_t stream,
-                               const Modulus<T>* mods)
-        {
-            const unsigned grid = static_cast<unsigned>((count + 255) / 256);
-            hipLaunchKernelGGL((kern::prep_pairs<T>), dim3(grid), dim3(256), 0, stream, src, dst, count, q,
-                               mods ? static_cast<T>(0) : recip_norm_host<T>(q), mods);
-            GPUNTT_HIP_CHECK(hipGetLastError());
-        }
-        template <typename T>
         void launch_prep_merge_from_fourstep(const T* n1_table, const T* w_table, lazy::Tw<T>* ws, int log_n1, int log_n2,
                                              int perm_tile_log, bool inverse, bool fold, T q, T ninv,
                                              const Modulus<T>* mods, const T* ninv_dev, lazy::Tw<T>* ws_ninv,
@@ -504,10 +473,6 @@ namespace gpuntt
                                                                 const uint32_t*, lazy::Tw32*, unsigned*, lazy::NormConst*,
                                                                 hipStream_t);
 
-        template void launch_prep_pairs<uint64_t>(const uint64_t*, lazy::Tw64*, unsigned long long, uint64_t,
-                                                  hipStream_t, const Modulus<uint64_t>*);
-        template void launch_prep_pairs<uint32_t>(const uint32_t*, lazy::Tw32*, unsigned long long, uint32_t,
-                                                  hipStream_t, const Modulus<uint32_t>*);
 
         template void launch_prep<uint64_t>(const uint64_t*, lazy::Tw64*, const Modulus<uint64_t>*, uint64_t, int,
                                             int, bool, int, const uint64_t*, lazy::Tw64*, unsigned*, lazy::NormConst*, hipStream_t, const int*,
