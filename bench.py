@@ -621,6 +621,10 @@ def run_sweep(g, args, dist_mod, dist, rank, world, dev):
         torch.cuda.synchronize()
         per = max((time.perf_counter() - t0) / w, 1e-6)
         steps = max(5, min(2000, int(0.15 / per)))
+        if dist is not None:  # every rank times the SAME number of steps (rank 0's estimate)
+            st = torch.tensor([steps], device=dev, dtype=torch.int64)
+            dist.broadcast(st, src=0)
+            steps = int(st[0])
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
         def timed():
