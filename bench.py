@@ -38,6 +38,7 @@ sys.path.insert(0, ROOT)
 from __graft_entry__ import _load_pkg  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+REDUCE_DEV = None   # device of the control-plane reductions: the rank's GPU under RCCL, the host under gloo
 E2E_TIMEOUT_S = 180  # multi-GPU runs: watchdog around the informational RCCL scatter / gather leg
 CPU_SECONDS = 5.0      # per CPU-baseline leg (1 thread, then all threads)
 
@@ -622,7 +623,7 @@ def run_sweep(g, args, dist_mod, dist, rank, world, dev):
         per = max((time.perf_counter() - t0) / w, 1e-6)
         steps = max(5, min(2000, int(0.15 / per)))
         if dist is not None:  # every rank times the SAME number of steps (rank 0's estimate)
-            st = torch.tensor([steps], device=dev, dtype=torch.int64)
+            st = torch.tensor([steps], device=REDUCE_DEV or dev, dtype=torch.int64)
             dist.broadcast(st, src=0)
             steps = int(st[0])
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -635,7 +636,7 @@ def run_sweep(g, args, dist_mod, dist, rank, world, dev):
         wall = dist_mod.timed_region(timed, 1, dist, dev)
         dev_ms = e0.elapsed_time(e1)
         if dist is not None:
-            tt = torch.tensor([dev_ms], device=dev, dtype=torch.float64)
+            tt = torch.tensor([dev_ms], device=REDUCE_DEV or dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dev_ms = float(tt[0])
         if rank == 0:
@@ -705,9 +706,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         return dry_run(cfg, args, dist_mod)
+    # GPUNTT_BENCH_BACKEND=gloo (diagnostic): control-plane collectives over gloo and ranks mapped onto the devices that
+    # exist (LOCAL_RANK % device count) -- lets a one-GPU box run the N-rank code path end to end; RCCL is the default
+    backend = os.environ.get("GPUNTT_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
-    dist, rank, world = dist_mod.init_process_group("nccl", dev)
+    dist, rank, world = dist_mod.init_process_group(backend, dev)
+    global REDUCE_DEV
+    REDUCE_DEV = dev if backend == "nccl" else "cpu"
     if args.sweep:
         run_sweep(g, args, dist_mod, dist, rank, world, dev)
         if dist is not None:
@@ -754,7 +762,7 @@ def main():
     wall = dist_mod.timed_region(timed_steps, 1, dist, dev)
     dev_ms = e0.elapsed_time(e1)
     if dist is not None:
-        t = torch.tensor([dev_ms], device=dev, dtype=torch.float64)
+        t = torch.tensor([dev_ms], device=REDUCE_DEV or dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dev_ms = float(t[0])
 

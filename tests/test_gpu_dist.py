@@ -75,3 +75,27 @@ def test_end_to_end_leg_with_device_tensors_two_ranks_one_gpu(tmp_path):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     got = [l for l in r.stdout.splitlines() if l.startswith("E2E")][0].split()[1]
     assert got == hashlib.sha256(want.tobytes()).hexdigest()
+
+
+def test_bench_two_ranks_on_one_gpu_over_gloo():
+    """`python bench.py --gpus 2` end to end on the one-GPU box: the script starts its own two ranks, both mapped onto
+    cuda:0, control-plane collectives over gloo (GPUNTT_BENCH_BACKEND, a diagnostic switch; RCCL is the default) -- the
+    N-rank code path of the headline config (shard geometry, barrier + MAX timing, end-to-end leg behind its watchdog)
+    and of the sweep, with the real library calls."""
+    import json
+    env = dict(os.environ, GPUNTT_BENCH_BACKEND="gloo")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = lines[0]
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "weak"
+    assert line["config"]["parallelism"] == "batch-shard x2"
+    assert "error" not in line["end_to_end"], line["end_to_end"]
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--sweep", "--sweep-min", "12",
+                          "--sweep-max", "12", "--sweep-kinds", "merge"],
+                         capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["value"] > 0
