@@ -158,7 +158,7 @@ def measure_traffic(config, api, out_of_place=False):
             cmd = [rocprof, "--pmc", counter, "-d", out, "-o", "pmc", "--", sys.executable,
                    os.path.join(ROOT, "bench.py"), "--config", config, "--api", api, "--steps", str(steps),
                    "--warmup", "0", "--child"] + (["--out-of-place"] if out_of_place else [])
-            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=180)
             dbs = glob.glob(out + "/**/*.db", recursive=True)
             if r.returncode != 0 or not dbs:
                 return None, "rocprofv3 --pmc %s failed: %s" % (counter, (r.stderr or r.stdout)[-300:])
