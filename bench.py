@@ -404,24 +404,48 @@ def build_case(g, cfg, rank, world, dev, api, inplace=True):
             case["plan"][0].execute(d_in, d_mid, batch)
             case["plan"][1].execute(d_mid, d_back, batch)
         step, other_step = (plan_step, dropin_step) if api == "plan" else (dropin_step, plan_step)
-        case.update(step=step, x=base, other_step=lambda: other_step, d_in=d_in, d_out=d_mid, table=tf[2], modulus=p4.modulus.value,
-                    transforms_per_step=2 * batch, p4=p4, natural=(tf, cf), run_shard=None)
+        case.update(step=step, x=base, other_step=lambda: other_step, d_in=d_in, d_out=d_mid, d_back=d_back, distinct=distinct,
+                    table=tf[2], modulus=p4.modulus.value, transforms_per_step=2 * batch, p4=p4, run_shard=None)
     return case
 
 
 def gpu_sample_for_check(g, cfg, case, polys):
-    """GPU output of the first `polys` polynomials in the order the CPU path produces"""
+    """GPU output of the first `polys` polynomials in the order the CPU path produces.  4-step (c3): polynomial 0 of
+    `d_mid`, THE buffer the timed GPU_4STEP_NTT calls write (reference layout n1 x n2), transposed on the device into
+    NTT_4STEP_CPU::ntt's order -- what the reference example's closing GPU_Transpose does (test_4step_ntt.cu:170-178)."""
     import torch
     n = case["n"]
     if cfg["kind"] != "4step":
         return g.to_host(case["d_out"])[:polys * n].copy()
-    # natural-order forward of polynomial 0 = NTT_4STEP_CPU::ntt
-    tf, cf = case["natural"]
-    a = g.to_device(case["x"][:n])
-    b = torch.zeros_like(a)
-    g.GPU_4STEP_NTT_NaturalOrder(a, b, *tf, case["p4"].modulus, cf, 1)
+    p4 = case["p4"]
     torch.cuda.synchronize()
-    return g.to_host(b)
+    return g.to_host(case["d_out"][:n].view(p4.n1, p4.n2).t().contiguous().view(-1))
+
+
+def fourstep_buffers_check(case):
+    """c3, after the timed steps, on the device, over the WHOLE batch: every copy of the `distinct` polynomials in the
+    forward output d_mid equals the first one (whose polynomial 0 the CPU leg checks), and the inverse output d_back
+    equals the input d_in (forward -> inverse is the identity in the reference layout up to the transposition the two
+    calls define: out_inv = in_fwd read as n2 x n1 -> n1 x n2).  Returns the dict for the JSON line."""
+    import torch
+    p4, n, distinct = case["p4"], case["n"], case["distinct"]
+    d_in, d_mid, d_back = case["d_in"], case["d_out"], case["d_back"]
+    torch.cuda.synchronize()
+    groups = d_mid.view(-1, distinct * n)
+    copies_equal = bool((groups == groups[0:1]).all())
+    # forward input of polynomial p is x^T (n2 x n1); the inverse call returns x as (n1 x n2)^T-of-the-natural-order,
+    # i.e. d_back[p] viewed n1 x n2 and transposed == x == d_in[p] viewed n2 x n1 and transposed back
+    ok = True
+    for p in range(distinct):
+        # natural-order polynomial, flat: the forward call read it transposed (d_in = n2 x n1), the inverse call
+        # returns it so that one GPU_Transpose(n1, n2) restores it (test_4step_intt.cu:170-179)
+        x_from_in = d_in[p * n:(p + 1) * n].view(p4.n2, p4.n1).t().contiguous().view(-1)
+        x_from_back = d_back[p * n:(p + 1) * n].view(p4.n1, p4.n2).t().contiguous().view(-1)
+        ok = ok and bool((x_from_in == x_from_back).all())
+    back_groups = d_back.view(-1, distinct * n)
+    ok = ok and bool((back_groups == back_groups[0:1]).all())
+    return {"forward_copies_identical": copies_equal, "inverse_returns_input": ok,
+            "polynomials_checked_on_device": int(d_mid.numel() // n)}
 
 
 # ------------------------------------------------------------------------------ self-launch
@@ -505,13 +529,15 @@ def sweep_case(g, kind, bits, logn, batch, dev, rank):
     cf = g.ntt4step_configuration(n_power=logn, ntt_type=g.FORWARD)
     step = lambda: g.GPU_4STEP_NTT(d_in, d_out, *tf, p4.modulus, cf, batch)  # noqa: E731
 
-    def natural0():  # natural-order forward of polynomial 0 = NTT_4STEP_CPU::ntt
-        a = g.to_device(base[:n], dev)
-        b = torch.empty_like(a)
-        g.GPU_4STEP_NTT_NaturalOrder(a, b, *tf, p4.modulus, cf, 1)
+    # the call reads its input as the n2 x n1 transpose of the natural-order polynomial and writes the spectrum n1 x n2:
+    # NTT_4STEP_CPU::ntt(x_nat) is polynomial 0 of THE OUTPUT BUFFER transposed (what the reference example's closing
+    # GPU_Transpose does, test_4step_ntt.cu:170-178)
+    x_nat = np.ascontiguousarray(base[:n].reshape(p4.n2, p4.n1).T).reshape(-1)
+
+    def out0():
         torch.cuda.synchronize()
-        return g.to_host(b)
-    return step, step, base[:n], natural0, [d_in, d_out] + tf
+        return g.to_host(d_out[:n].view(p4.n1, p4.n2).t().contiguous().view(-1))
+    return step, step, x_nat, out0, [d_in, d_out] + tf
 
 
 def sweep_cpu(kind, bits, logn, x0, y0):
@@ -858,8 +884,23 @@ def main():
             if e2e is not None:
                 line["end_to_end"] = e2e
             if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only
-                case["x_sample"] = case["x"][:cpu_polys * n] if cfg["kind"] != "4step" else case["x"][:n]
+                if cfg["kind"] != "4step":
+                    case["x_sample"] = case["x"][:cpu_polys * n]
+                else:
+                    # the timed forward call reads its input as the n2 x n1 transpose of the natural-order polynomial:
+                    # that polynomial is what NTT_4STEP_CPU::ntt gets
+                    p4 = case["p4"]
+                    case["x_sample"] = np.ascontiguousarray(case["x"][:n].reshape(p4.n2, p4.n1).T).reshape(-1)
                 line["cpu_baseline"] = cpu_baseline(cfg, case, y_first)
+                if cfg["kind"] == "4step":
+                    # the same polynomial of the same buffer AFTER the timed steps, and the whole batch on the device
+                    if not np.array_equal(y_first, gpu_sample_for_check(g, cfg, case, 1)):
+                        raise SystemExit("bench: the timed 4-step calls left a different result in their output buffer")
+                    chk = fourstep_buffers_check(case)
+                    if not (chk["forward_copies_identical"] and chk["inverse_returns_input"]):
+                        raise SystemExit("bench: 4-step batch check failed: %r" % (chk,))
+                    line["cpu_baseline"]["checked_buffer"] = "polynomial 0 of the buffer the timed GPU_4STEP_NTT calls wrote"
+                    line["batch_check"] = chk
             print(json.dumps(line), flush=True)
 
     # The RCCL legs around the transform (table broadcast, scatter, gather) are informational and have never run on

@@ -166,6 +166,8 @@ namespace gpuntt
             int small_tl = 0; // reference-layout plans of one-tile rings: tile of the one-launch path (0: two-phase path)
             int first_k = 0;  // forward reference-layout plans: stages of the first Merge pass (the one that reads the
                               // transposed input); tile_log is then the tile of the RING's Merge plan
+            int inv_tile = 0; // inverse reference-layout plans: tile of the transposing first pass the table was permuted for
+                              // (fixed at PLAN_PREPARE: the u64_big_tiles option may change before execute())
         };
 
         // fast path: single modulus with lazy headroom.  Workspace layout (Shoup pairs):
@@ -198,6 +200,10 @@ namespace gpuntt
                 return false;
             if (host::forced_path() == 1)
                 return false;
+            // table contract (ntt_4step.cuh): the plans below derive every twiddle from n1_table and one row of W
+            if (plan.mode != PLAN_EXECUTE && host::validate_4step_tables())
+                host::validate_fourstep_tables_or_throw<T>(n1_table, n2_table, w_table, log_n1, log_n2, INV, mod.value, mods_dev,
+                                                           stream);
             const size_t n1 = size_t(1) << log_n1, n2 = size_t(1) << log_n2, n = size_t(1) << n_power;
             // pairs: n1 table | W | n2 table | n^-1 ; then go-flag (16 B) and the normalisation constants
             const size_t pairs = n1 + n + n2 + 2;
@@ -274,11 +280,11 @@ namespace gpuntt
             if constexpr (!INV)
             {
                 {
-                    const int tlf = lim != 0 ? 12
-                                    : plan.mode != PLAN_NONE
+                    int k1 = plan.first_k;
+                    const int tlf = plan.mode != PLAN_NONE
                                         ? plan.tile_log
-                                        : host::lazy_tile_log<T>(n_power, false, static_cast<unsigned long long>(batch_size));
-                    const int k1 = plan.mode != PLAN_NONE ? plan.first_k : host::fourstep_first_k(n_power, log_n1, tlf);
+                                        : host::fourstep_fwd_tile<T>(n_power, log_n1, static_cast<unsigned long long>(batch_size),
+                                                                     lim, k1);
                     if (plan.mode != PLAN_EXECUTE)
                         host::launch_prep_merge_from_fourstep<T>(n1_table, w_table, ws_w, log_n1, log_n2, tlf, false, false,
                                                                  mod.value, T(0), mods_dev, nullptr, nullptr, go_flag,
@@ -347,7 +353,8 @@ namespace gpuntt
             if constexpr (INV)
             {
                 int k_a = 0, k_b = 0;
-                const int tli = host::fourstep_inv_tile<T>(n_power, lim);
+                const int tli = (plan.mode == PLAN_EXECUTE && plan.inv_tile != 0) ? plan.inv_tile
+                                                                                  : host::fourstep_inv_tile<T>(n_power, lim);
                 if (host::fourstep_inv_merge_split(n_power, log_n1, k_a, k_b, tli))
                 {
                     if (plan.mode != PLAN_EXECUTE)
@@ -516,6 +523,9 @@ namespace gpuntt
                 return false;
             if (host::forced_path() == 1)
                 return false;
+            if (plan.mode != PLAN_EXECUTE && host::validate_4step_tables())
+                host::validate_fourstep_tables_or_throw<T>(n1_table, n2_table, w_table, log_n1, log_n2, false, mod.value, nullptr,
+                                                           stream);
             const size_t n1 = size_t(1) << log_n1, n2 = size_t(1) << log_n2, n = size_t(1) << n_power;
             auto* ws = plan.mode != PLAN_NONE
                            ? plan.ws
@@ -576,6 +586,9 @@ namespace gpuntt
                 return false;
             if (host::forced_path() == 1)
                 return false;
+            if (plan.mode != PLAN_EXECUTE && host::validate_4step_tables())
+                host::validate_fourstep_tables_or_throw<T>(n1_table, n2_table, w_table, log_n1, log_n2, true, mod.value, nullptr,
+                                                           stream);
             const size_t n1 = size_t(1) << log_n1, n2 = size_t(1) << log_n2, n = size_t(1) << n_power;
             auto* ws = plan.mode != PLAN_NONE
                            ? plan.ws
@@ -817,13 +830,13 @@ namespace gpuntt
             if (!p->inverse && !natural_order)
             {
                 // forward: the Merge plan of the ring, first pass with the transposed gather
-                p->use.tile_log = host::modulus_lim<T>(modulus) != 0
-                                      ? 12
-                                      : host::lazy_tile_log<T>(p->n, false, static_cast<unsigned long long>(batch_hint));
-                p->use.first_k = host::fourstep_first_k(p->n, l1, p->use.tile_log);
+                p->use.tile_log = host::fourstep_fwd_tile<T>(p->n, l1, static_cast<unsigned long long>(batch_hint),
+                                                             host::modulus_lim<T>(modulus), p->use.first_k);
             }
             p->use.small_tl =
                 host::fourstep_small_tile<T>(p->n, p->inverse, static_cast<unsigned long long>(batch_hint), natural_order);
+            if (p->inverse && !natural_order)
+                p->use.inv_tile = host::fourstep_inv_tile<T>(p->n, host::modulus_lim<T>(modulus));
             // the eligibility checks of the fast paths decide (modulus width, n^-1 canonical, option "path")
             if (natural_order)
                 p->fast = p->inverse ? fourstep_natural_inverse_lazy<T>(nullptr, nullptr, p->n1_table, p->n2_table,

@@ -214,6 +214,17 @@ namespace gpuntt
                                                                        int, int, bool, bool, uint32_t, uint32_t,
                                                                        const Modulus<uint32_t>*, const uint32_t*,
                                                                        lazy::Tw32*, unsigned*, lazy::NormConst*, hipStream_t);
+        // option validate_4step_tables: one launch + one stream synchronisation; throws std::invalid_argument when the
+        // caller's tables are not the NTTParameters4Step tables of one root of order N (prep.hip)
+        template <typename T>
+        void validate_fourstep_tables_or_throw(const T* n1_table, const T* n2_table, const T* w_table, int log_n1, int log_n2,
+                                               bool inverse, T q, const Modulus<T>* mods, hipStream_t stream);
+        extern template void validate_fourstep_tables_or_throw<uint64_t>(const uint64_t*, const uint64_t*, const uint64_t*,
+                                                                         int, int, bool, uint64_t, const Modulus<uint64_t>*,
+                                                                         hipStream_t);
+        extern template void validate_fourstep_tables_or_throw<uint32_t>(const uint32_t*, const uint32_t*, const uint32_t*,
+                                                                         int, int, bool, uint32_t, const Modulus<uint32_t>*,
+                                                                         hipStream_t);
         // host Shoup companion floor(w * 2^W / q)
         inline uint64_t shoup_host(uint64_t w, uint64_t q)
         {
@@ -260,6 +271,10 @@ namespace gpuntt
         int lazy_contig_k(int n);
 
         bool lazy_reverse_passes();
+        bool validate_4step_tables();     // option validate_4step_tables (default off)
+        bool lazy_q59_enabled();          // option q59 (default on; A/B switch)
+        bool lazy_unit_skip_enabled();    // option unit_skip (default on; A/B switch)
+        bool lazy_fuse_batch1_enabled();  // option fuse_batch1 (default on; A/B switch)
         // forward 4-step in Merge form: stages of the first pass (the one that reads the transposed input) -- the first
         // strided pass of the ring's Merge plan on tile `tl`, widened to log2 n1 where that is larger (5 .. 8)
         inline int fourstep_first_k(int n_power, int log_n1, int tl)
@@ -268,6 +283,23 @@ namespace gpuntt
             const int k0 = (pl.count >= 2 && !pl.pass[0].contig) ? pl.pass[0].k : 0;
             const int k = k0 > log_n1 ? k0 : log_n1;
             return k > 8 ? 8 : k;
+        }
+
+        // forward 4-step in Merge form: tile of the ring's Merge plan and stages of the gathering first pass.  A 16384-coefficient
+        // tile whose remaining low stages (n - k1) would be fewer than 13 has no lazy-input contiguous kernel (only K = 13 /
+        // 14 exist on that tile): such rings -- only reachable through the u32_tile = 14 tuning option, 32-bit 2^15 .. 2^17 --
+        // keep the 4096-coefficient tile
+        template <typename T>
+        inline int fourstep_fwd_tile(int n_power, int log_n1, unsigned long long polys, int lim, int& k1)
+        {
+            int tl = lim != 0 ? 12 : lazy_tile_log<T>(n_power, false, polys);
+            k1 = fourstep_first_k(n_power, log_n1, tl);
+            if (tl == 14 && n_power > tl && n_power - k1 < 13)
+            {
+                tl = 12;
+                k1 = fourstep_first_k(n_power, log_n1, tl);
+            }
+            return tl;
         }
 
         // in_first: the pass reads canonical input (first pass of the transform)

@@ -395,6 +395,10 @@ namespace gpuntt
             const bool tile_in_range = (CONTIG && !FST) ? ((map.base + LTile<TLOG>::TILE) <= a.total) : true;
             if (a.poly_order != nullptr)
                 map.remap_poly(a.poly_order, a.n); // twiddle indices use flat & (N-1): unaffected
+            // lazy::Mod64::mul_acc_raw names the fixed register pair v[126:127]: every 64-bit kernel must be compiled for a
+            // budget of AT LEAST 128 VGPRs, i.e. at most 4 waves per SIMD in its __launch_bounds__
+            static_assert(sizeof(T) != 8 || LOcc<TLOG, T>::WAVES <= 4,
+                          "64-bit lazy kernels need the 128-VGPR budget (v126 / v127 are named in lazy.hpp)");
             M m;
             m.set(q_value, (a.norm_arr != nullptr) ? a.norm_arr[mi] : a.norm);
             const dev::ModCtx<T> em{q_value, q_bit, q_mu};

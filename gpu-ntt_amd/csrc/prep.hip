@@ -12,6 +12,7 @@
 // is always honoured.
 #include <atomic>
 #include <cstdlib>
+#include <initializer_list>
 #include <string>
 #include <map>
 #include <mutex>
@@ -244,6 +245,76 @@ namespace gpuntt
             ws[slot] = lazy::Tw<T>{w, shoup_quotient_r<T>(w, q, rinv)};
         }
 
+        // option validate_4step_tables: the fast 4-step path derives every twiddle from n1_table and ONE row of W (forward:
+        // row n1/2, inverse: row 1; prep_merge_from_fourstep above) where the reference multiplies by W[address] element
+        // by element and runs the rows through n2_table (src/lib/ntt_4step/ntt_4step.cu:1049-1058).  The results agree iff
+        // the tables are the ones NTTParameters4Step generates for ONE root w of order N (nttparameters.cu:356-444):
+        //   forward  W[r * n2 + j] = w^(brev(r, log n1) * j)      inverse  W[r * n2 + c] = w^(r * brev(c, log n2))
+        //   n2_table[i] = (w^n1)^brev(i, log n2 - 1)              n1_table[i] = (w^n2)^brev(i, log n1 - 1)
+        // This kernel takes w from the row the fast path reads (its entry with exponent 1), checks w^(N/2) = -1, and compares
+        // 128 pseudo-random W entries, 64 n2_table entries and up to 64 n1_table entries with the powers; *bad counts mismatches.
+        template <typename T> __device__ __forceinline__ T powmod_r(T base, unsigned long long e, T q, T rinv)
+        {
+            T r = 1, b = base;
+            while (e != 0ull)
+            {
+                if (e & 1ull)
+                    r = mulmod_r<T>(r, b, q, rinv);
+                b = mulmod_r<T>(b, b, q, rinv);
+                e >>= 1;
+            }
+            return r;
+        }
+        template <typename T>
+        __global__ __launch_bounds__(256) void validate_fourstep_tables(const T* __restrict__ n1_table,
+                                                                        const T* __restrict__ n2_table,
+                                                                        const T* __restrict__ w_table, int log_n1, int log_n2,
+                                                                        int inverse, T q_single,
+                                                                        const Modulus<T>* __restrict__ mods, unsigned seed,
+                                                                        unsigned* __restrict__ bad)
+        {
+            const T q = (mods != nullptr) ? mods[0].value : q_single;
+            if (q < 3 || (q >> (8 * sizeof(T) - 2)) != 0)
+                return; // outside the fast kernels' domain: the generic kernels read the caller's tables as they stand
+            const T rinv = recip_norm<T>(q);
+            const int n = log_n1 + log_n2;
+            const unsigned n1 = 1u << log_n1, n2 = 1u << log_n2;
+            const T w = inverse ? w_table[static_cast<unsigned long long>(n2) + (n2 >> 1)]
+                                : w_table[(static_cast<unsigned long long>(n2) << (log_n1 - 1)) + 1u];
+            const unsigned t = threadIdx.x;
+            // splitmix-style hash of (seed, t)
+            unsigned long long h = (static_cast<unsigned long long>(seed) << 32 | t) + 0x9E3779B97F4A7C15ull;
+            h = (h ^ (h >> 30)) * 0xBF58476D1CE4E5B9ull;
+            h = (h ^ (h >> 27)) * 0x94D049BB133111EBull;
+            h ^= h >> 31;
+            bool ok = true;
+            if (t == 0)
+                ok = (w < q) && powmod_r<T>(w, 1ull << (n - 1), q, rinv) == q - 1; // order exactly N
+            if (t < 128)
+            {
+                const unsigned r = static_cast<unsigned>(h) & (n1 - 1u), j = static_cast<unsigned>(h >> 32) & (n2 - 1u);
+                const unsigned long long e = inverse ? static_cast<unsigned long long>(r) * (__brev(j) >> (32 - log_n2))
+                                                     : static_cast<unsigned long long>(__brev(r) >> (32 - log_n1)) * j;
+                ok = ok && (w_table[static_cast<unsigned long long>(r) * n2 + j] == powmod_r<T>(w, e, q, rinv));
+            }
+            else if (t < 192)
+            {
+                const unsigned i = static_cast<unsigned>(h) & ((n2 >> 1) - 1u);
+                const unsigned long long e =
+                    (log_n2 > 1 ? static_cast<unsigned long long>(__brev(i) >> (33 - log_n2)) : 0ull) << log_n1;
+                ok = (n2_table[i] == powmod_r<T>(w, e, q, rinv));
+            }
+            else
+            {
+                const unsigned i = (t - 192u) & ((n1 >> 1) - 1u);
+                const unsigned long long e =
+                    (log_n1 > 1 ? static_cast<unsigned long long>(__brev(i) >> (33 - log_n1)) : 0ull) << log_n2;
+                ok = (n1_table[i] == powmod_r<T>(w, e, q, rinv));
+            }
+            if (!ok)
+                atomicAdd(bad, 1u);
+        }
+
     } // namespace kern
 
     namespace host
@@ -324,6 +395,10 @@ namespace gpuntt
                 std::atomic<int> big_tiles{14}; // largest 64-bit ring done in one big tile
                 std::atomic<int> u32_tile{0};   // 12 | 14: 32-bit tile above 2^14
                 std::atomic<int> no_scratch{0}; // test hook: behave as if the twiddle scratch could not be allocated
+                std::atomic<int> validate_4step{0}; // GPU_4STEP_NTT: spot-check the caller's n2 / W tables against the derived powers
+                std::atomic<int> q59{1};         // 64-bit moduli 2^59 + c, c < 2^32: the shift form of the quotient product
+                std::atomic<int> unit_skip{1};   // cyclic transforms: block-uniform twiddles equal to 1 skip their product
+                std::atomic<int> fuse_batch1{1}; // small calls: both passes of a two-pass plan in one launch
             } g_opt;
         } // namespace
 
@@ -332,7 +407,20 @@ namespace gpuntt
             if (name == nullptr || value == nullptr)
                 return false;
             const std::string k(name), v(value);
-            const int iv = std::atoi(value);
+            // numeric values: the whole string must be a number of the option's documented set -- "abc", "7" for
+            // contig_k or "13" for u32_tile are refused (false), not silently turned into 0 / the default
+            char* end = nullptr;
+            const long lv = std::strtol(value, &end, 10);
+            const bool is_num = end != value && *end == '\0';
+            const int iv = static_cast<int>(lv);
+            auto one_of = [&](std::initializer_list<int> set) {
+                if (!is_num)
+                    return false;
+                for (int x : set)
+                    if (x == iv)
+                        return true;
+                return false;
+            };
             if (k == "path")
             {
                 const int m = v == "generic" ? 1 : v == "fast" ? 2 : v == "fast-strict" ? 3 : v == "generic-capped" ? 4
@@ -342,19 +430,38 @@ namespace gpuntt
                 g_opt.path = m;
             }
             else if (k == "contig_k")
-                g_opt.contig_k = (iv >= 8 && iv <= 12) ? iv : 0;
-            else if (k == "xcd_order")
-                g_opt.xcd_order = iv != 0;
-            else if (k == "lim31")
-                g_opt.lim31 = iv != 0;
-            else if (k == "reverse")
-                g_opt.reverse = iv != 0;
+            {
+                if (!one_of({0, 8, 9, 10, 11, 12}))
+                    return false;
+                g_opt.contig_k = iv;
+            }
             else if (k == "u64_big_tiles")
+            {
+                if (!one_of({0, 13, 14}))
+                    return false;
                 g_opt.big_tiles = iv;
+            }
             else if (k == "u32_tile")
-                g_opt.u32_tile = (iv == 12 || iv == 14) ? iv : 0;
-            else if (k == "no_scratch")
-                g_opt.no_scratch = iv != 0;
+            {
+                if (!one_of({0, 12, 14}))
+                    return false;
+                g_opt.u32_tile = iv;
+            }
+            else if (k == "xcd_order" || k == "lim31" || k == "reverse" || k == "no_scratch" || k == "validate_4step_tables" ||
+                     k == "q59" || k == "unit_skip" || k == "fuse_batch1")
+            {
+                if (!one_of({0, 1}))
+                    return false;
+                std::atomic<int>& dst = k == "xcd_order"               ? g_opt.xcd_order
+                                        : k == "lim31"                 ? g_opt.lim31
+                                        : k == "reverse"               ? g_opt.reverse
+                                        : k == "no_scratch"            ? g_opt.no_scratch
+                                        : k == "validate_4step_tables" ? g_opt.validate_4step
+                                        : k == "q59"                   ? g_opt.q59
+                                        : k == "unit_skip"             ? g_opt.unit_skip
+                                                                       : g_opt.fuse_batch1;
+                dst = iv;
+            }
             else
                 return false;
             return true;
@@ -383,6 +490,10 @@ namespace gpuntt
         bool lazy_reverse_passes() { return g_opt.reverse.load(std::memory_order_relaxed) != 0; }
         int lazy_u64_big_tiles() { return g_opt.big_tiles.load(std::memory_order_relaxed); }
         int lazy_u32_tile_override() { return g_opt.u32_tile.load(std::memory_order_relaxed); }
+        bool validate_4step_tables() { return g_opt.validate_4step.load(std::memory_order_relaxed) != 0; }
+        bool lazy_q59_enabled() { return g_opt.q59.load(std::memory_order_relaxed) != 0; }
+        bool lazy_unit_skip_enabled() { return g_opt.unit_skip.load(std::memory_order_relaxed) != 0; }
+        bool lazy_fuse_batch1_enabled() { return g_opt.fuse_batch1.load(std::memory_order_relaxed) != 0; }
 
         void* lazy_workspace(hipStream_t stream, size_t bytes, bool or_null)
         {
@@ -450,6 +561,40 @@ namespace gpuntt
                                (fold_ninv_single != nullptr || (fold_ninv_rns && ninv_arr != nullptr)) ? 1 : 0);
             GPUNTT_HIP_CHECK(hipGetLastError());
         }
+        template <typename T>
+        void validate_fourstep_tables_or_throw(const T* n1_table, const T* n2_table, const T* w_table, int log_n1, int log_n2,
+                                               bool inverse, T q, const Modulus<T>* mods, hipStream_t stream)
+        {
+            if (n1_table == nullptr || n2_table == nullptr || w_table == nullptr)
+                throw std::invalid_argument("4-step tables: null pointer argument");
+            unsigned* bad = nullptr;
+            GPUNTT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&bad), sizeof(unsigned)));
+            unsigned host_bad = 0;
+            hipError_t err = hipMemsetAsync(bad, 0, sizeof(unsigned), stream);
+            if (err == hipSuccess)
+            {
+                static std::atomic<unsigned> call_seed{0x5EED};
+                hipLaunchKernelGGL((kern::validate_fourstep_tables<T>), dim3(1), dim3(256), 0, stream, n1_table, n2_table,
+                                   w_table, log_n1, log_n2, inverse ? 1 : 0, q, mods, call_seed.fetch_add(0x9E37u), bad);
+                err = hipGetLastError();
+            }
+            if (err == hipSuccess)
+                err = hipMemcpyAsync(&host_bad, bad, sizeof(unsigned), hipMemcpyDeviceToHost, stream);
+            if (err == hipSuccess)
+                err = hipStreamSynchronize(stream);
+            (void) hipFree(bad);
+            GPUNTT_HIP_CHECK(err);
+            if (host_bad != 0)
+                throw std::invalid_argument(
+                    "4-step tables are not consistent with one root of order N (NTTParameters4Step layout): the fast path "
+                    "derives its twiddles from n1_table and one row of W and would not compute what the tables say "
+                    "(option validate_4step_tables; include/gpuntt/ntt_4step/ntt_4step.cuh, table contract)");
+        }
+        template void validate_fourstep_tables_or_throw<uint64_t>(const uint64_t*, const uint64_t*, const uint64_t*, int, int,
+                                                                  bool, uint64_t, const Modulus<uint64_t>*, hipStream_t);
+        template void validate_fourstep_tables_or_throw<uint32_t>(const uint32_t*, const uint32_t*, const uint32_t*, int, int,
+                                                                  bool, uint32_t, const Modulus<uint32_t>*, hipStream_t);
+
         template <typename T>
         void launch_prep_merge_from_fourstep(const T* n1_table, const T* w_table, lazy::Tw<T>* ws, int log_n1, int log_n2,
                                              int perm_tile_log, bool inverse, bool fold, T q, T ninv,

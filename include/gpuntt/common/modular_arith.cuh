@@ -44,6 +44,13 @@ namespace gpuntt_detail
 // say) converts to that power of two and gets bit = 61, not its exact length 60.  Every kernel family accepts
 // the over-stated width (Barrett shifts, lazy ranges and path selection all key on `bit`), and a caller that
 // compares or serialises the three words sees the reference's values.
+// ONE divergence from the reference's constructor, at the edge of / outside its documented domain (:66-67: "does not
+// work modulus higher than 30 bit for Data32 ... 62 bit for Data64"): a modulus whose mu = floor(2^(2*bit+1) / q) does
+// not fit the word is REFUSED with std::invalid_argument, where the reference stores the truncated quotient and
+// computes wrong Barrett products with it from then on.  That concerns (a) Data64: a 61-bit prime within double
+// rounding of 2^61 (it gets bit = 62); (b) Data32: EVERY modulus of 2^30 or more (bit >= 31 makes 2^(2*bit+1) / q >=
+// 2^32) -- such a Modulus32 constructs in the reference (unusable there too) and throws here.  Callers that only
+// want the three words of an out-of-domain modulus can fill the struct through the default constructor.
 template <typename T1> struct Modulus
 {
     T1 value;

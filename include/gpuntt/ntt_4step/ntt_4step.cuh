@@ -15,6 +15,27 @@
 //   device_in != device_out.  Unlike the reference (which always used the legacy default
 //   stream) every launch honours cfg.stream; GPU_Transpose runs on the default stream.
 //   Unsupported n_power: message on stdout, no throw (reference ntt_4step.cu:2529-2532).
+//
+// TABLE CONTRACT (narrower than the reference; this is the one place the drop-in reads LESS than it is given).
+//   The reference multiplies element (i, j) by W[i*n2 + j] as it stands and runs the rows through the n2 table
+//   (src/lib/ntt_4step/ntt_4step.cu:1049-1058), so it computes "whatever the three tables say".  The fast path here runs
+//   the transform as the ring's Merge plan and derives EVERY twiddle from
+//       n1_table  (all n1/2 entries)   and   ONE row of W:  row n1/2 for FORWARD (W[(n1/2)*n2 + j] = w^j),
+//                                                           row 1    for INVERSE (W[n2 + c] = w^-brev(c)),
+//   via  w^k = Wrow(k mod n2) * n1_table[brev(k / n2)];  it never reads n2_table nor the other N - n2 entries of W.
+//   The two agree exactly when the tables are those of ONE root w of order N in the layout NTTParameters4Step
+//   generates (src/lib/common/nttparameters.cu:356-444):
+//       FORWARD  W[r*n2 + j] = w^(brev(r, log n1) * j)     INVERSE  W[r*n2 + c] = v^(r * brev(c, log n2)),  v = w^-1
+//       n1_table[i] = (root^n2)^brev(i, log n1 - 1)        n2_table[i] = (root^n1)^brev(i, log n2 - 1)
+//   True for NTTParameters4Step (host) and GPU_GeneratePowerTable / GPU_Generate4StepW (device).  NOT true for tables
+//   filled with unrelated values -- the reference's own timing program passes random tables with n1 / n2 swapped
+//   (benchmark/bench_4step_ntt.cu:80-90); such a call runs here at the same speed and computes a different
+//   (equally meaningless) result.  GPU_NTT_SetOption("validate_4step_tables", "1") makes every GPU_4STEP_NTT /
+//   GPU_4STEP_NTT_NaturalOrder call and every FourStepPlan constructor spot-check the tables on the device (the root's
+//   order, 128 random W entries, 64 n2_table and up to 64 n1_table entries; one small launch + one stream
+//   synchronisation) and throw std::invalid_argument on a mismatch.  The generic (Barrett) fall-back -- moduli outside
+//   the fast domain, RNS overload with mod_count > 1, option path = generic -- reads all three tables element by
+//   element like the reference does.
 #pragma once
 
 #include "gpuntt/ntt_4step/ntt_4step_cpu.cuh"
@@ -71,16 +92,16 @@ namespace gpuntt
                                              int batch_size);
 
     // Prepared 4-step transform (extension; the 4-step counterpart of NTTPlan<T>, ntt_merge/ntt.cuh).
-    // GPU_4STEP_NTT re-derives, on every call, the Shoup pairs of the caller's n1 / n2 / W tables into a
-    // library-owned scratch buffer -- at 2^24 that is 128 MiB read and 256 MiB written before the first
-    // sweep, most of a batch-1 call.  A plan does it once, into memory the caller owns (or the plan
-    // allocates), and execute() launches the sweeps only: no allocation, no synchronisation, no
-    // preparation launch, hipGraph-capturable from the first call.
+    // GPU_4STEP_NTT rebuilds, on every call, the ring's Merge table (Shoup pairs {w^k, floor(w^k * 2^W / q)}, 2 words per
+    // coefficient) from the caller's n1 table and one row of W (table contract above) into a library-owned scratch
+    // buffer -- at 2^24 that is 256 MiB written before the first sweep, a quarter of a batch-1 call.  A plan does it
+    // once, into memory the caller owns (or the plan allocates), and execute() launches the sweeps only: no
+    // allocation, no synchronisation, no preparation launch, hipGraph-capturable from the first call.
     //   natural_order false: execute() == GPU_4STEP_NTT (n2 x n1 in, n1 x n2 out, in != out);
     //   natural_order true:  execute() == GPU_4STEP_NTT_NaturalOrder (device_in is scratch).
     // cfg.stream is the stream the preparation runs on; the constructor waits for it (one host wait per plan), so
     // execute() may run on any stream without a dependency on the construction stream.  batch_hint: the batch
-    // size the plan will mostly run (decides the row-pass tile the n2 table is laid out for; any batch
+    // size the plan will mostly run (decides the tile the Merge table's last stages are permuted for; any batch
     // size is correct).  The caller's tables must stay alive when fast_path() is false (moduli without
     // lazy headroom run GPU_4STEP_NTT / _NaturalOrder on them).
     template <typename T> class FourStepPlan

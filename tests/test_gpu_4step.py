@@ -249,6 +249,78 @@ def test_full_size_c3_properties(g, golden_dir):
     assert bool((z == d_base.view(1, -1)).all()), "forward -> inverse is not the identity at batch 64"
 
 
+def test_full_size_c3_reference_layout(g, golden_dir):
+    """BASELINE config 3's OWN call at its own shape: GPU_4STEP_NTT in the reference layout (n2 x n1 in, n1 x n2 out;
+    example/ntt_4step/test_4step_ntt.cu:147-178, test_4step_intt.cu:81-179), u64, 2^24, batch 64, forward then inverse,
+    through the plain overload, the RNS overload (one device-side modulus) and FourStepPlan -- 8 distinct polynomials x
+    8 copies, EVERY one of the 64 outputs compared on the device, three times over.  The expected spectra are the
+    reference build's: NTT_4STEP_CPU::ntt of each polynomial, pinned by tests/golden/c3_polys.json
+    (tools/make_golden.py --add-c3), uploaded and transposed on the device into the call's n1 x n2 layout."""
+    import torch
+    P = O.Port(64)
+    rec = json.load(open(os.path.join(golden_dir, "c3_polys.json")))
+    logn, batch, distinct = 24, 64, len(rec["polys"])
+    assert distinct == 8
+    p4 = g.NTTParameters4Step(logn, 64)
+    assert (p4.modulus.value, p4.n1, p4.n2) == (rec["q"], rec["n1"], rec["n2"])
+    n, n1, n2 = p4.n, p4.n1, p4.n2
+    oprm = P.fourstep_params(logn)
+    x_nat = np.concatenate([P.splitmix(r["seed"], 0, n, rec["q"]) for r in rec["polys"]])
+    want = np.empty_like(x_nat)
+    for i, r in enumerate(rec["polys"]):
+        assert sha(x_nat[i * n:(i + 1) * n]) == r["sha_in"]
+        want[i * n:(i + 1) * n] = P.fourstep_ntt(x_nat[i * n:(i + 1) * n], oprm)
+        assert sha(want[i * n:(i + 1) * n]) == r["sha_fwd"], ("oracle != reference build digest", i)
+    d_x = g.to_device(x_nat)
+    # the forward call reads x^T (n2 x n1); its output is the spectrum as n1 x n2 = NTT_4STEP_CPU::ntt's order transposed;
+    # the inverse call returns x so that one GPU_Transpose(n1, n2) restores the natural order
+    exp_in = d_x.view(distinct, n1, n2).transpose(1, 2).contiguous().view(-1)
+    exp_fwd = g.to_device(want).view(distinct, n2, n1).transpose(1, 2).contiguous().view(1, distinct * n)
+    exp_back = d_x.view(distinct, n2, n1).transpose(1, 2).contiguous().view(1, distinct * n)
+    del d_x
+    d_in = exp_in.repeat(batch // distinct)
+    in_digest = int(d_in.view(torch.int64).sum())
+    d_mid = torch.zeros_like(d_in)
+    d_back = torch.zeros_like(d_in)
+    tf = [g.to_device(t) for t in p4.tables["fwd"]]
+    ti = [g.to_device(t) for t in p4.tables["inv"]]
+    cf = g.ntt4step_configuration(n_power=logn, ntt_type=g.FORWARD)
+    ci = g.ntt4step_configuration(n_power=logn, ntt_type=g.INVERSE, mod_inverse=p4.n_inv)
+    mods = g.modulus_array_to_device([p4.modulus], 64)
+    ninv = g.to_device(np.array([p4.n_inv], dtype=np.uint64))
+    rf = g.ntt4step_rns_configuration(n_power=logn, ntt_type=g.FORWARD, mod_inverse=ninv)
+    ri = g.ntt4step_rns_configuration(n_power=logn, ntt_type=g.INVERSE, mod_inverse=ninv)
+    plan_f = g.FourStepPlan(*tf, p4.modulus, cf, batch_hint=batch)
+    plan_i = g.FourStepPlan(*ti, p4.modulus, ci, batch_hint=batch)
+    assert plan_f.fast_path and plan_i.fast_path
+    forms = {
+        "plain": (lambda: g.GPU_4STEP_NTT(d_in, d_mid, *tf, p4.modulus, cf, batch),
+                  lambda: g.GPU_4STEP_NTT(d_mid, d_back, *ti, p4.modulus, ci, batch)),
+        "rns": (lambda: g.GPU_4STEP_NTT(d_in, d_mid, *tf, mods, rf, batch, 1),
+                lambda: g.GPU_4STEP_NTT(d_mid, d_back, *ti, mods, ri, batch, 1)),
+        "plan": (lambda: plan_f.execute(d_in, d_mid, batch), lambda: plan_i.execute(d_mid, d_back, batch)),
+    }
+    g.set_option("path", "fast-strict")
+    try:
+        for it in range(3):
+            for name, (fwd, inv) in forms.items():
+                d_mid.zero_()
+                d_back.zero_()
+                fwd()
+                torch.cuda.synchronize()
+                bad = (d_mid.view(batch // distinct, distinct * n) != exp_fwd).view(batch, n).any(dim=1)
+                assert not bool(bad.any()), ("forward", name, it, torch.nonzero(bad).view(-1).tolist())
+                inv()
+                torch.cuda.synchronize()
+                bad = (d_back.view(batch // distinct, distinct * n) != exp_back).view(batch, n).any(dim=1)
+                assert not bool(bad.any()), ("inverse", name, it, torch.nonzero(bad).view(-1).tolist())
+                assert int(d_in.view(torch.int64).sum()) == in_digest, "the out-of-place call modified its input"
+    finally:
+        g.set_option("path", os.environ.get("GPUNTT_PATH", "default"))
+        plan_f.close()
+        plan_i.close()
+
+
 def test_fourstep_unsupported_size_is_silent(g, capfd):
     # reference ntt_4step.cu:2529-2532: message on stdout, no exception
     import torch

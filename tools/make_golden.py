@@ -95,9 +95,61 @@ def add_fourstep(shapes):
         json.dump(digests, f, indent=1)
 
 
+def add_merge(shapes):
+    """`make_golden.py --add-merge 64:24 32:24`: append Merge digest records (both reduction polynomials) of further
+    ring sizes to digests.json without regenerating the rest (SURVEY.md 8c asks for 2^24)"""
+    path = os.path.join(OUT, "digests.json")
+    digests = json.load(open(path))
+    have = {(r["bits"], r["logn"], r["poly"]) for r in digests["merge"]}
+    for item in shapes:
+        bits, logn = (int(v) for v in item.split(":"))
+        R, P = O.Ref(bits), O.Port(bits)
+        for poly in (O.X_N_plus, O.X_N_minus):
+            if (bits, logn, poly) in have:
+                continue
+            prm = R.merge_params(logn, poly)
+            q = prm["mod"][0]
+            seed = SEED + logn * 4 + poly * 2 + (bits == 32)
+            x = P.splitmix(seed, 0, prm["n"], q)
+            fwd = R.merge_ntt(x, prm, False)
+            inv = R.merge_ntt(x, prm, True)
+            digests["merge"].append(dict(bits=bits, poly=poly, logn=logn, batch=1, seed=seed, q=q, bit=prm["mod"][1],
+                                         mu=prm["mod"][2], omega=prm["omega"], psi=prm["psi"], n_inv=prm["n_inv"],
+                                         root=prm["root"], inv_root=prm["inv_root"], sha_in=sha(x),
+                                         sha_fwd_gpu_table=sha(prm["fwd_gpu"]), sha_inv_gpu_table=sha(prm["inv_gpu"]),
+                                         sha_fwd=sha(fwd), sha_inv=sha(inv)))
+            R.merge_free(prm)
+            print("merge", bits, logn, poly, "added", flush=True)
+    with open(path, "w") as f:
+        json.dump(digests, f, indent=1)
+
+
+def add_c3(count=8):
+    """`make_golden.py --add-c3`: BASELINE config 3's own call (u64, 2^24) on `count` distinct polynomials -- digests of
+    NTT_4STEP_CPU::ntt / ::intt from the reference build for seeds seed0 + 7 i (polynomial 0 is the existing 2^24
+    record), written to tests/golden/c3_polys.json"""
+    R, P = O.Ref(64), O.Port(64)
+    prm = R.fourstep_params(24)
+    q = prm["mod"][0]
+    seed0 = SEED + 1000 + 24 * 2
+    out = dict(bits=64, logn=24, q=q, n1=prm["n1"], n2=prm["n2"], seed0=seed0, stride=7, polys=[])
+    for i in range(count):
+        x = P.splitmix(seed0 + 7 * i, 0, prm["n"], q)
+        out["polys"].append(dict(seed=seed0 + 7 * i, sha_in=sha(x), sha_fwd=sha(R.fourstep_run(x, prm, 0)),
+                                 sha_inv=sha(R.fourstep_run(x, prm, 1))))
+        print("c3 poly", i, "done", flush=True)
+    R.fourstep_free(prm)
+    with open(os.path.join(OUT, "c3_polys.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
 def main():
     if len(sys.argv) > 2 and sys.argv[1] == "--add-fourstep":
         return add_fourstep(sys.argv[2:])
+    if len(sys.argv) > 2 and sys.argv[1] == "--add-merge":
+        return add_merge(sys.argv[2:])
+    if len(sys.argv) > 1 and sys.argv[1] == "--add-c3":
+        return add_c3()
     os.makedirs(OUT, exist_ok=True)
     digests = {"seed": SEED, "merge": [], "fourstep": [], "mt19937": []}
     for bits in (32, 64):
