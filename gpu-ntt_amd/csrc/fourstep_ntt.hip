@@ -182,14 +182,18 @@ namespace gpuntt
                                const Modulus<T>& mod, T ninv, int n_power, int log_n1, int log_n2,
                                int batch_size, hipStream_t stream, const Modulus<T>* mods_dev = nullptr,
                                const T* ninv_dev = nullptr, const unsigned** go_flag_out = nullptr,
-                               const PlanUse<T>& plan = PlanUse<T>())
+                               const PlanUse<T>& plan = PlanUse<T>(), int dev_family = 0)
         {
             using TW = lazy::Tw<T>;
             if (plan.mode != PLAN_NONE && mods_dev != nullptr)
                 return false;
+            // dev_family = 4 (64-bit words, device-side modulus): the SECOND enqueue of the call -- the 4 q kernels that own
+            // it when the go-flag says GO_LAZY_4Q (61- / 62-bit modulus).  The table was prepared by the first enqueue
+            // (prep_merge_from_fourstep permutes it for the family that will run); only the kernels are launched here.
+            const bool do_prep = plan.mode != PLAN_EXECUTE && dev_family == 0;
             // host-side modulus: 61- / 62-bit moduli run the same plans on the LIMIT = 8 / 4 kernels (the whole
             // documented domain of the reference, modular_arith.cuh:66-67), like the Merge entry points
-            int lim = 0;
+            int lim = (mods_dev != nullptr) ? dev_family : 0;
             if (mods_dev == nullptr)
             {
                 if (!host::modulus_fast<T>(mod) || (INV && ninv >= mod.value))
@@ -201,7 +205,7 @@ namespace gpuntt
             if (host::forced_path() == 1)
                 return false;
             // table contract (ntt_4step.cuh): the plans below derive every twiddle from n1_table and one row of W
-            if (plan.mode != PLAN_EXECUTE && host::validate_4step_tables())
+            if (do_prep && host::validate_4step_tables())
                 host::validate_fourstep_tables_or_throw<T>(n1_table, n2_table, w_table, log_n1, log_n2, INV, mod.value, mods_dev,
                                                            stream);
             const size_t n1 = size_t(1) << log_n1, n2 = size_t(1) << log_n2, n = size_t(1) << n_power;
@@ -230,7 +234,7 @@ namespace gpuntt
                 small_tl = 0; // the LIMIT = 8 / 4 kernels exist for 4096-coefficient tiles only
             if (small_tl != 0)
             {
-                if (plan.mode != PLAN_EXECUTE)
+                if (do_prep)
                     host::launch_prep_merge_from_fourstep<T>(n1_table, w_table, ws_w, log_n1, log_n2,
                                                              (n_power >= small_tl) ? small_tl : 0, INV, INV, mod.value, ninv,
                                                              mods_dev, (INV && mods_dev) ? ninv_dev : nullptr, ws_ninv, go_flag,
@@ -285,7 +289,7 @@ namespace gpuntt
                                         ? plan.tile_log
                                         : host::fourstep_fwd_tile<T>(n_power, log_n1, static_cast<unsigned long long>(batch_size),
                                                                      lim, k1);
-                    if (plan.mode != PLAN_EXECUTE)
+                    if (do_prep)
                         host::launch_prep_merge_from_fourstep<T>(n1_table, w_table, ws_w, log_n1, log_n2, tlf, false, false,
                                                                  mod.value, T(0), mods_dev, nullptr, nullptr, go_flag,
                                                                  norm_arr, stream);
@@ -357,7 +361,7 @@ namespace gpuntt
                                                                                   : host::fourstep_inv_tile<T>(n_power, lim);
                 if (host::fourstep_inv_merge_split(n_power, log_n1, k_a, k_b, tli))
                 {
-                    if (plan.mode != PLAN_EXECUTE)
+                    if (do_prep)
                         host::launch_prep_merge_from_fourstep<T>(n1_table, w_table, ws_w, log_n1, log_n2, tli, true, true,
                                                                  mod.value, ninv, mods_dev, mods_dev ? ninv_dev : nullptr,
                                                                  ws_ninv, go_flag, norm_arr, stream);
@@ -672,7 +676,22 @@ namespace gpuntt
                 else
                     fourstep_run_lazy<T, true>(in, out, n1_table, n2_table, w_table, Modulus<T>(), T(0), n_power, l1,
                                                l2, batch_size, stream, mods, ninv_arr, &skip_flag);
+                // 64-bit words: the 4 q family behind the same flag (a 61- / 62-bit modulus), no second preparation
+                if constexpr (sizeof(T) == 8)
+                {
+                    if (skip_flag != nullptr)
+                    {
+                        if (ntt_type == FORWARD)
+                            fourstep_run_lazy<T, false>(in, out, n1_table, n2_table, w_table, Modulus<T>(), T(0), n_power, l1,
+                                                        l2, batch_size, stream, mods, ninv_arr, nullptr, PlanUse<T>(), 4);
+                        else
+                            fourstep_run_lazy<T, true>(in, out, n1_table, n2_table, w_table, Modulus<T>(), T(0), n_power, l1,
+                                                       l2, batch_size, stream, mods, ninv_arr, nullptr, PlanUse<T>(), 4);
+                    }
+                }
             }
+            if (mods != nullptr && mod_count == 1 && skip_flag != nullptr && host::forced_path() == 3)
+                return; // test hook (path = fast-strict): no generic shadow launches -- the lazy families must own the call
             if (mods == nullptr)
             {
                 const bool done =

@@ -48,7 +48,10 @@ namespace gpuntt
         // LIM = 0: the default lazy range of the word size (16 q for 64-bit words, q < 2^60; 4 q for 32-bit words,
         // q < 2^30); LIM = 31: 64-bit words with 31 q < 2^64 (forward transforms); LIM = 8: 64-bit words with 61-bit moduli (8 q < 2^64: one range correction per stage);
         // LIM = 4: 62-bit moduli (4 q < 2^64: products corrected to [0, 2q), the 32-bit scheme in 64-bit words)
-        template <typename T, int LIM = 0> struct Mod;
+        // VQ: the modulus differs per LANE (PerCoefficient layout with an RNS stack: column c uses modulus c % mod_count, and
+        // the lanes of a wave hold different columns) -- q, -q and every multiple of them live in vector registers, and so
+        // do the twiddles; the instruction sequences are the same, only the operand classes change
+        template <typename T, int LIM = 0, bool VQ = false> struct Mod;
 
         // constants of the one-multiply final normalisation (64-bit only): for x < 16 q
         //   k = ((x >> sh) * M) >> (32 + c)  is floor(x / q) or one less, so x - k*q is in [0, 2q)
@@ -98,7 +101,7 @@ namespace gpuntt
         }
 
         // ---- 64-bit: sloppy-quotient Shoup product in [0, 4q); LIMIT 16 needs q < 2^60, LIMIT 8 q < 2^61 ------
-        template <int LIM> struct Mod64
+        template <int LIM, bool VQ = false> struct Mod64
         {
             static constexpr int TB = (LIM == 4) ? 2 : 4; // product bound (units of q)
             static constexpr int LIMIT = LIM;              // lazy values stay below LIMIT * q < 2^64
@@ -172,8 +175,8 @@ namespace gpuntt
                 asm("v_mad_u64_u32 %0, %1, %2, 1, %3" : "=v"(qh), "=s"(carry) : "v"(h2), "v"(qh));
                 uint64_t c = mad32z<UNI>(x0, hi32(t.w));
                 c = mad32<UNI>(x1, lo32(t.w), c);
-                c = mad32<true>(lo32(qh), hi32(qneg), c);
-                c = mad32<true>(hi32(qh), lo32(qneg), c);
+                c = mad32<!VQ>(lo32(qh), hi32(qneg), c);
+                c = mad32<!VQ>(hi32(qh), lo32(qneg), c);
                 uint64_t a = ZERO ? mad32z<UNI>(x0, lo32(t.w)) : mad32<UNI>(x0, lo32(t.w), acc);
                 // the cross sum goes into the accumulator's high word BEFORE the last multiply-add, so the result
                 // leaves the chain as one 64-bit register pair (with the add last, the compiler started the
@@ -181,13 +184,16 @@ namespace gpuntt
                 uint32_t ah;
                 asm("v_add_u32 %0, %1, %2" : "=v"(ah) : "v"(hi32(a)), "v"(lo32(c)));
                 a = (static_cast<uint64_t>(ah) << 32) | lo32(a);
-                return mad32<true>(lo32(qh), lo32(qneg), a);
+                return mad32<!VQ>(lo32(qh), lo32(qneg), a);
             }
-            // 2 x + k (k wave-uniform): one v_lshl_add_u64
+            // 2 x + k (k wave-uniform unless VQ): one v_lshl_add_u64
             __device__ __forceinline__ uint64_t shl1_add(uint64_t x, uint64_t k) const
             {
                 uint64_t d;
-                asm("v_lshl_add_u64 %0, %1, 1, %2" : "=v"(d) : "v"(x), "s"(k));
+                if constexpr (VQ)
+                    asm("v_lshl_add_u64 %0, %1, 1, %2" : "=v"(d) : "v"(x), "v"(k));
+                else
+                    asm("v_lshl_add_u64 %0, %1, 1, %2" : "=v"(d) : "v"(x), "s"(k));
                 return d;
             }
             // x * w  (mod q), any x < 2^64, result in [0, 4q)
@@ -204,23 +210,30 @@ namespace gpuntt
                 const uint64_t m = kq(K);
                 const uint64_t negm = 0 - m;
                 uint64_t d;
-                asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(d) : "v"(x), "s"(negm));
+                if constexpr (VQ)
+                    asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(d) : "v"(x), "v"(negm));
+                else
+                    asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(d) : "v"(x), "s"(negm));
                 return (x >= m) ? d : x;
             }
         };
 
-        template <> struct Mod<uint64_t, 0> : Mod64<16>
+        template <> struct Mod<uint64_t, 0, false> : Mod64<16>
         {
         };
         // 31 q < 2^64 (every prime of the reference's 64-bit pools: 2^59 + small): twice the headroom, forward
         // transforms correct the range every fourth stage instead of every second (host-side switch, lim = 31)
-        template <> struct Mod<uint64_t, 31> : Mod64<31>
+        template <> struct Mod<uint64_t, 31, false> : Mod64<31>
         {
         };
-        template <> struct Mod<uint64_t, 8> : Mod64<8>
+        template <> struct Mod<uint64_t, 8, false> : Mod64<8>
         {
         };
-        template <> struct Mod<uint64_t, 4> : Mod64<4>
+        template <> struct Mod<uint64_t, 4, false> : Mod64<4>
+        {
+        };
+        // per-lane moduli: one family for the whole documented domain (<= 62 bit), the 4 q range
+        template <> struct Mod<uint64_t, 4, true> : Mod64<4, true>
         {
         };
 
@@ -256,12 +269,15 @@ namespace gpuntt
                 return d < x ? d : x;
             }
         };
-        template <> struct Mod<uint32_t, 0> : Mod32<4>
+        template <> struct Mod<uint32_t, 0, false> : Mod32<4>
+        {
+        };
+        template <> struct Mod<uint32_t, 0, true> : Mod32<4> // plain C arithmetic: the same code serves per-lane moduli
         {
         };
         // moduli below 2^29 (the reference's 32-bit pools: 469762049, ...): twice the headroom, a range correction
         // every third forward stage instead of every stage (host-side switch, lim = 8; both directions)
-        template <> struct Mod<uint32_t, 8> : Mod32<8>
+        template <> struct Mod<uint32_t, 8, false> : Mod32<8>
         {
         };
 

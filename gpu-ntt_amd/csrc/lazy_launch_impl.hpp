@@ -31,7 +31,7 @@ namespace gpuntt
                 return;
             if (tiles > 0x7fffffffull)
                 throw std::invalid_argument("batch_size * N too large for one launch");
-            const unsigned grid = static_cast<unsigned>(tiles);
+            const unsigned grid = lazy_grid_cap<T, LIMSEL>(tiles, a.go_flag);
 #define GPUNTT_ONE(CONTIG_, K_, IN_, LAST_)                                                      \
     return launch_lazy_one<T, TLOG, INV, CONTIG_, K_, IN_, LAST_, LIMSEL>(a, grid, stream)
             if constexpr (sizeof(T) == 8 && TLOG >= 13)
@@ -240,7 +240,7 @@ namespace gpuntt
                 return;
             if (tiles > 0x7fffffffull)
                 throw std::invalid_argument("batch_size * N too large for one launch");
-            const unsigned grid = static_cast<unsigned>(tiles);
+            const unsigned grid = lazy_grid_cap<T, LIMSEL>(tiles, a.go_flag);
             switch (k)
             {
 #define GPUNTT_CASE(KK)                                                                                               \
@@ -267,7 +267,7 @@ namespace gpuntt
                 return;
             if (tiles > 0x7fffffffull)
                 throw std::invalid_argument("batch_size * N too large for one launch");
-            const unsigned grid = static_cast<unsigned>(tiles);
+            const unsigned grid = lazy_grid_cap<T, LIMSEL>(tiles, a.go_flag);
             if constexpr (sizeof(T) == 8 && LIMSEL == 0)
                 if (tile_log == 13 && log_n1 == 6)
                 {
@@ -306,7 +306,7 @@ namespace gpuntt
                 return;
             if (tiles > 0x7fffffffull)
                 throw std::invalid_argument("batch_size * N too large for one launch");
-            const unsigned grid = static_cast<unsigned>(tiles);
+            const unsigned grid = lazy_grid_cap<T, LIMSEL>(tiles, a.go_flag);
 #define GPUNTT_ROWS(K_, S_)                                                                                                \
     hipLaunchKernelGGL((kern::merge_pass_lazy<T, 12, true, true, K_, LIM / 2, true, LIMSEL, S_>), dim3(grid),               \
                        dim3(kern::LTile<12>::NT), 0, stream, a)
@@ -435,7 +435,8 @@ namespace gpuntt
                     return;
                 if (tiles > 0x7fffffffull)
                     throw std::invalid_argument("batch_size * N too large for one launch");
-                hipLaunchKernelGGL((kern::fourstep_small_lazy<uint64_t, 12, INV, 12, LIMSEL>), dim3(static_cast<unsigned>(tiles)),
+                hipLaunchKernelGGL((kern::fourstep_small_lazy<uint64_t, 12, INV, 12, LIMSEL>),
+                                   dim3(lazy_grid_cap<uint64_t, LIMSEL>(tiles, a.go_flag)),
                                    dim3(kern::LTile<12>::NT), 0, stream, a);
                 GPUNTT_HIP_CHECK(hipGetLastError());
                 return;

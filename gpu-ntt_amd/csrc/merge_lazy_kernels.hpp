@@ -39,6 +39,8 @@ namespace gpuntt
             int n2_log;                      // 4-step transposing passes: log2 of the row stride of the transposed side
             int row_log;                     // natural-order 4-step row passes (FST = 2): log2 of the row stride of the row-major side (n2); a.n stays the ring (twiddle indices)
             int batch;                       // > 1: polynomials of the call, blocks are ordered poly-minor (big-ring contiguous passes)
+            int col_log;                     // per-lane moduli (VQ, PerCoefficient RNS): log2 of the matrix row = number of columns
+            int mod_shift;                   // per-lane moduli (VQ): log2 of the table stride per modulus (the ring size n_power)
             unsigned long long total;
             int n;
             int poly_shift;
@@ -352,17 +354,23 @@ namespace gpuntt
             }
         }
 
+        // VQ: per-lane moduli -- the PerCoefficient layout with an RNS stack (reference ForwardCoreTranspose /
+        // InverseCoreTranspose, src/lib/ntt_merge/ntt.cu:1554-2074: column c uses modulus c % mod_count with its own table
+        // slot and n^-1).  Strided passes only; the 16 coefficients of a thread lie in ONE column in every round (register
+        // windows of strided passes never dip below the contiguous-run bits), so a thread keeps one modulus for the pass
+        // and only the operand classes change: q, -q, twiddles and n^-1 in vector registers (lazy::Mod<T, LIM, true>).
         template <typename T, int TLOG, bool EXACT, bool INV, bool CONTIG, int K, int IN_BOUND, bool LAST,
-                  int FST = 0, int LIM = 0, int XP = 0, int SKIP = 0>
+                  int FST = 0, int LIM = 0, int XP = 0, int SKIP = 0, bool VQ = false>
         __device__ __forceinline__ void pass_body(const LazyArgsT<T>& a, T* lds, T q_value, T q_bit, T q_mu,
                                                   int mi, unsigned long long fst_poly = 0,
                                                   unsigned fst_tile = 0, long long blk_override = -1,
                                                   unsigned fst_seg = 0)
         {
             using G = LGeo<TLOG, CONTIG, K>;
-            using M = lazy::Mod<T, LIM>;
+            using M = lazy::Mod<T, LIM, VQ>;
             using SCH = PassSched<TLOG, INV, CONTIG, K, IN_BOUND, M::LIMIT, M::TB, SKIP>;
             using TW = lazy::Tw<T>;
+            static_assert(!VQ || (!CONTIG && !FST && !XP && !EXACT && SKIP == 0), "per-lane moduli: plain strided passes");
             constexpr int TL = TLOG;
             constexpr int NT = LTile<TLOG>::NT;
             constexpr int NR_ = SCH::NR;
@@ -395,6 +403,16 @@ namespace gpuntt
             const bool tile_in_range = (CONTIG && !FST) ? ((map.base + LTile<TLOG>::TILE) <= a.total) : true;
             if (a.poly_order != nullptr)
                 map.remap_poly(a.poly_order, a.n); // twiddle indices use flat & (N-1): unaffected
+            if constexpr (VQ)
+            {
+                // the thread's column (the same in every round, see above) picks its modulus
+                const unsigned col = static_cast<unsigned>(map.flat(elem_of<SCH::wl_of(0)>(t, 0))) & ((1u << a.col_log) - 1u);
+                mi = static_cast<int>(col % static_cast<unsigned>(a.mod_count));
+                const Modulus<T> md = a.mods[mi];
+                q_value = md.value;
+                q_bit = md.bit;
+                q_mu = md.mu;
+            }
             // lazy::Mod64::mul_acc_raw names the fixed register pair v[126:127]: every 64-bit kernel must be compiled for a
             // budget of AT LEAST 128 VGPRs, i.e. at most 4 waves per SIMD in its __launch_bounds__
             static_assert(sizeof(T) != 8 || LOcc<TLOG, T>::WAVES <= 4,
@@ -402,7 +420,7 @@ namespace gpuntt
             M m;
             m.set(q_value, (a.norm_arr != nullptr) ? a.norm_arr[mi] : a.norm);
             const dev::ModCtx<T> em{q_value, q_bit, q_mu};
-            const unsigned long long root_base = static_cast<unsigned long long>(mi) << a.n;
+            const unsigned long long root_base = static_cast<unsigned long long>(mi) << (VQ ? a.mod_shift : a.n);
             // (word by word: selecting between the two 8-byte structs as a whole left a dead 16-byte stack slot --
             // and with it a scratch allocation -- in every 32-bit inverse kernel)
             T ninv_w = a.ninv.w, ninv_wp = a.ninv.wp;
@@ -772,6 +790,7 @@ namespace gpuntt
                         constexpr int j1 = j0 | (1 << jb);
                         constexpr int kk = j0 >> (jb + 1);
                         const TW tw = tw_cur[off + kk];
+                        constexpr bool UNI_TW = UNIFORM_R && !VQ; // twiddle in scalar registers
                         if constexpr (EXACT)
                         {
                             if constexpr (!INV)
@@ -789,14 +808,14 @@ namespace gpuntt
                             // butterfly (block-uniform scalar test, so tables that differ still work);
                             // V is a canonical input there, so V itself is the product
                             bool unit = false;
-                            if constexpr (UNIFORM_R && r == 0 && s == 0 && IN_BOUND <= M::TB && !FST)
+                            if constexpr (UNI_TW && r == 0 && s == 0 && IN_BOUND <= M::TB && !FST)
                                 unit = (tw.w == 1);
                             // U' = U + T comes out of the product's own multiply-add chain;
                             // V' = U - T + TB q = 2 U + TB q - U'  (mod 2^W; the true value is below LIMIT q)
                             // (32-bit words: the separate product is one instruction shorter)
                             if constexpr (sizeof(T) == 8)
                             {
-                                const T nu = unit ? static_cast<T>(U + v[j1]) : m.template mul_acc<UNIFORM_R>(v[j1], tw, U);
+                                const T nu = unit ? static_cast<T>(U + v[j1]) : m.template mul_acc<UNI_TW>(v[j1], tw, U);
                                 v[j0] = nu;
                                 // 2 U + TB q as ONE v_lshl_add_u64, then one 64-bit subtract: kept opaque so that
                                 // the sum is not re-associated into shift, subtract, add (a fourth instruction)
@@ -804,7 +823,7 @@ namespace gpuntt
                             }
                             else
                             {
-                                const T Tm = unit ? v[j1] : m.template mul<UNIFORM_R>(v[j1], tw);
+                                const T Tm = unit ? v[j1] : m.template mul<UNI_TW>(v[j1], tw);
                                 v[j0] = U + Tm;
                                 v[j1] = U + m.kq(M::TB) - Tm;
                             }
@@ -823,7 +842,7 @@ namespace gpuntt
                             // w * n^-1, so scaling the sum as well finishes the n^-1 product (the product
                             // takes any 64-bit value: no range correction of the sum there)
                             if constexpr (LAST && r == NR_ - 1 && s == STAGES - 1)
-                                v[j0] = m.template mul<true>(U + V, ninv);
+                                v[j0] = m.template mul<!VQ>(U + V, ninv);
                             else
                             {
                                 constexpr int ko = SCH::d.ko[r][s][h];
@@ -832,7 +851,7 @@ namespace gpuntt
                                     S = m.template csub<ko>(S);
                                 v[j0] = S;
                             }
-                            v[j1] = m.template mul<UNIFORM_R>(U + m.kq(c) - V, tw);
+                            v[j1] = m.template mul<UNI_TW>(U + m.kq(c) - V, tw);
                         }
                     });
                     off += 1 << (R - 1 - jb);
@@ -848,7 +867,7 @@ namespace gpuntt
                     {
                         // moduli of >= 48 bits: quotient estimate from the high word (one shift less per coefficient);
                         // the test is wave-uniform, both forms are straight-line code
-                        if (m.hi_norm())
+                        if (!VQ && m.hi_norm())
                             static_for<EPT>([&](auto j_) {
                                 constexpr int j = decltype(j_)::value;
                                 v[j] = lazy::normalize<SCH::d.bout[r][j], true>(m, v[j]);
@@ -1088,6 +1107,40 @@ namespace gpuntt
             });
         }
 
+        // Drop-in RNS calls keep their moduli in device memory, so the host cannot pick the kernel family: the preparation
+        // kernel classifies the stack and publishes a three-state go-flag (prep.hip: 0 = generic Barrett kernels, 1 = the
+        // default lazy range of the word size, 2 = 64-bit words with a 61- / 62-bit modulus in the stack: the 4 q range),
+        // every family is enqueued and the ones the flag does not name return at once.
+        constexpr unsigned GO_GENERIC = 0u, GO_LAZY = 1u, GO_LAZY_4Q = 2u;
+        template <typename T, int LIM> __device__ __forceinline__ bool not_my_call(const unsigned* go_flag)
+        {
+            return go_flag != nullptr && *go_flag != ((sizeof(T) == 8 && LIM == 4) ? GO_LAZY_4Q : GO_LAZY);
+        }
+
+        // The 4 q family of 64-bit words is enqueued behind EVERY drop-in RNS call as a shadow of the default family (it owns
+        // the call only when the stack holds a 61- / 62-bit prime).  A skipped launch costs about 0.4 ns per block (7 us for
+        // the 16384 blocks of a C2-sized pass, > 100 us for a C3-sized one), so that family runs on a CAPPED grid whose blocks
+        // walk the tiles (host: lazy_grid_cap) -- like the generic kernels' shadow launches (merge_kernels.hpp).  f(block
+        // index, number of blocks of the uncapped grid).
+        template <typename T, int LIM> struct WalksTiles
+        {
+            static constexpr bool value = (sizeof(T) == 8 && LIM == 4);
+        };
+        template <bool WALK, typename F> __device__ __forceinline__ void for_each_block(unsigned nblocks, F&& f)
+        {
+            if constexpr (WALK)
+            {
+                for (unsigned vb = blockIdx.x; vb < nblocks; vb += gridDim.x)
+                {
+                    if (vb != blockIdx.x)
+                        __syncthreads(); // every wave is done with the LDS of the previous tile
+                    f(vb, nblocks);
+                }
+            }
+            else
+                f(blockIdx.x, gridDim.x);
+        }
+
         // Poly-minor block order (the polynomials of a batch that share a slice of the twiddle / W table run back
         // to back), XCD-aware: the dispatcher sends workgroup b to XCD b % 8 and every XCD has its own L2, so a
         // slice shared by consecutive block indices is fetched from the fabric once per XCD -- up to 8 times
@@ -1122,10 +1175,12 @@ namespace gpuntt
             constexpr bool NEEDS_LDS = (SCH::NR > 1) || (SCH::wl_of(0) < 4);
             __shared__ T lds[NEEDS_LDS ? LTile<TLOG>::LDS_ELEMS : 1];
 
-            // RNS calls: the twiddle-prep kernel publishes whether every modulus has the lazy
-            // headroom; if not, the generic kernels launched alongside do the work
-            if (a.go_flag != nullptr && *a.go_flag == 0u)
+            // RNS calls: the twiddle-prep kernel publishes which kernel family the stack of moduli needs (not_my_call);
+            // the other families, launched alongside, return here
+            if (not_my_call<T, LIM>(a.go_flag))
                 return;
+            for_each_block<WalksTiles<T, LIM>::value>(
+                static_cast<unsigned>((a.total + LTile<TLOG>::TILE - 1) >> TLOG), [&](unsigned bidx, unsigned nblk) {
             // the block's modulus: polynomial index of the tile % mod_count (tiles never straddle
             // polynomials with different moduli here: RNS calls with N < tile and mod_count > 1
             // are routed to the generic kernels by the host)
@@ -1136,7 +1191,7 @@ namespace gpuntt
             // twiddle table back to back (L2 hits instead of one HBM read per polynomial)
             // F_REVERSE: consecutive passes of one transform walk the batch in opposite directions, so a pass
             // starts on the data its predecessor wrote last -- the part still in the 256 MiB Infinity Cache
-            const unsigned bx = (a.flags & F_REVERSE) ? (gridDim.x - 1u - blockIdx.x) : blockIdx.x;
+            const unsigned bx = (a.flags & F_REVERSE) ? (nblk - 1u - bidx) : bidx;
             long long blk = static_cast<long long>(bx);
             if (a.batch > 1)
             {
@@ -1156,6 +1211,29 @@ namespace gpuntt
                 qm = md.mu;
             }
             pass_body<T, TLOG, false, INV, CONTIG, K, IN_BOUND, LAST, 0, LIM, 0, SKIP>(a, lds, qv, qb, qm, mi, 0, 0, blk);
+                });
+        }
+
+        // PerCoefficient layout with an RNS stack: strided pass with per-lane moduli (pass_body VQ).  One lazy family serves
+        // every modulus of the documented domain -- 64-bit words the 4 q range (<= 62 bit), 32-bit words the default one
+        // -- so the go-flag only separates it from the generic kernels.  a.n = log2(N * batch) (the virtual ring the
+        // columns form), a.col_log = log2 batch, a.mod_shift = log2 N, a.mods / a.ninv_arr / a.norm_arr per modulus.
+        template <typename T> struct VqLim
+        {
+            static constexpr int LIM = (sizeof(T) == 8) ? 4 : 0;
+        };
+        template <typename T, bool INV, int K, int IN_BOUND, bool LAST>
+        __global__ __launch_bounds__(LTile<12>::NT, (LOcc<12, T>::WAVES)) void merge_pass_lazy_vq(LazyArgsT<T> a)
+        {
+            constexpr int LIM = VqLim<T>::LIM;
+            using M = lazy::Mod<T, LIM, true>;
+            using SCH = PassSched<12, INV, false, K, IN_BOUND, M::LIMIT, M::TB, 0>;
+            constexpr bool NEEDS_LDS = (SCH::NR > 1) || (SCH::wl_of(0) < 4);
+            __shared__ T lds[NEEDS_LDS ? LTile<12>::LDS_ELEMS : 1];
+            if (a.go_flag != nullptr && *a.go_flag == GO_GENERIC)
+                return;
+            pass_body<T, 12, false, INV, false, K, IN_BOUND, LAST, 0, LIM, 0, 0, true>(a, lds, 0, 0, 0, 0, 0, 0,
+                                                                                       static_cast<long long>(blockIdx.x));
         }
 
         // block -> (polynomial, tile of the polynomial) for the transposing row passes of the natural-order 4-step: tile =
@@ -1216,7 +1294,7 @@ namespace gpuntt
         __global__ __launch_bounds__(LTile<12>::NT, (LOcc<12, T>::WAVES)) void fourstep_first_lazy(LazyArgsT<T> a)
         {
             __shared__ T lds[LTile<12>::LDS_ELEMS];
-            if (a.go_flag != nullptr && *a.go_flag == 0u)
+            if (not_my_call<T, LIM>(a.go_flag))
                 return;
             T qv = a.q, qb = a.q_bit, qm = a.q_mu;
             if (a.mods != nullptr)
@@ -1226,9 +1304,11 @@ namespace gpuntt
                 qb = md.bit;
                 qm = md.mu;
             }
-            const unsigned bx = (a.flags & F_REVERSE) ? (gridDim.x - 1u - blockIdx.x) : blockIdx.x;
-            pass_body<T, 12, false, false, false, K, 1, false, 0, LIM, 5>(a, lds, qv, qb, qm, 0, 0, 0,
-                                                                          static_cast<long long>(bx));
+            for_each_block<WalksTiles<T, LIM>::value>(static_cast<unsigned>(a.total >> 12), [&](unsigned bidx, unsigned nblk) {
+                const unsigned bx = (a.flags & F_REVERSE) ? (nblk - 1u - bidx) : bidx;
+                pass_body<T, 12, false, false, false, K, 1, false, 0, LIM, 5>(a, lds, qv, qb, qm, 0, 0, 0,
+                                                                              static_cast<long long>(bx));
+            });
         }
 
         // inverse 4-step, first pass in Merge form (FST = 3).  With e = (a << l1) | b the natural index of the result x =
@@ -1245,7 +1325,7 @@ namespace gpuntt
         __global__ __launch_bounds__(LTile<TLOG>::NT, (LOcc<TLOG, T>::WAVES)) void fourstep_inv_first_lazy(LazyArgsT<T> a)
         {
             __shared__ T lds[LTile<TLOG>::LDS_ELEMS_FST];
-            if (a.go_flag != nullptr && *a.go_flag == 0u)
+            if (not_my_call<T, LIM>(a.go_flag))
                 return;
             T qv = a.q, qb = a.q_bit, qm = a.q_mu;
             if (a.mods != nullptr)
@@ -1255,18 +1335,20 @@ namespace gpuntt
                 qb = md.bit;
                 qm = md.mu;
             }
-            const unsigned bx = (a.flags & F_REVERSE) ? (gridDim.x - 1u - blockIdx.x) : blockIdx.x;
-            const int tiles_log = a.n - TLOG;
-            unsigned poly, tile;
-            if (a.batch > 1)
-                poly_minor_order(bx, static_cast<unsigned>(a.batch), tiles_log, poly, tile, a.flags);
-            else
-            {
-                poly = bx >> tiles_log;
-                tile = bx & ((1u << tiles_log) - 1u);
-            }
-            pass_body<T, TLOG, false, true, true, TLOG, 1, false, 3, LIM, 16 + L1>(a, lds, qv, qb, qm, 0, uniform32(poly),
-                                                                                  uniform32(tile));
+            for_each_block<WalksTiles<T, LIM>::value>(static_cast<unsigned>(a.total >> TLOG), [&](unsigned bidx, unsigned nblk) {
+                const unsigned bx = (a.flags & F_REVERSE) ? (nblk - 1u - bidx) : bidx;
+                const int tiles_log = a.n - TLOG;
+                unsigned poly, tile;
+                if (a.batch > 1)
+                    poly_minor_order(bx, static_cast<unsigned>(a.batch), tiles_log, poly, tile, a.flags);
+                else
+                {
+                    poly = bx >> tiles_log;
+                    tile = bx & ((1u << tiles_log) - 1u);
+                }
+                pass_body<T, TLOG, false, true, true, TLOG, 1, false, 3, LIM, 16 + L1>(a, lds, qv, qb, qm, 0, uniform32(poly),
+                                                                                      uniform32(tile));
+            });
         }
 
         // 4-step transform of a ring that fits one tile (2^12 .. 2^14): ONE contiguous Merge pass over the whole ring
@@ -1278,7 +1360,7 @@ namespace gpuntt
         {
             static_assert(K >= 12 && K == TLOG, "one-tile 4-step rings fill their tile: 32 x n2 with n2 >= 128");
             __shared__ T lds[LTile<TLOG>::LDS_ELEMS];
-            if (a.go_flag != nullptr && *a.go_flag == 0u)
+            if (not_my_call<T, LIM>(a.go_flag))
                 return;
             T qv = a.q, qb = a.q_bit, qm = a.q_mu;
             if (a.mods != nullptr)
@@ -1288,8 +1370,11 @@ namespace gpuntt
                 qb = md.bit;
                 qm = md.mu;
             }
-            pass_body<T, TLOG, false, INV, true, K, 1, true, 0, LIM, NAT ? (INV ? 4 : 3) : (INV ? 2 : 1)>(
-                a, lds, qv, qb, qm, 0, 0, 0, static_cast<long long>(blockIdx.x));
+            for_each_block<WalksTiles<T, LIM>::value>(
+                static_cast<unsigned>((a.total + LTile<TLOG>::TILE - 1) >> TLOG), [&](unsigned bidx, unsigned) {
+                    pass_body<T, TLOG, false, INV, true, K, 1, true, 0, LIM, NAT ? (INV ? 4 : 3) : (INV ? 2 : 1)>(
+                        a, lds, qv, qb, qm, 0, 0, 0, static_cast<long long>(bidx));
+                });
         }
 
     } // namespace kern

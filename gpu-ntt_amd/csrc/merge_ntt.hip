@@ -62,8 +62,8 @@ namespace gpuntt
         // Used for calls whose moduli leave the lazy headroom: bit <= 60 (Data64) / bit <= 30 (Data32).
         //   single modulus: the host sees Modulus<T>::bit and picks the path;
         //   RNS: the moduli live in device memory, so the twiddle-prep kernel classifies them and
-        //        publishes a go-flag; the fast kernels AND the generic kernels are both enqueued,
-        //        each returning at once when the flag says the call belongs to the other family.
+        //        publishes a three-state go-flag (generic / default lazy range / 4 q range); every family is
+        //        enqueued, each returning at once when the flag names another one (run_transform_lazy_rns).
         // Tiny single-modulus rings (below 2^5 / 2^11), small RNS jobs, rings above 2^24 and RNS
         // stacks of rings below one tile use the generic kernels only.
         // option path = generic | fast overrides the size heuristic (testing / A-B timing; host::set_option);
@@ -184,6 +184,34 @@ namespace gpuntt
             return a;
         }
 
+        // Drop-in RNS calls (moduli in device memory): every lazy family is enqueued behind the three-state go-flag the
+        // preparation kernel publishes (kern::not_my_call) -- the default range of the word size and, for 64-bit words,
+        // the 4 q family that serves a stack with a 61- / 62-bit prime (4096-coefficient tiles; prep_twiddles lays the
+        // table out for the family that will run).  The families the flag does not name return at once; the generic
+        // kernels behind them (capped shadow grid) are left with moduli outside the documented domain.
+        template <typename TU, bool INV>
+        inline void run_transform_lazy_rns(const kern::LazyArgsT<TU>& la, unsigned in_flags, unsigned out_flags,
+                                           hipStream_t stream)
+        {
+            host::run_transform_lazy<TU, INV>(la, in_flags, out_flags, stream);
+            if constexpr (sizeof(TU) == 8)
+            {
+                kern::LazyArgsT<TU> wide = la;
+                wide.lim = 4;
+                host::run_transform_lazy<TU, INV>(wide, in_flags, out_flags, stream);
+            }
+        }
+
+        // option path = generic-capped (test hook): a device word holding kern::GO_GENERIC, so that the generic kernels of an
+        // RNS call run exactly as they do behind a go-flag that names them -- capped grid, blocks walking the tiles.  (No
+        // modulus of the documented domain reaches that state any more: 61- / 62-bit primes run the 4 q lazy family.)
+        inline const unsigned* zeroed_flag(hipStream_t stream)
+        {
+            auto* flag = static_cast<unsigned*>(host::lazy_workspace(stream, 16));
+            GPUNTT_HIP_CHECK(hipMemsetAsync(flag, 0, 16, stream));
+            return flag;
+        }
+
         // ---- PerCoefficient (column-wise) layout ------------------------------------------
         // The matrix is N rows (coefficient index) x batch columns (polynomials), row-major; every
         // column is transformed (reference ForwardCoreTranspose / InverseCoreTranspose,
@@ -259,6 +287,84 @@ namespace gpuntt
                 host::launch_pass_lazy<TU, INV>(p, 12, i == 0, i == pl.count - 1, b, stream);
                 src = out;
             }
+            return true;
+        }
+
+        // PerCoefficient layout with an RNS stack (column c = a polynomial of modulus c % mod_count, table slot and n^-1 of
+        // that modulus: reference ForwardCoreTranspose / InverseCoreTranspose, ntt.cu:1693-1835, 1957-2074) on the lazy
+        // kernels with PER-LANE moduli (kern::merge_pass_lazy_vq): the lanes of a wave hold different columns, so q, -q, the
+        // twiddles and n^-1 are vector operands; one family covers the documented domain (64-bit: the 4 q range, <= 62 bit).
+        // The moduli live in device memory: the preparation kernel classifies them, *go_flag_out receives the flag the
+        // generic kernels behind this call must test.  false: the call must take the generic kernels alone.
+        template <typename TU, bool INV>
+        bool run_percoefficient_lazy_rns(const void* in, TU* out, const TU* roots, const Modulus<TU>* mods_dev, int mod_count,
+                                         const TU* ninv_dev, int n_power, ReductionPolynomial poly, int batch_size,
+                                         unsigned in_flags, unsigned out_flags, hipStream_t stream,
+                                         const unsigned** go_flag_out)
+        {
+            using TW = lazy::Tw<TU>;
+            if (batch_size <= 0 || (batch_size & (batch_size - 1)) != 0 || mod_count < 1)
+                return false; // (the generic path reports the error)
+            if (forced_path() == 1 || forced_path() == 4 || (INV && ninv_dev == nullptr))
+                return false;
+            int log_w = 0;
+            while ((1 << log_w) < batch_size)
+                log_w++;
+            const int nv = n_power + log_w;
+            if (nv < 12 || nv > 30)
+                return false;
+            host::Plan pl{};
+            const int np = (n_power + 7) / 8;
+            int top = n_power;
+            for (int i = 0; i < np; i++)
+            {
+                const int k = n_power / np + ((i < n_power % np) ? 1 : 0);
+                top -= k;
+                pl.pass[pl.count++] = host::Pass{false, k, log_w + top};
+                if (12 - k > log_w + top)
+                    return false; // a tile row would be wider than the matrix row: small-matrix kernel (generic)
+            }
+            const size_t entries = (static_cast<size_t>(mod_count) << n_power) + mod_count;
+            const size_t norm_bytes = (sizeof(lazy::NormConst) * static_cast<size_t>(mod_count) + 15u) & ~size_t(15);
+            auto* ws = static_cast<TW*>(host::lazy_workspace(stream, sizeof(TW) * entries + 16 + norm_bytes, true));
+            if (ws == nullptr)
+                return false;
+            TW* ws_ninv = ws + (static_cast<size_t>(mod_count) << n_power);
+            unsigned char* tail_p = reinterpret_cast<unsigned char*>(ws + entries);
+            unsigned* go_flag = reinterpret_cast<unsigned*>(tail_p);
+            auto* norm_arr = reinterpret_cast<lazy::NormConst*>(tail_p + 16);
+            const bool neg = (poly == ReductionPolynomial::X_N_plus);
+            host::launch_prep<TU>(roots, ws, mods_dev, TU(0), mod_count, n_power, neg, 0, INV ? ninv_dev : nullptr,
+                                  INV ? ws_ninv : nullptr, go_flag, norm_arr, stream, nullptr, nullptr, INV);
+            kern::LazyArgsT<TU> a{};
+            a.tw = ws;
+            a.mods = mods_dev;
+            a.ninv = TW{0, 0};
+            a.ninv_arr = INV ? ws_ninv : nullptr;
+            a.norm_arr = norm_arr;
+            a.go_flag = go_flag;
+            a.total = 1ull << nv;
+            a.n = nv;
+            a.poly_shift = nv;
+            a.mod_count = mod_count;
+            a.col_log = log_w;
+            a.mod_shift = n_power;
+            const void* src = in;
+            for (int i = 0; i < pl.count; i++)
+            {
+                const host::Pass& p = INV ? pl.pass[pl.count - 1 - i] : pl.pass[i];
+                kern::LazyArgsT<TU> b = a;
+                b.in = src;
+                b.out = out;
+                b.p_lo = p.p_lo;
+                if (i == 0)
+                    b.flags |= in_flags;
+                if (i == pl.count - 1)
+                    b.flags |= out_flags;
+                host::launch_pass_lazy_vq<TU, INV>(p, i == 0, i == pl.count - 1, b, stream);
+                src = out;
+            }
+            *go_flag_out = go_flag;
             return true;
         }
 
@@ -450,16 +556,30 @@ namespace gpuntt
                                                  cfg.reduction_poly, batch_size);
             a.mods = modulus;
             a.mod_count = mod_count;
+            const bool lazy = run_percoefficient_lazy_rns<TU, false>(device_in, device_out, root_of_unity_table, modulus,
+                                                                     mod_count, nullptr, cfg.n_power, cfg.reduction_poly,
+                                                                     batch_size, in_flags, 0u, cfg.stream, &skip_flag);
+            if (forced_path() == 3)
+            {
+                if (!lazy)
+                    throw std::invalid_argument("fast path unavailable for this call (path = fast-strict)");
+                return; // test hook: no generic shadow launches
+            }
+            a.skip_flag = skip_flag;
             run_percoefficient<TU, false>(a, cfg.n_power, batch_size, in_flags, 0u, cfg.stream);
             return;
         }
-        if (batch_size > 0 && lazy_eligible<TU>(cfg.n_power, batch_size, mod_count, cfg.stream))
+        if (batch_size > 0 && forced_path() == 4)
+            skip_flag = zeroed_flag(cfg.stream); // test hook: the generic kernels as they run behind a go-flag that names them
+        else if (batch_size > 0 && lazy_eligible<TU>(cfg.n_power, batch_size, mod_count, cfg.stream))
         {
             kern::LazyArgsT<TU> la =
                 lazy_args<TU>(device_in, device_out, root_of_unity_table, Modulus<TU>(), modulus, mod_count,
                               nullptr, cfg.n_power, cfg.reduction_poly, batch_size, cfg.stream);
-            host::run_transform_lazy<TU, false>(la, in_flags, 0u, cfg.stream);
+            run_transform_lazy_rns<TU, false>(la, in_flags, 0u, cfg.stream);
             skip_flag = la.go_flag;
+            if (forced_path() == 3)
+                return; // test hook (path = fast-strict): no generic shadow launches -- the lazy families must own the call
         }
         kern::PassArgs<TU> a = base_args<TU>(device_in, device_out, root_of_unity_table, cfg.n_power,
                                              cfg.reduction_poly, batch_size);
@@ -493,18 +613,33 @@ namespace gpuntt
             a.mods = modulus;
             a.mod_count = mod_count;
             a.ninv_arr = cfg.mod_inverse;
+            const bool lazy = run_percoefficient_lazy_rns<TU, true>(device_in, reinterpret_cast<TU*>(device_out),
+                                                                    root_of_unity_table, modulus, mod_count, cfg.mod_inverse,
+                                                                    cfg.n_power, cfg.reduction_poly, batch_size, 0u, out_flags,
+                                                                    cfg.stream, &skip_flag);
+            if (forced_path() == 3)
+            {
+                if (!lazy)
+                    throw std::invalid_argument("fast path unavailable for this call (path = fast-strict)");
+                return; // test hook: no generic shadow launches
+            }
+            a.skip_flag = skip_flag;
             run_percoefficient<TU, true>(a, cfg.n_power, batch_size, 0u, out_flags, cfg.stream);
             return;
         }
-        if (batch_size > 0 && cfg.mod_inverse != nullptr &&
+        if (batch_size > 0 && forced_path() == 4)
+            skip_flag = zeroed_flag(cfg.stream); // test hook: the generic kernels as they run behind a go-flag that names them
+        else if (batch_size > 0 && cfg.mod_inverse != nullptr &&
             lazy_eligible<TU>(cfg.n_power, batch_size, mod_count, cfg.stream))
         {
             kern::LazyArgsT<TU> la =
                 lazy_args<TU>(device_in, reinterpret_cast<TU*>(device_out), root_of_unity_table,
                               Modulus<TU>(), modulus, mod_count, cfg.mod_inverse, cfg.n_power,
                               cfg.reduction_poly, batch_size, cfg.stream);
-            host::run_transform_lazy<TU, true>(la, 0u, out_flags, cfg.stream);
+            run_transform_lazy_rns<TU, true>(la, 0u, out_flags, cfg.stream);
             skip_flag = la.go_flag;
+            if (forced_path() == 3)
+                return; // test hook (path = fast-strict): no generic shadow launches
         }
         kern::PassArgs<TU> a =
             base_args<TU>(device_in, reinterpret_cast<TU*>(device_out), root_of_unity_table,
@@ -701,7 +836,7 @@ namespace gpuntt
             kern::LazyArgsT<T> la = lazy_args<T>(second, device_out, forward_table, Modulus<T>(), modulus, mod_count,
                                                  nullptr, cfg.n_power, cfg.reduction_poly, batch_size, cfg.stream);
             la.mul_in = first;
-            host::run_transform_lazy<T, false>(la, 0u, 0u, cfg.stream);
+            run_transform_lazy_rns<T, false>(la, 0u, 0u, cfg.stream);
             skip_flag = la.go_flag;
         }
         {
@@ -1005,9 +1140,9 @@ namespace gpuntt
                                  batch_size, cfg.stream, mod_order);
                 la.poly_order = poly_order;
                 if (inv)
-                    host::run_transform_lazy<T, true>(la, 0u, kern::F_SCALE, cfg.stream);
+                    run_transform_lazy_rns<T, true>(la, 0u, kern::F_SCALE, cfg.stream);
                 else
-                    host::run_transform_lazy<T, false>(la, 0u, 0u, cfg.stream);
+                    run_transform_lazy_rns<T, false>(la, 0u, 0u, cfg.stream);
                 skip_flag = la.go_flag;
             }
             kern::PassArgs<T> a = base_args<T>(device_in, device_out, table, cfg.n_power,

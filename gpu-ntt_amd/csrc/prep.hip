@@ -100,19 +100,37 @@ namespace gpuntt
                                                              T ninv_single, int fold_ninv)
         {
             const unsigned long long gid = blockIdx.x * 256ull + threadIdx.x;
-            if (gid == 0 && go_flag != nullptr)
+            // RNS stacks (moduli in device memory): classify the stack -- kern::GO_GENERIC (a modulus outside the fast
+            // kernels' domain), GO_LAZY (every modulus leaves the default lazy range of the word size its headroom: bit <= 60 /
+            // 30) or GO_LAZY_4Q (64-bit words, a 61- / 62-bit modulus in the stack: the 4 q kernels, 4096-coefficient tiles
+            // only).  Block 0 publishes the state; every block needs it when the default family would run on a bigger tile,
+            // because the per-tile permutation of the last three stages must match the family that will really run.
+            unsigned state = GO_LAZY;
+            if (mods != nullptr && (perm_tile_log > 12 || blockIdx.x == 0))
             {
-                // every modulus must leave the lazy kernels their headroom
-                unsigned ok = 1u;
-                for (int i = 0; i < mod_count; i++)
+                bool bad = false, wide = false;
+                for (int i = static_cast<int>(threadIdx.x); i < mod_count; i += 256)
                 {
                     const Modulus<T> md = mods[mod_order != nullptr ? mod_order[i] : i];
-                    if (md.bit > static_cast<T>(lazy::Mod<T>::MAX_BIT) || md.value < 3)
-                        ok = 0u;
-                    if (norm_arr != nullptr)
-                        norm_arr[i] = lazy::make_norm_const(md.value, md.bit);
+                    if (md.value < 3 || md.bit > static_cast<T>(sizeof(T) == 8 ? 62 : lazy::Mod<T>::MAX_BIT))
+                        bad = true;
+                    else if (md.bit > static_cast<T>(lazy::Mod<T>::MAX_BIT))
+                        wide = true;
                 }
-                *go_flag = ok;
+                const int any_bad = __syncthreads_or(bad ? 1 : 0), any_wide = __syncthreads_or(wide ? 1 : 0);
+                state = any_bad ? GO_GENERIC : (any_wide ? GO_LAZY_4Q : GO_LAZY);
+            }
+            if (state == GO_LAZY_4Q && perm_tile_log > 12)
+                perm_tile_log = 12;
+            if (gid == 0 && go_flag != nullptr)
+            {
+                if (norm_arr != nullptr)
+                    for (int i = 0; i < mod_count; i++)
+                    {
+                        const Modulus<T> md = mods[mod_order != nullptr ? mod_order[i] : i];
+                        norm_arr[i] = lazy::make_norm_const(md.value, md.bit);
+                    }
+                *go_flag = state;
             }
             const unsigned long long per_mod = 1ull << n;
             // RNS stacks: the reciprocal of the block's modulus is derived once per block (a block
@@ -200,10 +218,17 @@ namespace gpuntt
                     s_rinv = recip_norm<T>(q);
                 __syncthreads();
                 rinv = s_rinv;
+                // three-state go-flag, like prep_twiddles; a 61- / 62-bit modulus runs the 4 q family on 4096-coefficient
+                // tiles, so the table takes that tile's permutation
+                const unsigned state = (md.value < 3 || md.bit > static_cast<T>(sizeof(T) == 8 ? 62 : lazy::Mod<T>::MAX_BIT))
+                                           ? GO_GENERIC
+                                           : (md.bit > static_cast<T>(lazy::Mod<T>::MAX_BIT) ? GO_LAZY_4Q : GO_LAZY);
+                if (state == GO_LAZY_4Q && perm_tile_log > 12)
+                    perm_tile_log = 12;
                 if (gid == 0)
                 {
                     if (go_flag != nullptr)
-                        *go_flag = (md.bit > static_cast<T>(lazy::Mod<T>::MAX_BIT) || md.value < 3) ? 0u : 1u;
+                        *go_flag = state;
                     if (norm_arr != nullptr)
                         norm_arr[0] = lazy::make_norm_const(md.value, md.bit);
                 }

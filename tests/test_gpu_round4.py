@@ -153,3 +153,163 @@ def test_inverse_fourstep_plan_keeps_its_tile_when_the_option_changes(g):
         plan_small.close()
     finally:
         g.set_option("u64_big_tiles", "14")
+
+
+def _distinct_factors(widths, logn):
+    out, seen = [], set()
+    for w in widths:
+        skip = 0
+        while True:
+            f = find_ntt_factors(w, logn, skip)
+            if f[0] not in seen:
+                break
+            skip += 1
+        seen.add(f[0])
+        out.append(f)
+    return out
+
+
+@pytest.mark.parametrize("logn,batch,widths", [(12, 11, (60, 61)), (13, 10, (62, 60, 61)), (14, 260, (60, 60, 61, 60)),
+                                               (14, 7, (60, 60)), (16, 9, (61, 60, 60)), (16, 8, (62, 62)), (21, 3, (60, 61)),
+                                               (22, 2, (62, 60))])
+def test_rns_stacks_with_61_and_62_bit_primes_on_the_lazy_kernels(g, logn, batch, widths):
+    """a drop-in RNS call whose moduli live in device memory classifies them in its preparation kernel;
+    the go-flag now has three states, so a stack that contains a 61- / 62-bit prime (inside the reference's domain,
+    modular_arith.cuh:66-67; RNS indexing ntt.cu:613) runs the 4 q lazy family instead of the Barrett kernels.  path =
+    fast-strict enqueues NO generic kernels behind an RNS call, so a result can only come from a lazy family.  Every
+    polynomial, forward + inverse, rings whose default family uses a bigger tile included (2^13, 2^14 x 260, 2^21, 2^22:
+    the table is permuted on the device for the family that runs)."""
+    import torch
+    poly = O.X_N_plus if logn % 2 else O.X_N_minus
+    cases = [MergeCase(g, 64, logn, poly, f) for f in _distinct_factors(widths, logn)]
+    mc, n = len(cases), 1 << logn
+    fwd = np.zeros(mc * n, dtype=np.uint64)
+    inv = np.zeros_like(fwd)
+    for i, c in enumerate(cases):
+        sz = c.prm.root_of_unity_size
+        fwd[i * n:i * n + sz] = c.prm.forward_table_device_order
+        inv[i * n:i * n + sz] = c.prm.inverse_table_device_order
+    d_fwd, d_inv = g.to_device(fwd), g.to_device(inv)
+    mods = g.modulus_array_to_device([c.prm.modulus for c in cases], 64)
+    ninv = g.to_device(np.array([c.prm.n_inv for c in cases], dtype=np.uint64))
+    x = np.concatenate([cases[p % mc].P.splitmix(91000 + p, 0, n, cases[p % mc].q) for p in range(batch)])
+    want = np.concatenate([cases[p % mc].P.merge_ntt(x[p * n:(p + 1) * n], cases[p % mc].oprm) for p in range(batch)])
+    cf = g.ntt_rns_configuration(n_power=logn, reduction_poly=poly)
+    ci = g.ntt_rns_configuration(n_power=logn, ntt_type=g.INVERSE, reduction_poly=poly, mod_inverse=ninv)
+    g.set_option("path", "fast-strict")
+    try:
+        for rep in range(2):
+            d = g.to_device(x)
+            o = torch.zeros_like(d)
+            g.GPU_NTT(d, o, d_fwd, mods, cf, batch, mc)
+            torch.cuda.synchronize()
+            assert np.array_equal(g.to_host(o), want), ("forward", rep)
+            g.GPU_INTT_Inplace(o, d_inv, mods, ci, batch, mc)
+            torch.cuda.synchronize()
+            assert np.array_equal(g.to_host(o), x), ("inverse", rep)
+    finally:
+        g.set_option("path", os.environ.get("GPUNTT_PATH", "default"))
+
+
+@pytest.mark.parametrize("qbits", [60, 61, 62])
+def test_fourstep_rns_overload_with_a_wide_device_side_modulus_on_the_lazy_kernels(g, qbits):
+    """the RNS overload of GPU_4STEP_NTT with ONE device-side modulus (how the reference's example calls it,
+    example/ntt_4step/test_4step_ntt.cu:126-146) of 61 / 62 bits: the 4 q family behind the three-state go-flag, no
+    generic kernels (path = fast-strict).  Rings whose default family runs one launch on a bigger tile (2^13, 2^14 x 256)
+    and the 8192-tile inverse (2^21) included.  Device-generated tables; expected values from the Merge oracle through
+    GPU_4STEP_NTT(transpose(x)) == MergeNTT(x) and transpose(GPU_4STEP_NTT(y, INVERSE)) == x."""
+    import torch
+    P = O.Port(64)
+    g.set_option("path", "fast-strict")
+    try:
+        for logn, batch in ((12, 3), (13, 5), (14, 256), (16, 3), (18, 2), (21, 2)):
+            q, omega, psi = find_ntt_factors(qbits, logn)
+            m = g.Modulus(q, bits=64)
+            assert m.bit == qbits
+            shape = g.NTTParameters4Step(logn, 64)
+            n, n1, n2 = shape.n, shape.n1, shape.n2
+            oprm = P.merge_params(logn, O.X_N_minus, (q, omega, psi))
+            x = P.splitmix(4700 + logn + qbits, 0, batch * n, q)
+            y = P.merge_ntt(x, oprm)
+            mods = g.modulus_array_to_device([m], 64)
+            ninv = g.to_device(np.array([pow(n, -1, q)], dtype=np.uint64))
+            for inverse in (False, True):
+                r = pow(omega, -1, q) if inverse else omega
+                kind = g.INVERSE if inverse else g.FORWARD
+                w = torch.zeros(n, dtype=torch.int64, device="cuda")
+                t1 = torch.zeros(n1 >> 1, dtype=torch.int64, device="cuda")
+                t2 = torch.zeros(n2 >> 1, dtype=torch.int64, device="cuda")
+                g.GPU_Generate4StepW(w, r, m, logn, kind)
+                g.GPU_GeneratePowerTable(t1, pow(r, n // n1, q), m, int(np.log2(n1)) - 1, True)
+                g.GPU_GeneratePowerTable(t2, pow(r, n // n2, q), m, int(np.log2(n2)) - 1, True)
+                cfg = g.ntt4step_rns_configuration(n_power=logn, ntt_type=kind, mod_inverse=ninv)
+                src = x.reshape(batch, n1, n2).transpose(0, 2, 1).reshape(-1).copy() if not inverse else y
+                d_in = g.to_device(src)
+                d_out = torch.zeros_like(d_in)
+                g.GPU_4STEP_NTT(d_in, d_out, t1, t2, w, mods, cfg, batch, 1)
+                torch.cuda.synchronize()
+                got = g.to_host(d_out)
+                if not inverse:
+                    assert np.array_equal(got, y), ("forward", qbits, logn)
+                else:
+                    assert np.array_equal(got.reshape(batch, n1, n2).transpose(0, 2, 1).reshape(-1), x), ("inverse", qbits, logn)
+    finally:
+        g.set_option("path", os.environ.get("GPUNTT_PATH", "default"))
+
+
+@pytest.mark.parametrize("bits", [32, 64])
+def test_percoefficient_rns_on_the_lazy_kernels_with_per_lane_moduli(g, bits):
+    """PerCoefficient layout with mod_count > 1 (reference ForwardCoreTranspose / InverseCoreTranspose RNS overloads,
+    src/lib/ntt_merge/ntt.cu:1693-1835, 1957-2074): column c is a polynomial of modulus c % mod_count.  The lanes of a
+    wave hold different columns, so the strided lazy kernels run with PER-LANE moduli (kern::merge_pass_lazy_vq; 64-bit
+    words: the 4 q range, 61- / 62-bit primes included).  path = fast-strict: no generic kernels behind the call.  Every
+    column against NTTCPU, both directions, one- and two-pass shapes, mod_count that does not divide the row, in place
+    and out of place, signed input / centred output."""
+    import torch
+    wide = (60, 61, 62) if bits == 64 else (30, 29, 30)
+    g.set_option("path", "fast-strict")
+    try:
+        for logn, w, mc, poly in ((9, 1024, 3, O.X_N_plus), (9, 64, 2, O.X_N_minus), (8, 256, 3, O.X_N_plus),
+                                  (7, 128, 5, O.X_N_minus), (4, 4096, 3, O.X_N_plus), (6, 64, 1, O.X_N_minus),
+                                  (9, 8192, 7, O.X_N_plus)):
+            fl = _distinct_factors([wide[i % 3] for i in range(mc)], logn)
+            cases = [MergeCase(g, bits, logn, poly, f) for f in fl]
+            n = 1 << logn
+            fwd = np.zeros(mc * n, dtype=cases[0].P.T)
+            inv = np.zeros_like(fwd)
+            for i, c in enumerate(cases):
+                sz = c.prm.root_of_unity_size
+                fwd[i * n:i * n + sz] = c.prm.forward_table_device_order
+                inv[i * n:i * n + sz] = c.prm.inverse_table_device_order
+            d_fwd, d_inv = g.to_device(fwd), g.to_device(inv)
+            mods = g.modulus_array_to_device([c.prm.modulus for c in cases], bits)
+            ninv = g.to_device(np.array([c.prm.n_inv for c in cases], dtype=cases[0].P.T))
+            cols = np.stack([cases[p % mc].P.splitmix(95000 + p, 0, n, cases[p % mc].q) for p in range(w)])  # w x n
+            mat = np.ascontiguousarray(cols.T)
+            want_f = np.stack([cases[p % mc].P.merge_ntt(cols[p], cases[p % mc].oprm) for p in range(w)]).T
+            cfg = g.ntt_rns_configuration(n_power=logn, ntt_layout=g.PerCoefficient, reduction_poly=poly)
+            icfg = g.ntt_rns_configuration(n_power=logn, ntt_type=g.INVERSE, ntt_layout=g.PerCoefficient,
+                                           reduction_poly=poly, mod_inverse=ninv)
+            for rep in range(2):
+                d = g.to_device(mat.reshape(-1))
+                o = torch.zeros_like(d)
+                g.GPU_NTT(d, o, d_fwd, mods, cfg, w, mc)
+                torch.cuda.synchronize()
+                assert np.array_equal(g.to_host(o).reshape(n, w), want_f), ("fwd", bits, logn, w, mc, rep)
+                g.GPU_INTT_Inplace(o, d_inv, mods, icfg, w, mc)
+                torch.cuda.synchronize()
+                assert np.array_equal(g.to_host(o).reshape(n, w), mat), ("inv", bits, logn, w, mc, rep)
+            # inverse of raw data against the oracle, centred signed output
+            want_i = np.stack([cases[p % mc].P.merge_ntt(cols[p], cases[p % mc].oprm, inverse=True) for p in range(w)]).T
+            d = g.to_device(mat.reshape(-1))
+            o = torch.zeros_like(d)
+            g.GPU_INTT(d, o, d_inv, mods, icfg, w, mc, dtype="s%d" % bits)
+            torch.cuda.synchronize()
+            got = g.to_host(o, signed=True).reshape(n, w).astype(object)
+            for p in (0, 1, w // 2, w - 1):
+                q = cases[p % mc].q
+                col = np.array([int(v) for v in want_i[:, p]], dtype=object)
+                centred = np.array([v - q if v > q // 2 else v for v in col], dtype=object)
+                assert all(int(a) == int(b) for a, b in zip(got[:, p], centred)), ("centred", bits, logn, p)
+    finally:
+        g.set_option("path", os.environ.get("GPUNTT_PATH", "default"))

@@ -213,3 +213,20 @@ def test_fourstep_output_order_matches_merge():
         for b in (0, 3, n1 - 1):
             k = P.lib.ora_bitreverse(a, l2) * n1 + P.lib.ora_bitreverse(b, l1)
             assert y4[a * n1 + b] == X[k]
+
+
+def test_c3_polynomial_fixture_is_anchored(golden_dir):
+    """tests/golden/c3_polys.json (8 polynomials of BASELINE config 3, reference-build digests; consumed by the -m gpu
+    test test_full_size_c3_reference_layout, which also re-derives every spectrum with the C port): polynomial 0 IS the
+    2^24 record of digests.json, the seeds follow the stated stride, inputs are regenerated from the portable stream."""
+    c3 = json.load(open(os.path.join(golden_dir, "c3_polys.json")))
+    rec = [r for r in json.load(open(os.path.join(golden_dir, "digests.json")))["fourstep"]
+           if r["bits"] == 64 and r["logn"] == 24][0]
+    assert (c3["q"], c3["n1"], c3["n2"], c3["seed0"]) == (rec["q"], rec["n1"], rec["n2"], rec["seed"])
+    p0 = c3["polys"][0]
+    assert (p0["sha_in"], p0["sha_fwd"], p0["sha_inv"]) == (rec["sha_in"], rec["sha_fwd"], rec["sha_inv"])
+    assert [p["seed"] for p in c3["polys"]] == [c3["seed0"] + c3["stride"] * i for i in range(8)]
+    assert len({p["sha_fwd"] for p in c3["polys"]}) == 8
+    P = O.Port(64)
+    x = P.splitmix(c3["polys"][3]["seed"], 0, 1 << 24, c3["q"])
+    assert sha(x) == c3["polys"][3]["sha_in"]
