@@ -448,6 +448,51 @@ def fourstep_buffers_check(case):
             "polynomials_checked_on_device": int(d_mid.numel() // n)}
 
 
+def c4_shard_overheads(g, cfg, dev, shard_batch=1024):
+    """C4 is the strongly scaled config: on 8 GPUs each rank holds 8192 / 8 = 1024 polynomials of 2^14 x u32 -- about
+    40 us of kernel time, the size of the per-call host overhead.  What one such shard costs through the three call
+    forms, on ONE GPU (us per call, HIP events over back-to-back calls): the drop-in call (one preparation launch + the
+    transform), NTTPlan (the transform only) and NTTPlan replayed from a hipGraph (no per-call host launch path).  The
+    8-GPU strong-scaling efficiency of C4 is bounded by these, not by the transform."""
+    import torch
+    bits, logn = cfg["bits"], cfg["logn"]
+    n = 1 << logn
+    poly = g.X_N_minus if cfg["poly"] == "minus" else g.X_N_plus
+    prm = g.NTTParameters(logn, poly, bits)
+    x = splitmix64_mod(0xC4C4, shard_batch * n, prm.modulus.value).astype(g.np_dtype(bits))
+    d = g.to_device(x, dev)
+    table = g.to_device(prm.forward_table_device_order, dev)
+    c = g.ntt_configuration(n_power=logn, ntt_type=g.FORWARD, reduction_poly=poly)
+    plan = g.NTTPlan(table, prm.modulus, logn, poly, g.FORWARD, batch_hint=shard_batch)
+
+    def timed(fn, iters=400):
+        for _ in range(50):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return {"device_us": e0.elapsed_time(e1) * 1e3 / iters, "host_wall_us": (time.perf_counter() - t0) * 1e6 / iters}
+
+    out = {"batch": shard_batch, "log2N": logn, "dtype": "u%d" % bits,
+           "dropin": timed(lambda: g.GPU_NTT_Inplace(d, table, prm.modulus, c, shard_batch)),
+           "plan": timed(lambda: plan.execute(d, d, shard_batch))}
+    try:
+        side = torch.cuda.Stream()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            plan.execute(d, d, shard_batch, stream=torch.cuda.current_stream())
+        out["plan_hipgraph"] = timed(graph.replay)
+    except Exception as e:  # informational
+        out["plan_hipgraph"] = {"error": repr(e)}
+    plan.close()
+    return out
+
+
 # ------------------------------------------------------------------------------ self-launch
 def spawn_ranks(n):
     """`python bench.py --gpus N` without torchrun: re-execute this command line under torch.distributed.run with N
@@ -883,6 +928,11 @@ def main():
                 line["power"] = power
             if e2e is not None:
                 line["end_to_end"] = e2e
+            if args.config == "c4":
+                try:
+                    line["shard_of_8_gpus_call_overheads"] = c4_shard_overheads(g, cfg, dev)
+                except Exception as e:  # informational only
+                    line["shard_of_8_gpus_call_overheads"] = {"error": repr(e)}
             if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only
                 if cfg["kind"] != "4step":
                     case["x_sample"] = case["x"][:cpu_polys * n]

@@ -27,7 +27,8 @@ from typing import Optional
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgpuntt.so")
+# GPUNTT_LIB: an alternative build of the library (A/B experiments under tools/: same sources, one macro changed)
+LIB_PATH = os.environ.get("GPUNTT_LIB") or os.path.join(_HERE, "lib", "libgpuntt.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 # enum values (reference src/include/gpuntt/common/nttparameters.cuh:19-36)

@@ -112,3 +112,78 @@ def test_bench_starts_its_own_ranks_without_torchrun():
     assert d["dry_run"] is True and d["value"] is None and d["n_gpus"] == 2 and d["steps"] == 3
     # weak scaling: every rank its own 512 polynomials, shard bounds multiples of the 8 primes
     assert d["config"]["shards"] == [[0, 512], [512, 1024]]
+
+
+def test_first_multigpu_lease_script_parses_and_names_existing_programs():
+    """tools/first_multigpu_lease.sh --list: the command list of the first multi-GPU lease -- RCCL smoke,
+    headline at 2 / 4 / 8 ranks, the strongly scaled c4, the sweep, the digest check, the 1-GPU reference points; every
+    step has a timeout, a unique rendezvous port, a rank count that matches its name and a program that exists"""
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "first_multigpu_lease.sh"), "--list"], capture_output=True,
+                       text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    steps = [l.split("|", 2) for l in r.stdout.splitlines() if l.strip()]
+    assert len(steps) == 17
+    names = [s[1] for s in steps]
+    order = [n.rsplit("_x", 1)[0] for n in names]
+    assert order[:3] == ["rccl_smoke"] * 3, "the RCCL smoke test must come first"
+    for kind in ("rccl_smoke", "bench_c2", "bench_c4_strong", "sweep", "digests"):
+        assert [n for n in names if n.startswith(kind + "_x")][:3] == [kind + "_x%d" % k for k in (2, 4, 8)]
+    assert "bench_c2_x1" in names and "bench_c4_strong_x1" in names
+    ports = set()
+    for tmo, name, cmd in steps:
+        assert int(tmo) >= 60
+        n = int(name.rsplit("_x", 1)[1])
+        words = cmd.split()
+        prog = [w for w in words if w.endswith(".py")][0]
+        assert os.path.exists(os.path.join(ROOT, prog)), prog
+        if n > 1:
+            assert words[words.index("--nproc-per-node") + 1] == str(n)
+            assert words[words.index("--master-addr") + 1] == "127.0.0.1"
+            port = words[words.index("--master-port") + 1]
+            assert port.isdigit() and port not in ports
+            ports.add(port)
+            if prog == "bench.py":
+                assert words[words.index("--gpus") + 1] == str(n)
+
+
+def test_rccl_smoke_steps_over_gloo_two_ranks():
+    """tools/rccl_smoke.py -- the first thing the multi-GPU lease runs -- with --backend gloo on CPU tensors: the same
+    init / all_reduce / broadcast / scatter / gather / digest steps through gpu-ntt_amd/dist.py's helpers, payloads checked"""
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "tools", "rccl_smoke.py"), "--backend",
+                        "gloo", "--words", "4096"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("RCCL_SMOKE ")][0]
+    d = json.loads(line[len("RCCL_SMOKE "):])
+    assert d["ok"] is True and d["world"] == 2 and d["backend"] == "gloo"
+    assert all(d[k] > 0 for k in ("broadcast_s", "scatter_s", "gather_s"))
+
+
+def test_nccl_process_group_is_created_with_the_rank_device(monkeypatch):
+    """dist.init_process_group("nccl", "cuda:<LOCAL_RANK>") must reach torch.distributed.init_process_group with backend
+    "nccl" (= RCCL on ROCm) AND device_id set -- eager communicator creation bound to the rank's GPU, which is what a
+    one-process-per-GPU RCCL job needs.  No GPU here: torch.distributed is mocked at that call."""
+    import importlib
+    import torch
+    import torch.distributed as td
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import load_pkg
+    load_pkg()
+    dm = importlib.import_module("gpu_ntt_amd.dist")
+    seen = {}
+
+    def fake_init(backend, rank=None, world_size=None, **kw):
+        seen.update(backend=backend, rank=rank, world_size=world_size, **kw)
+
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    monkeypatch.setenv("RANK", "5")
+    monkeypatch.delenv("MASTER_ADDR", raising=False)
+    monkeypatch.setattr(td, "is_initialized", lambda: False)
+    monkeypatch.setattr(td, "init_process_group", fake_init)
+    dist, rank, world = dm.init_process_group("nccl", "cuda:5")
+    assert (rank, world) == (5, 8) and dist is td
+    assert seen["backend"] == "nccl" and seen["rank"] == 5 and seen["world_size"] == 8
+    assert seen["device_id"] == torch.device("cuda:5")
+    assert os.environ["MASTER_ADDR"] == "127.0.0.1"
