@@ -187,8 +187,8 @@ namespace gpuntt
             using TW = lazy::Tw<T>;
             if (plan.mode != PLAN_NONE && mods_dev != nullptr)
                 return false;
-            // dev_family = 4 (64-bit words, device-side modulus): the SECOND enqueue of the call -- the 4 q kernels that own
-            // it when the go-flag says GO_LAZY_4Q (61- / 62-bit modulus).  The table was prepared by the first enqueue
+            // dev_family = 8 / 4 (64-bit words, device-side modulus): a FURTHER enqueue of the call -- the 8 q / 4 q kernels that
+            // own it when the go-flag says GO_LAZY_8Q / GO_LAZY_4Q (61- / 62-bit modulus).  The table was prepared by the first enqueue
             // (prep_merge_from_fourstep permutes it for the family that will run); only the kernels are launched here.
             const bool do_prep = plan.mode != PLAN_EXECUTE && dev_family == 0;
             // host-side modulus: 61- / 62-bit moduli run the same plans on the LIMIT = 8 / 4 kernels (the whole
@@ -676,18 +676,19 @@ namespace gpuntt
                 else
                     fourstep_run_lazy<T, true>(in, out, n1_table, n2_table, w_table, Modulus<T>(), T(0), n_power, l1,
                                                l2, batch_size, stream, mods, ninv_arr, &skip_flag);
-                // 64-bit words: the 4 q family behind the same flag (a 61- / 62-bit modulus), no second preparation
+                // 64-bit words: the 8 q / 4 q families behind the same flag (a 61- / 62-bit modulus), no second preparation
                 if constexpr (sizeof(T) == 8)
                 {
                     if (skip_flag != nullptr)
-                    {
-                        if (ntt_type == FORWARD)
-                            fourstep_run_lazy<T, false>(in, out, n1_table, n2_table, w_table, Modulus<T>(), T(0), n_power, l1,
-                                                        l2, batch_size, stream, mods, ninv_arr, nullptr, PlanUse<T>(), 4);
-                        else
-                            fourstep_run_lazy<T, true>(in, out, n1_table, n2_table, w_table, Modulus<T>(), T(0), n_power, l1,
-                                                       l2, batch_size, stream, mods, ninv_arr, nullptr, PlanUse<T>(), 4);
-                    }
+                        for (int fam : {8, 4})
+                        {
+                            if (ntt_type == FORWARD)
+                                fourstep_run_lazy<T, false>(in, out, n1_table, n2_table, w_table, Modulus<T>(), T(0), n_power,
+                                                            l1, l2, batch_size, stream, mods, ninv_arr, nullptr, PlanUse<T>(), fam);
+                            else
+                                fourstep_run_lazy<T, true>(in, out, n1_table, n2_table, w_table, Modulus<T>(), T(0), n_power,
+                                                           l1, l2, batch_size, stream, mods, ninv_arr, nullptr, PlanUse<T>(), fam);
+                        }
                 }
             }
             if (mods != nullptr && mod_count == 1 && skip_flag != nullptr && host::forced_path() == 3)

@@ -302,12 +302,12 @@ namespace gpuntt
             return tl;
         }
 
-        // grid of a lazy kernel of the 4 q family (64-bit words) launched behind a go-flag, i.e. in its shadow role behind a
+        // grid of a lazy kernel of the 8 q / 4 q family (64-bit words) launched behind a go-flag, i.e. in its shadow role behind a
         // drop-in RNS call: capped, the blocks walk the tiles (kern::for_each_block) -- 8 blocks per CU keep the part full
         // when the family owns the call, and a skipped launch costs < 1 us instead of 0.4 ns per tile
         template <typename T, int LIMSEL> inline unsigned lazy_grid_cap(unsigned long long tiles, const unsigned* go_flag)
         {
-            if (sizeof(T) == 8 && LIMSEL == 4 && go_flag != nullptr && tiles > 2048)
+            if (sizeof(T) == 8 && (LIMSEL == 4 || LIMSEL == 8) && go_flag != nullptr && tiles > 2048)
                 return 2048u;
             return static_cast<unsigned>(tiles);
         }

@@ -354,13 +354,57 @@ namespace gpuntt
             }
         }
 
+        // ---- pass modes: which gather (round 0) and which store (last round) a pass_body instantiation uses ----------------
+        //   tag                  gather (first round)                                  store (last round)                       kernel
+        //   Fst::none, Xp::none  the tile as the plan maps it (direct / coalescing     the same on the way out                  merge_pass_lazy
+        //                        pass / wave-local 64-contiguous window)
+        //   Xp::small_fwd        n2 x 32 tile read as it lies, dropped into LDS        plain                                    fourstep_small_lazy (forward)
+        //                        transposed = natural order
+        //   Xp::small_inv        plain                                                 natural-order result through LDS at its    fourstep_small_lazy (inverse)
+        //                                                                              transposed position, stored as it lies
+        //   Xp::small_nat_fwd    plain (natural-order input)                           wave-local turn, then LDS at o + (o >> 5),  fourstep_small_lazy<NAT> (forward)
+        //                                                                              spectrum stored transposed
+        //   Xp::small_nat_inv    tile read as it lies, staged in LDS, picked up at     plain                                    fourstep_small_lazy<NAT> (inverse)
+        //                        the spectrum positions of the 64-contiguous window
+        //   Xp::first_gather     STRIDED first pass of a forward 4-step: 2^(K - l1)    plain (lazy hand-over)                   fourstep_first_lazy
+        //                        coalesced runs of the transposed input through LDS
+        //   Fst::nat_rows        (inverse) 2^RB-row runs of the column-major side      (forward) rows of 2^K through LDS, stored  fourstep_nat_last_lazy /
+        //                        transposed through LDS                                transposed                               fourstep_nat_first_inv_lazy
+        //   Fst::inv_first       plain (the spectrum as it lies)                       rows of 2^ROWLEN = n1 through LDS, stored  fourstep_inv_first_lazy
+        //                                                                              transposed (lazy hand-over)
+        // Every mode that changes the LDS layout between two uses of the buffer goes through relayout_barrier() below.
+        enum class Fst : int
+        {
+            none = 0,
+            nat_rows = 2,
+            inv_first = 3
+        };
+        enum class Xp : int
+        {
+            none = 0,
+            small_fwd = 1,
+            small_inv = 2,
+            small_nat_fwd = 3,
+            small_nat_inv = 4,
+            first_gather = 5
+        };
+
+        // "The LDS layout changes here": everything a thread has read from the buffer in the old layout must have ARRIVED
+        // (pin_loaded: the compiler may otherwise sink the reads below the barrier) before any wave writes the new layout.
+        // The ONE way to separate two layouts of the same LDS buffer -- a bare __syncthreads() at such a point is the
+        // round-3 race.
+        template <typename T, int N> __device__ __forceinline__ void relayout_barrier(T (&loaded)[N])
+        {
+            relayout_barrier(loaded);
+        }
+
         // VQ: per-lane moduli -- the PerCoefficient layout with an RNS stack (reference ForwardCoreTranspose /
         // InverseCoreTranspose, src/lib/ntt_merge/ntt.cu:1554-2074: column c uses modulus c % mod_count with its own table
         // slot and n^-1).  Strided passes only; the 16 coefficients of a thread lie in ONE column in every round (register
         // windows of strided passes never dip below the contiguous-run bits), so a thread keeps one modulus for the pass
         // and only the operand classes change: q, -q, twiddles and n^-1 in vector registers (lazy::Mod<T, LIM, true>).
         template <typename T, int TLOG, bool EXACT, bool INV, bool CONTIG, int K, int IN_BOUND, bool LAST,
-                  int FST = 0, int LIM = 0, int XP = 0, int SKIP = 0, bool VQ = false>
+                  Fst FST = Fst::none, int LIM = 0, Xp XP = Xp::none, int SKIP = 0, bool VQ = false, int ROWLEN = 0>
         __device__ __forceinline__ void pass_body(const LazyArgsT<T>& a, T* lds, T q_value, T q_bit, T q_mu,
                                                   int mi, unsigned long long fst_poly = 0,
                                                   unsigned fst_tile = 0, long long blk_override = -1,
@@ -370,13 +414,14 @@ namespace gpuntt
             using M = lazy::Mod<T, LIM, VQ>;
             using SCH = PassSched<TLOG, INV, CONTIG, K, IN_BOUND, M::LIMIT, M::TB, SKIP>;
             using TW = lazy::Tw<T>;
-            static_assert(!VQ || (!CONTIG && !FST && !XP && !EXACT && SKIP == 0), "per-lane moduli: plain strided passes");
+            static_assert(!VQ || (!CONTIG && FST == Fst::none && XP == Xp::none && !EXACT && SKIP == 0), "per-lane moduli: plain strided passes");
+            constexpr bool HAS_FST = (FST != Fst::none);
             constexpr int TL = TLOG;
             constexpr int NT = LTile<TLOG>::NT;
             constexpr int NR_ = SCH::NR;
 
             // single-pass transforms of rings smaller than a tile: the tile holds several polynomials
-            constexpr bool MULTI_POLY = CONTIG && (K < TL) && (IN_BOUND == 1) && (LAST || FST);
+            constexpr bool MULTI_POLY = CONTIG && (K < TL) && (IN_BOUND == 1) && (LAST || HAS_FST);
             // Wave-local exchanges.  elem_of<WL> sends thread bit b >= WL to tile bit b + 4, so in every register
             // window with WL <= 6 the wave index (thread bits >= 6) IS the index of the 1024-coefficient
             // sub-block (tile bits >= 10) the wave's 16 x 64 coefficients lie in.  An exchange between two such
@@ -385,22 +430,22 @@ namespace gpuntt
             // <= 10 stages, the last exchange of every longer one (u64 K = 11, 12; u32 big tiles).  Full-tile
             // contiguous passes also enter / leave through the 64-contiguous window (512-byte runs per wave
             // instruction, WIO) with a wave-local transposition instead of the block-wide coalescing pass.
-            constexpr bool WIO_OK = CONTIG && (!FST || FST == 3) && !MULTI_POLY && !EXACT && (TL >= 10);
+            constexpr bool WIO_OK = CONTIG && (!HAS_FST || FST == Fst::inv_first) && !MULTI_POLY && !EXACT && (TL >= 10);
             constexpr int WIO = 6;
             const int t = threadIdx.x;
-            constexpr bool SEG = (FST == 2);
+            constexpr bool SEG = (FST == Fst::nat_rows);
             using Map = LTileMap<TLOG, CONTIG, K, SEG>;
             Map map = SEG   ? Map((fst_poly << a.poly_shift) +
                                       ((static_cast<unsigned long long>(fst_tile) << (TL - K)) << a.row_log) +
                                       (static_cast<unsigned long long>(fst_seg) << K),
                                   a.row_log)
-                      : FST ? Map((fst_poly << a.poly_shift) + (static_cast<unsigned long long>(fst_tile) << TL))
+                      : HAS_FST ? Map((fst_poly << a.poly_shift) + (static_cast<unsigned long long>(fst_tile) << TL))
                             : Map(a.n, a.p_lo,
                                   blk_override >= 0 ? static_cast<unsigned long long>(blk_override)
                                                     : static_cast<unsigned long long>(blockIdx.x));
             // whole tile inside the batch (always true for N >= 4096); taken before *_Poly_Ordered moves
             // the tile to its memory slot, which may lie beyond batch * N
-            const bool tile_in_range = (CONTIG && !FST) ? ((map.base + LTile<TLOG>::TILE) <= a.total) : true;
+            const bool tile_in_range = (CONTIG && !HAS_FST) ? ((map.base + LTile<TLOG>::TILE) <= a.total) : true;
             if (a.poly_order != nullptr)
                 map.remap_poly(a.poly_order, a.n); // twiddle indices use flat & (N-1): unaffected
             if constexpr (VQ)
@@ -502,7 +547,7 @@ namespace gpuntt
             const bool full_tile = tile_in_range;
             const bool plain_io = full_tile; // signed input is converted after the unguarded loads
             // (only the first pass of a forward transform can see signed words)
-            const bool signed_in = (!INV && IN_BOUND == 1 && !FST) ? ((a.flags & F_SIGNED_IN) != 0u) : false;
+            const bool signed_in = (!INV && IN_BOUND == 1 && !HAS_FST) ? ((a.flags & F_SIGNED_IN) != 0u) : false;
             auto to_residue = [&](T x) -> T {
                 using S = typename std::make_signed<T>::type;
                 return (static_cast<S>(x) < 0) ? static_cast<T>(x + m.q) : x;
@@ -546,7 +591,7 @@ namespace gpuntt
                         return inside ? val : static_cast<T>(0);
                     };
                     const T* src = static_cast<const T*>(a.in); // may alias a.out (in-place calls)
-                    if constexpr (XP == 1)
+                    if constexpr (XP == Xp::small_fwd)
                     {
                         // coalesced read of the n2 x 32 tile, transposed into natural order through LDS
                         // (groups of XG loads in flight: the 64-VGPR kernels of the 32-bit big tile spill with all 16)
@@ -586,8 +631,7 @@ namespace gpuntt
                             for (int j = 0; j < EPT; j++)
                                 v[j] = lds[xp_lds<K>(static_cast<unsigned>(elem_of<WL>(t, j)))];
                         }
-                        pin_loaded(v);
-                        __syncthreads(); // the exchanges below reuse the buffer in the e + (e >> 4) layout
+                        relayout_barrier(v); // the exchanges below reuse the buffer in the e + (e >> 4) layout
                     }
                     else if constexpr (SEG && INV)
                     {
@@ -613,10 +657,9 @@ namespace gpuntt
 #pragma unroll
                         for (int j = 0; j < EPT; j++)
                             v[j] = lds[lds_pad_t<K>(elem_of<WL>(t, j))];
-                        pin_loaded(v);
-                        __syncthreads(); // the exchanges below reuse the buffer in the e + (e >> 4) layout
+                        relayout_barrier(v); // the exchanges below reuse the buffer in the e + (e >> 4) layout
                     }
-                    else if constexpr (XP == 5)
+                    else if constexpr (XP == Xp::first_gather)
                     {
                         // forward 4-step, first pass in Merge form: an ordinary strided first pass of the ring's Merge
                         // plan -- the tile is 2^K rows x 2^L columns of the natural layout, rows = the top K index
@@ -655,8 +698,7 @@ namespace gpuntt
                             const unsigned e = static_cast<unsigned>(elem_of<WL>(t, j));
                             v[j] = lds[e + (e >> (TL - l1))];
                         }
-                        pin_loaded(v);
-                        __syncthreads(); // the exchanges below reuse the buffer in the e + (e >> 4) layout
+                        relayout_barrier(v); // the exchanges below reuse the buffer in the e + (e >> 4) layout
                     }
                     else if constexpr (DIRECT_IO)
                     {
@@ -687,7 +729,7 @@ namespace gpuntt
                         constexpr int IWL = WIO;
                         const unsigned lane = map.part(elem_of<IWL>(t, 0));
                         T tmp[EPT];
-                        if constexpr (XP == 4)
+                        if constexpr (XP == Xp::small_nat_inv)
                         {
                             // natural-order inverse 4-step: the tile is read as it lies (n2 x 32), staged in LDS and
                             // picked up at the spectrum positions of the 64-contiguous window
@@ -706,8 +748,7 @@ namespace gpuntt
 #pragma unroll
                             for (int j = 0; j < EPT; j++)
                                 tmp[j] = lds[xp_nat_lds(xp_nat_pos<K>(static_cast<unsigned>(elem_of<IWL>(t, j))))];
-                            pin_loaded(tmp);
-                            __syncthreads(); // the wave-local turn below rewrites the buffer in the e + (e >> 4) layout
+                            relayout_barrier(tmp); // the wave-local turn below rewrites the buffer in the e + (e >> 4) layout
                         }
                         else
                         {
@@ -808,7 +849,7 @@ namespace gpuntt
                             // butterfly (block-uniform scalar test, so tables that differ still work);
                             // V is a canonical input there, so V itself is the product
                             bool unit = false;
-                            if constexpr (UNI_TW && r == 0 && s == 0 && IN_BOUND <= M::TB && !FST)
+                            if constexpr (UNI_TW && r == 0 && s == 0 && IN_BOUND <= M::TB && !HAS_FST)
                                 unit = (tw.w == 1);
                             // U' = U + T comes out of the product's own multiply-add chain;
                             // V' = U - T + TB q = 2 U + TB q - U'  (mod 2^W; the true value is below LIMIT q)
@@ -860,7 +901,7 @@ namespace gpuntt
                 // ---- scatter ----------------------------------------------------------
                 if constexpr (r == NR_ - 1)
                 {
-                    constexpr bool PMUL_OK = LAST && !INV && !FST && !EXACT;
+                    constexpr bool PMUL_OK = LAST && !INV && !HAS_FST && !EXACT;
                     const T* mul_in = PMUL_OK ? a.mul_in : nullptr;
                     (void) mul_in;
                     if constexpr (LAST && !INV && !EXACT && sizeof(T) == 8)
@@ -899,11 +940,10 @@ namespace gpuntt
                             }
                         });
                     }
-                    if constexpr (XP == 2)
+                    if constexpr (XP == Xp::small_inv)
                     {
                         // natural-order result -> LDS at its transposed position -> coalesced stores of the 32 x n2 tile
-                        pin_loaded(v);   // (everything read from the e + (e >> 4) layout has arrived)
-                        __syncthreads(); // every wave is done with the e + (e >> 4) layout
+                        relayout_barrier(v);   // (everything read from the e + (e >> 4) layout has arrived) // every wave is done with the e + (e >> 4) layout
 #pragma unroll
                         for (int j = 0; j < EPT; j++)
                             lds[xp_lds<K>(xp_swap_inv<K>(static_cast<unsigned>(elem_of<WL>(t, j))))] = v[j];
@@ -919,17 +959,16 @@ namespace gpuntt
                                 a.out[map.base + o] = x;
                         }
                     }
-                    else if constexpr (FST && !(SEG && INV))
+                    else if constexpr (HAS_FST && !(SEG && INV))
                     {
                         // FST = 3: the tile is 2^(TL - TK) rows of 2^TK = n1 coefficients (TK = XP - 16), all TL stages of the
                         // ring's inverse Merge plan done on it; FST = 2: rows of 2^K, K stages
-                        constexpr int TK = (FST == 3) ? (XP - 16) : K;
-                        static_assert(FST == 2 || FST == 3, "transposing store: natural-order last pass / inverse first pass");
+                        constexpr int TK = (FST == Fst::inv_first) ? ROWLEN : K;
+                        static_assert(FST == Fst::nat_rows || FST == Fst::inv_first, "transposing store: natural-order last pass / inverse first pass");
                         static_assert(CONTIG && TK >= 4 && TK <= 9, "4-step row runs are 16..512 long");
-                        static_assert(FST != 3 || (INV && K == TL && !LAST), "Merge-form inverse first pass");
+                        static_assert(FST != Fst::inv_first || (INV && K == TL && !LAST), "Merge-form inverse first pass");
                         constexpr int RB = TL - TK; // log2 rows per tile
-                        pin_loaded(v);
-                        __syncthreads();           // all gathers from the e + (e >> 4) layout are done
+                        relayout_barrier(v);           // all gathers from the e + (e >> 4) layout are done
 #pragma unroll
                         for (int j = 0; j < EPT; j++)
                             lds[lds_pad_t<TK>(elem_of<WL>(t, j))] = v[j];
@@ -981,12 +1020,11 @@ namespace gpuntt
 #pragma unroll
                         for (int j = 0; j < EPT; j++)
                             v[j] = lo[lds_joff<OWL>(j)];
-                        if constexpr (XP == 3)
+                        if constexpr (XP == Xp::small_nat_fwd)
                         {
                             // natural-order forward 4-step: from the 64-contiguous window (lanes = consecutive a) into LDS
                             // at the transposed position, then out as it lies (n2 x 32, coalesced)
-                            pin_loaded(v);
-                            __syncthreads(); // every wave is done with the e + (e >> 4) layout
+                            relayout_barrier(v); // every wave is done with the e + (e >> 4) layout
 #pragma unroll
                             for (int j = 0; j < EPT; j++)
                                 lds[xp_nat_lds(xp_nat_pos<K>(static_cast<unsigned>(elem_of<OWL>(t, j))))] = v[j];
@@ -1108,23 +1146,24 @@ namespace gpuntt
         }
 
         // Drop-in RNS calls keep their moduli in device memory, so the host cannot pick the kernel family: the preparation
-        // kernel classifies the stack and publishes a three-state go-flag (prep.hip: 0 = generic Barrett kernels, 1 = the
-        // default lazy range of the word size, 2 = 64-bit words with a 61- / 62-bit modulus in the stack: the 4 q range),
-        // every family is enqueued and the ones the flag does not name return at once.
-        constexpr unsigned GO_GENERIC = 0u, GO_LAZY = 1u, GO_LAZY_4Q = 2u;
+        // kernel classifies the stack and publishes a four-state go-flag (prep.hip: 0 = generic Barrett kernels, 1 = the
+        // default lazy range of the word size, 2 / 3 = 64-bit words whose widest modulus has 61 / 62 bits: the 8 q / 4 q
+        // range), every family is enqueued and the ones the flag does not name return at once.
+        constexpr unsigned GO_GENERIC = 0u, GO_LAZY = 1u, GO_LAZY_8Q = 2u, GO_LAZY_4Q = 3u;
         template <typename T, int LIM> __device__ __forceinline__ bool not_my_call(const unsigned* go_flag)
         {
-            return go_flag != nullptr && *go_flag != ((sizeof(T) == 8 && LIM == 4) ? GO_LAZY_4Q : GO_LAZY);
+            constexpr unsigned mine = (sizeof(T) == 8 && LIM == 4) ? GO_LAZY_4Q : ((sizeof(T) == 8 && LIM == 8) ? GO_LAZY_8Q : GO_LAZY);
+            return go_flag != nullptr && *go_flag != mine;
         }
 
-        // The 4 q family of 64-bit words is enqueued behind EVERY drop-in RNS call as a shadow of the default family (it owns
-        // the call only when the stack holds a 61- / 62-bit prime).  A skipped launch costs about 0.4 ns per block (7 us for
-        // the 16384 blocks of a C2-sized pass, > 100 us for a C3-sized one), so that family runs on a CAPPED grid whose blocks
+        // The 8 q and 4 q families of 64-bit words are enqueued behind EVERY drop-in RNS call as shadows of the default family
+        // (one of them owns the call only when the stack holds a 61- / 62-bit prime).  A skipped launch costs about 0.4 ns per block (7 us for
+        // the 16384 blocks of a C2-sized pass, > 100 us for a C3-sized one), so those families run on a CAPPED grid whose blocks
         // walk the tiles (host: lazy_grid_cap) -- like the generic kernels' shadow launches (merge_kernels.hpp).  f(block
         // index, number of blocks of the uncapped grid).
         template <typename T, int LIM> struct WalksTiles
         {
-            static constexpr bool value = (sizeof(T) == 8 && LIM == 4);
+            static constexpr bool value = (sizeof(T) == 8 && (LIM == 4 || LIM == 8));
         };
         template <bool WALK, typename F> __device__ __forceinline__ void for_each_block(unsigned nblocks, F&& f)
         {
@@ -1210,7 +1249,7 @@ namespace gpuntt
                 qb = md.bit;
                 qm = md.mu;
             }
-            pass_body<T, TLOG, false, INV, CONTIG, K, IN_BOUND, LAST, 0, LIM, 0, SKIP>(a, lds, qv, qb, qm, mi, 0, 0, blk);
+            pass_body<T, TLOG, false, INV, CONTIG, K, IN_BOUND, LAST, Fst::none, LIM, Xp::none, SKIP>(a, lds, qv, qb, qm, mi, 0, 0, blk);
                 });
         }
 
@@ -1232,7 +1271,7 @@ namespace gpuntt
             __shared__ T lds[NEEDS_LDS ? LTile<12>::LDS_ELEMS : 1];
             if (a.go_flag != nullptr && *a.go_flag == GO_GENERIC)
                 return;
-            pass_body<T, 12, false, INV, false, K, IN_BOUND, LAST, 0, LIM, 0, 0, true>(a, lds, 0, 0, 0, 0, 0, 0,
+            pass_body<T, 12, false, INV, false, K, IN_BOUND, LAST, Fst::none, LIM, Xp::none, 0, true>(a, lds, 0, 0, 0, 0, 0, 0,
                                                                                        static_cast<long long>(blockIdx.x));
         }
 
@@ -1269,7 +1308,7 @@ namespace gpuntt
             unsigned poly, tile;
             nat_block(a, TLOG, poly, tile);
             const unsigned rb = tile & ((1u << rb_log) - 1u), seg = tile >> rb_log;
-            pass_body<T, TLOG, false, false, true, K, IN_BOUND, true, 2>(a, lds, a.q, a.q_bit, a.q_mu, 0, poly, rb, -1, seg);
+            pass_body<T, TLOG, false, false, true, K, IN_BOUND, true, Fst::nat_rows>(a, lds, a.q, a.q_bit, a.q_mu, 0, poly, rb, -1, seg);
         }
 
         // natural-order 4-step, inverse direction (the forward passes run backwards):
@@ -1284,7 +1323,7 @@ namespace gpuntt
             unsigned poly, tile;
             nat_block(a, TLOG, poly, tile);
             const unsigned rb = tile & ((1u << rb_log) - 1u), seg = tile >> rb_log;
-            pass_body<T, TLOG, false, true, true, K, 1, false, 2>(a, lds, a.q, a.q_bit, a.q_mu, 0, poly, rb, -1, seg);
+            pass_body<T, TLOG, false, true, true, K, 1, false, Fst::nat_rows>(a, lds, a.q, a.q_bit, a.q_mu, 0, poly, rb, -1, seg);
         }
 
         // forward 4-step, first pass in Merge form with the transposed gather (XP = 5): the first strided pass of the ring's
@@ -1306,7 +1345,7 @@ namespace gpuntt
             }
             for_each_block<WalksTiles<T, LIM>::value>(static_cast<unsigned>(a.total >> 12), [&](unsigned bidx, unsigned nblk) {
                 const unsigned bx = (a.flags & F_REVERSE) ? (nblk - 1u - bidx) : bidx;
-                pass_body<T, 12, false, false, false, K, 1, false, 0, LIM, 5>(a, lds, qv, qb, qm, 0, 0, 0,
+                pass_body<T, 12, false, false, false, K, 1, false, Fst::none, LIM, Xp::first_gather>(a, lds, qv, qb, qm, 0, 0, 0,
                                                                               static_cast<long long>(bx));
             });
         }
@@ -1346,7 +1385,7 @@ namespace gpuntt
                     poly = bx >> tiles_log;
                     tile = bx & ((1u << tiles_log) - 1u);
                 }
-                pass_body<T, TLOG, false, true, true, TLOG, 1, false, 3, LIM, 16 + L1>(a, lds, qv, qb, qm, 0, uniform32(poly),
+                pass_body<T, TLOG, false, true, true, TLOG, 1, false, Fst::inv_first, LIM, Xp::none, 0, false, L1>(a, lds, qv, qb, qm, 0, uniform32(poly),
                                                                                       uniform32(tile));
             });
         }
@@ -1372,7 +1411,8 @@ namespace gpuntt
             }
             for_each_block<WalksTiles<T, LIM>::value>(
                 static_cast<unsigned>((a.total + LTile<TLOG>::TILE - 1) >> TLOG), [&](unsigned bidx, unsigned) {
-                    pass_body<T, TLOG, false, INV, true, K, 1, true, 0, LIM, NAT ? (INV ? 4 : 3) : (INV ? 2 : 1)>(
+                    pass_body<T, TLOG, false, INV, true, K, 1, true, Fst::none, LIM,
+                              NAT ? (INV ? Xp::small_nat_inv : Xp::small_nat_fwd) : (INV ? Xp::small_inv : Xp::small_fwd)>(
                         a, lds, qv, qb, qm, 0, 0, 0, static_cast<long long>(bidx));
                 });
         }

@@ -62,7 +62,7 @@ namespace gpuntt
         // Used for calls whose moduli leave the lazy headroom: bit <= 60 (Data64) / bit <= 30 (Data32).
         //   single modulus: the host sees Modulus<T>::bit and picks the path;
         //   RNS: the moduli live in device memory, so the twiddle-prep kernel classifies them and
-        //        publishes a three-state go-flag (generic / default lazy range / 4 q range); every family is
+        //        publishes a four-state go-flag (generic / default lazy range / 8 q / 4 q range); every family is
         //        enqueued, each returning at once when the flag names another one (run_transform_lazy_rns).
         // Tiny single-modulus rings (below 2^5 / 2^11), small RNS jobs, rings above 2^24 and RNS
         // stacks of rings below one tile use the generic kernels only.
@@ -184,10 +184,10 @@ namespace gpuntt
             return a;
         }
 
-        // Drop-in RNS calls (moduli in device memory): every lazy family is enqueued behind the three-state go-flag the
+        // Drop-in RNS calls (moduli in device memory): every lazy family is enqueued behind the four-state go-flag the
         // preparation kernel publishes (kern::not_my_call) -- the default range of the word size and, for 64-bit words,
-        // the 4 q family that serves a stack with a 61- / 62-bit prime (4096-coefficient tiles; prep_twiddles lays the
-        // table out for the family that will run).  The families the flag does not name return at once; the generic
+        // the 8 q / 4 q families that serve a stack whose widest prime has 61 / 62 bits (4096-coefficient tiles, capped
+        // tile-walking grids; prep_twiddles lays the table out for the family that will run).  The families the flag does not name return at once; the generic
         // kernels behind them (capped shadow grid) are left with moduli outside the documented domain.
         template <typename TU, bool INV>
         inline void run_transform_lazy_rns(const kern::LazyArgsT<TU>& la, unsigned in_flags, unsigned out_flags,
@@ -197,7 +197,10 @@ namespace gpuntt
             if constexpr (sizeof(TU) == 8)
             {
                 kern::LazyArgsT<TU> wide = la;
-                wide.lim = 4;
+                wide.lim = 8; // widest modulus 61 bit (measured: a C5-shaped stack with one 61-bit prime 0.30 ms on the
+                              // 4 q kernels against 0.22 ms on the 8 q ones)
+                host::run_transform_lazy<TU, INV>(wide, in_flags, out_flags, stream);
+                wide.lim = 4; // widest modulus 62 bit
                 host::run_transform_lazy<TU, INV>(wide, in_flags, out_flags, stream);
             }
         }

@@ -102,25 +102,28 @@ namespace gpuntt
             const unsigned long long gid = blockIdx.x * 256ull + threadIdx.x;
             // RNS stacks (moduli in device memory): classify the stack -- kern::GO_GENERIC (a modulus outside the fast
             // kernels' domain), GO_LAZY (every modulus leaves the default lazy range of the word size its headroom: bit <= 60 /
-            // 30) or GO_LAZY_4Q (64-bit words, a 61- / 62-bit modulus in the stack: the 4 q kernels, 4096-coefficient tiles
-            // only).  Block 0 publishes the state; every block needs it when the default family would run on a bigger tile,
-            // because the per-tile permutation of the last three stages must match the family that will really run.
+            // 30), GO_LAZY_8Q / GO_LAZY_4Q (64-bit words, widest modulus 61 / 62 bits: the 8 q / 4 q kernels, 4096-coefficient
+            // tiles only).  Block 0 publishes the state; every block needs it when the default family would run on a bigger
+            // tile, because the per-tile permutation of the last three stages must match the family that will really run.
             unsigned state = GO_LAZY;
             if (mods != nullptr && (perm_tile_log > 12 || blockIdx.x == 0))
             {
-                bool bad = false, wide = false;
+                bool bad = false, w61 = false, w62 = false;
                 for (int i = static_cast<int>(threadIdx.x); i < mod_count; i += 256)
                 {
                     const Modulus<T> md = mods[mod_order != nullptr ? mod_order[i] : i];
                     if (md.value < 3 || md.bit > static_cast<T>(sizeof(T) == 8 ? 62 : lazy::Mod<T>::MAX_BIT))
                         bad = true;
-                    else if (md.bit > static_cast<T>(lazy::Mod<T>::MAX_BIT))
-                        wide = true;
+                    else if (sizeof(T) == 8 && md.bit == static_cast<T>(62))
+                        w62 = true;
+                    else if (sizeof(T) == 8 && md.bit == static_cast<T>(61))
+                        w61 = true;
                 }
-                const int any_bad = __syncthreads_or(bad ? 1 : 0), any_wide = __syncthreads_or(wide ? 1 : 0);
-                state = any_bad ? GO_GENERIC : (any_wide ? GO_LAZY_4Q : GO_LAZY);
+                const int any_bad = __syncthreads_or(bad ? 1 : 0), any62 = __syncthreads_or(w62 ? 1 : 0),
+                          any61 = __syncthreads_or(w61 ? 1 : 0);
+                state = any_bad ? GO_GENERIC : (any62 ? GO_LAZY_4Q : (any61 ? GO_LAZY_8Q : GO_LAZY));
             }
-            if (state == GO_LAZY_4Q && perm_tile_log > 12)
+            if (state >= GO_LAZY_8Q && perm_tile_log > 12)
                 perm_tile_log = 12;
             if (gid == 0 && go_flag != nullptr)
             {
@@ -218,12 +221,14 @@ namespace gpuntt
                     s_rinv = recip_norm<T>(q);
                 __syncthreads();
                 rinv = s_rinv;
-                // three-state go-flag, like prep_twiddles; a 61- / 62-bit modulus runs the 4 q family on 4096-coefficient
+                // four-state go-flag, like prep_twiddles; a 61- / 62-bit modulus runs the 8 q / 4 q family on 4096-coefficient
                 // tiles, so the table takes that tile's permutation
                 const unsigned state = (md.value < 3 || md.bit > static_cast<T>(sizeof(T) == 8 ? 62 : lazy::Mod<T>::MAX_BIT))
                                            ? GO_GENERIC
-                                           : (md.bit > static_cast<T>(lazy::Mod<T>::MAX_BIT) ? GO_LAZY_4Q : GO_LAZY);
-                if (state == GO_LAZY_4Q && perm_tile_log > 12)
+                                           : ((sizeof(T) == 8 && md.bit == static_cast<T>(62))
+                                                  ? GO_LAZY_4Q
+                                                  : ((sizeof(T) == 8 && md.bit == static_cast<T>(61)) ? GO_LAZY_8Q : GO_LAZY));
+                if (state >= GO_LAZY_8Q && perm_tile_log > 12)
                     perm_tile_log = 12;
                 if (gid == 0)
                 {

@@ -174,8 +174,8 @@ def _distinct_factors(widths, logn):
                                                (22, 2, (62, 60))])
 def test_rns_stacks_with_61_and_62_bit_primes_on_the_lazy_kernels(g, logn, batch, widths):
     """a drop-in RNS call whose moduli live in device memory classifies them in its preparation kernel;
-    the go-flag now has three states, so a stack that contains a 61- / 62-bit prime (inside the reference's domain,
-    modular_arith.cuh:66-67; RNS indexing ntt.cu:613) runs the 4 q lazy family instead of the Barrett kernels.  path =
+    the go-flag now has four states, so a stack that contains a 61- / 62-bit prime (inside the reference's domain,
+    modular_arith.cuh:66-67; RNS indexing ntt.cu:613) runs the 8 q / 4 q lazy family instead of the Barrett kernels.  path =
     fast-strict enqueues NO generic kernels behind an RNS call, so a result can only come from a lazy family.  Every
     polynomial, forward + inverse, rings whose default family uses a bigger tile included (2^13, 2^14 x 260, 2^21, 2^22:
     the table is permuted on the device for the family that runs)."""
@@ -269,7 +269,7 @@ def test_percoefficient_rns_on_the_lazy_kernels_with_per_lane_moduli(g, bits):
     wide = (60, 61, 62) if bits == 64 else (30, 29, 30)
     g.set_option("path", "fast-strict")
     try:
-        for logn, w, mc, poly in ((9, 1024, 3, O.X_N_plus), (9, 64, 2, O.X_N_minus), (8, 256, 3, O.X_N_plus),
+        for logn, w, mc, poly in ((9, 1024, 3, O.X_N_plus), (9, 256, 2, O.X_N_minus), (8, 256, 3, O.X_N_plus),
                                   (7, 128, 5, O.X_N_minus), (4, 4096, 3, O.X_N_plus), (6, 64, 1, O.X_N_minus),
                                   (9, 8192, 7, O.X_N_plus)):
             fl = _distinct_factors([wide[i % 3] for i in range(mc)], logn)
