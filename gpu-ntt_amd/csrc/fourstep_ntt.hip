@@ -523,8 +523,11 @@ namespace gpuntt
         {
             using TW = lazy::Tw<T>;
             (void) n2_table;
-            if (mod.bit > T(lazy::Mod<T>::MAX_BIT) || mod.value < 3)
+            // 61- / 62-bit moduli (64-bit words): the same sweeps on the 4 q kernels (round 4; Barrett kernels between two
+            // transposes before)
+            if (!host::modulus_fast<T>(mod))
                 return false;
+            const bool wide = host::modulus_lim<T>(mod) != 0;
             if (host::forced_path() == 1)
                 return false;
             if (plan.mode != PLAN_EXECUTE && host::validate_4step_tables())
@@ -539,9 +542,11 @@ namespace gpuntt
             TW* ws_merge = ws + n1; // the W region of the workspace holds the ring's Merge table
             // rings that fill one tile: ONE launch (contiguous Merge pass, the transposition in LDS); the table then
             // carries the per-tile permutation of its last three stages
-            const int small_tl = plan.mode != PLAN_NONE
-                                     ? plan.small_tl
-                                     : host::fourstep_small_tile<T>(n_power, false, static_cast<unsigned long long>(batch_size));
+            int small_tl = plan.mode != PLAN_NONE
+                               ? plan.small_tl
+                               : host::fourstep_small_tile<T>(n_power, false, static_cast<unsigned long long>(batch_size));
+            if (wide && small_tl != 12)
+                small_tl = 0; // the 4 q kernels exist for 4096-coefficient tiles only
             if (plan.mode != PLAN_EXECUTE)
                 host::launch_prep_merge_from_fourstep<T>(n1_table, w_table, ws_merge, log_n1, log_n2, small_tl, false, false,
                                                          mod.value, T(0), nullptr, nullptr, nullptr, nullptr, nullptr, stream);
@@ -554,26 +559,44 @@ namespace gpuntt
             {
                 a.in = in;
                 a.out = out;
+                if constexpr (sizeof(T) == 8)
+                    if (wide)
+                    {
+                        host::launch_fourstep_lim<false, 4>(3, log_n1, a, stream);
+                        return true;
+                    }
                 host::launch_fourstep_small_lazy<T, false>(small_tl, n_power, a, stream, true);
                 return true;
             }
+            auto strided = [&](const host::Pass& p, bool first) {
+                if constexpr (sizeof(T) == 8)
+                    if (wide)
+                        return host::launch_pass_lazy_lim<false, 4>(p, first, false, a, stream);
+                host::launch_pass_lazy<T, false>(p, 12, first, false, a, stream);
+            };
             a.in = in;
             a.out = in;
             // 1. top log2(n1) stages, canonical in, lazy out
             a.p_lo = log_n2;
-            host::launch_pass_lazy<T, false>(host::Pass{false, log_n1, log_n2}, 12, true, false, a, stream);
+            strided(host::Pass{false, log_n1, log_n2}, true);
             // 2. index bits [8, log2 n2)
             const int k_last = (log_n2 > 9) ? 8 : log_n2;
             if (log_n2 > 9)
             {
                 a.p_lo = k_last;
-                host::launch_pass_lazy<T, false>(host::Pass{false, log_n2 - k_last, k_last}, 12, false, false, a, stream);
+                strided(host::Pass{false, log_n2 - k_last, k_last}, false);
             }
             // 3. low stages + transposed store (big rings: poly-minor block order, the batch shares the table in L2)
             a.in = in;
             a.out = out;
             a.p_lo = 0;
             a.batch = (n_power >= 20 && batch_size >= 2) ? batch_size : 0;
+            if constexpr (sizeof(T) == 8)
+                if (wide)
+                {
+                    host::launch_fourstep_nat_last_lazy<T, 4>(k_last, a, stream);
+                    return true;
+                }
             host::launch_fourstep_nat_last_lazy<T>(k_last, a, stream);
             return true;
         }
@@ -586,8 +609,9 @@ namespace gpuntt
         {
             using TW = lazy::Tw<T>;
             (void) n2_table;
-            if (mod.bit > T(lazy::Mod<T>::MAX_BIT) || mod.value < 3 || ninv >= mod.value)
+            if (!host::modulus_fast<T>(mod) || ninv >= mod.value)
                 return false;
+            const bool wide = host::modulus_lim<T>(mod) != 0; // 61- / 62-bit moduli: the 4 q kernels
             if (host::forced_path() == 1)
                 return false;
             if (plan.mode != PLAN_EXECUTE && host::validate_4step_tables())
@@ -600,9 +624,11 @@ namespace gpuntt
             if (ws == nullptr)
                 return false; // no device memory for the scratch: the generic kernels need none
             TW* ws_merge = ws + n1;
-            const int small_tl = plan.mode != PLAN_NONE
-                                     ? plan.small_tl
-                                     : host::fourstep_small_tile<T>(n_power, true, static_cast<unsigned long long>(batch_size), true);
+            int small_tl = plan.mode != PLAN_NONE
+                               ? plan.small_tl
+                               : host::fourstep_small_tile<T>(n_power, true, static_cast<unsigned long long>(batch_size), true);
+            if (wide && small_tl != 12)
+                small_tl = 0;
             // inverse Merge table of the ring, N^-1 folded into the single twiddle of the final stage (slot 1)
             if (plan.mode != PLAN_EXECUTE)
                 host::launch_prep_merge_from_fourstep<T>(n1_table, w_table, ws_merge, log_n1, log_n2, small_tl, true, true,
@@ -617,6 +643,12 @@ namespace gpuntt
                 a.in = in;
                 a.out = out;
                 a.ninv = TW{ninv, host::shoup_host(ninv, mod.value)};
+                if constexpr (sizeof(T) == 8)
+                    if (wide)
+                    {
+                        host::launch_fourstep_lim<true, 4>(3, log_n1, a, stream);
+                        return true;
+                    }
                 host::launch_fourstep_small_lazy<T, true>(small_tl, n_power, a, stream, true);
                 return true;
             }
@@ -625,19 +657,33 @@ namespace gpuntt
             a.out = out;
             const int k_first = (log_n2 > 9) ? 8 : log_n2;
             a.batch = (n_power >= 20 && batch_size >= 2) ? batch_size : 0; // poly-minor: the batch shares the table in L2
-            host::launch_fourstep_nat_first_inv_lazy<T>(k_first, a, stream);
+            bool first_done = false;
+            if constexpr (sizeof(T) == 8)
+                if (wide)
+                {
+                    host::launch_fourstep_nat_first_inv_lazy<T, 4>(k_first, a, stream);
+                    first_done = true;
+                }
+            if (!first_done)
+                host::launch_fourstep_nat_first_inv_lazy<T>(k_first, a, stream);
             a.batch = 0;
+            auto strided = [&](const host::Pass& p, bool last) {
+                if constexpr (sizeof(T) == 8)
+                    if (wide)
+                        return host::launch_pass_lazy_lim<true, 4>(p, false, last, a, stream);
+                host::launch_pass_lazy<T, true>(p, 12, false, last, a, stream);
+            };
             // 2. index bits [8, log2 n2), in place
             a.in = out;
             if (log_n2 > 9)
             {
                 a.p_lo = k_first;
-                host::launch_pass_lazy<T, true>(host::Pass{false, log_n2 - k_first, k_first}, 12, false, false, a, stream);
+                strided(host::Pass{false, log_n2 - k_first, k_first}, false);
             }
             // 3. top log2(n1) stages with N^-1: canonical, natural order
             a.p_lo = log_n2;
             a.ninv = TW{ninv, host::shoup_host(ninv, mod.value)};
-            host::launch_pass_lazy<T, true>(host::Pass{false, log_n1, log_n2}, 12, false, true, a, stream);
+            strided(host::Pass{false, log_n1, log_n2}, true);
             return true;
         }
 

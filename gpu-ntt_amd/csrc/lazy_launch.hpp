@@ -191,14 +191,16 @@ namespace gpuntt
             return (sizeof(T) == 8 && n_power == 21 && lim == 0 && lazy_u64_big_tiles() >= 13) ? 13 : 12;
         }
         // natural-order 4-step (extension) in Merge form: strided Merge passes + one transposing row pass
-        template <typename T>
+        template <typename T, int LIMSEL = 0>
         void launch_fourstep_nat_last_lazy(int k, const kern::LazyArgsT<T>& a, hipStream_t stream);
-        extern template void launch_fourstep_nat_last_lazy<uint64_t>(int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
-        extern template void launch_fourstep_nat_last_lazy<uint32_t>(int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
-        template <typename T>
+        extern template void launch_fourstep_nat_last_lazy<uint64_t, 0>(int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
+        extern template void launch_fourstep_nat_last_lazy<uint32_t, 0>(int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
+        extern template void launch_fourstep_nat_last_lazy<uint64_t, 4>(int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
+        template <typename T, int LIMSEL = 0>
         void launch_fourstep_nat_first_inv_lazy(int k, const kern::LazyArgsT<T>& a, hipStream_t stream);
-        extern template void launch_fourstep_nat_first_inv_lazy<uint64_t>(int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
-        extern template void launch_fourstep_nat_first_inv_lazy<uint32_t>(int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
+        extern template void launch_fourstep_nat_first_inv_lazy<uint64_t, 0>(int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
+        extern template void launch_fourstep_nat_first_inv_lazy<uint32_t, 0>(int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
+        extern template void launch_fourstep_nat_first_inv_lazy<uint64_t, 4>(int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
         // Merge table of the 4-step ring (bit-reversed powers of its root), rebuilt from the caller's 4-step tables
         // straight into the Merge kernels' stage layout (prep.hip: prep_merge_from_fourstep)
         template <typename T>

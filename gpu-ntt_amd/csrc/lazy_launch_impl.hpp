@@ -166,8 +166,9 @@ namespace gpuntt
                             default: break;
                         }
                     // strided passes that END a forward transform / BEGIN an inverse one: the PerCoefficient layout
-                    // (rows = coefficients, every stage is a strided stage; default lazy range, 4096-coefficient tiles)
-                    if constexpr (LIMSEL == 0 && TLOG == 12)
+                    // (rows = coefficients, every stage is a strided stage; default lazy range and, for 61- / 62-bit moduli
+                    // in 64-bit words, the 4 q range; 4096-coefficient tiles)
+                    if constexpr ((LIMSEL == 0 || (LIMSEL == 4 && sizeof(T) == 8)) && TLOG == 12)
                         if (last)
                             switch (p.k * 2 + (in_first ? 1 : 0))
                             {
@@ -188,7 +189,7 @@ namespace gpuntt
                 }
                 else
                 {
-                    if constexpr (LIMSEL == 0 && TLOG == 12)
+                    if constexpr ((LIMSEL == 0 || (LIMSEL == 4 && sizeof(T) == 8)) && TLOG == 12)
                         if (in_first)
                             switch (p.k * 2 + (last ? 1 : 0))
                             {
@@ -376,15 +377,15 @@ namespace gpuntt
         }
 
         // natural-order forward 4-step (fourstep_ntt.hip): the transposing last row pass, k = 7 .. 9 low stages of the
-        // ring, lazy input from the strided passes above it
-        template <typename T>
+        // ring, lazy input from the strided passes above it.  LIMSEL = 4: 64-bit words with a 61- / 62-bit modulus
+        template <typename T, int LIMSEL>
         void launch_fourstep_nat_last_lazy(int k, const kern::LazyArgsT<T>& a, hipStream_t stream)
         {
             constexpr int TLOG = 12;
-            constexpr int LIM = lazy::Mod<T>::LIMIT;
+            constexpr int LIM = lazy::Mod<T, LIMSEL>::LIMIT;
             const unsigned grid = static_cast<unsigned>(a.total >> TLOG);
 #define GPUNTT_ONE(KK)                                                                            \
-    hipLaunchKernelGGL((kern::fourstep_nat_last_lazy<T, TLOG, KK, LIM>), dim3(grid),               \
+    hipLaunchKernelGGL((kern::fourstep_nat_last_lazy<T, TLOG, KK, LIM, LIMSEL>), dim3(grid),       \
                        dim3(kern::LTile<TLOG>::NT), 0, stream, a)
             if (k == 7)
                 GPUNTT_ONE(7);
@@ -399,7 +400,7 @@ namespace gpuntt
         }
 
         // natural-order inverse 4-step: the transposing first row pass (k = 7 .. 9 low stages of the ring)
-        template <typename T>
+        template <typename T, int LIMSEL>
         void launch_fourstep_nat_first_inv_lazy(int k, const kern::LazyArgsT<T>& a, hipStream_t stream)
         {
             constexpr int TLOG = 12;
@@ -408,7 +409,7 @@ namespace gpuntt
             {
 #define GPUNTT_CASE(KK)                                                                          \
     case KK:                                                                                      \
-        hipLaunchKernelGGL((kern::fourstep_nat_first_inv_lazy<T, TLOG, KK>), dim3(grid),          \
+        hipLaunchKernelGGL((kern::fourstep_nat_first_inv_lazy<T, TLOG, KK, LIMSEL>), dim3(grid),  \
                            dim3(kern::LTile<TLOG>::NT), 0, stream, a);                            \
         break;
                 GPUNTT_CASE(7)
@@ -421,23 +422,29 @@ namespace gpuntt
             GPUNTT_HIP_CHECK(hipGetLastError());
         }
         // 4-step kernels for 64-bit words with a 61- / 62-bit modulus (LIMIT = 8 / 4): what = 1 first pass of the forward
-        // Merge plan (log_n1 = its stage count), 2 the one-launch 2^12 ring
+        // Merge plan (log_n1 = its stage count), 2 the one-launch 2^12 ring, 3 the same in natural order (LIMIT = 4 only)
         template <bool INV, int LIMSEL>
         void launch_fourstep_lim(int what, int log_n1, const kern::LazyArgsT<uint64_t>& a, hipStream_t stream)
         {
             if constexpr (!INV)
                 if (what == 1)
                     return launch_fourstep_first_lazy<uint64_t, LIMSEL>(log_n1, a, stream);
-            if (what == 2)
+            if (what == 2 || what == 3)
             {
                 const unsigned long long tiles = a.total >> 12;
                 if (tiles == 0)
                     return;
                 if (tiles > 0x7fffffffull)
                     throw std::invalid_argument("batch_size * N too large for one launch");
-                hipLaunchKernelGGL((kern::fourstep_small_lazy<uint64_t, 12, INV, 12, LIMSEL>),
-                                   dim3(lazy_grid_cap<uint64_t, LIMSEL>(tiles, a.go_flag)),
-                                   dim3(kern::LTile<12>::NT), 0, stream, a);
+                if (what == 2)
+                    hipLaunchKernelGGL((kern::fourstep_small_lazy<uint64_t, 12, INV, 12, LIMSEL>),
+                                       dim3(lazy_grid_cap<uint64_t, LIMSEL>(tiles, a.go_flag)),
+                                       dim3(kern::LTile<12>::NT), 0, stream, a);
+                else if constexpr (LIMSEL == 4) // natural-order extension (4 q family only)
+                    hipLaunchKernelGGL((kern::fourstep_small_lazy<uint64_t, 12, INV, 12, LIMSEL, true>),
+                                       dim3(static_cast<unsigned>(tiles)), dim3(kern::LTile<12>::NT), 0, stream, a);
+                else
+                    throw std::invalid_argument("internal: bad 4-step kernel selector");
                 GPUNTT_HIP_CHECK(hipGetLastError());
                 return;
             }

@@ -3,7 +3,7 @@
 namespace gpuntt { namespace host {
 template void launch_pass_lazy<uint32_t, true>(const Pass&, int, bool, bool, const kern::LazyArgsT<uint32_t>&, hipStream_t);
 template void launch_fourstep_small_lazy<uint32_t, true>(int, int, const kern::LazyArgsT<uint32_t>&, hipStream_t, bool);
-template void launch_fourstep_nat_first_inv_lazy<uint32_t>(int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
+template void launch_fourstep_nat_first_inv_lazy<uint32_t, 0>(int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
 template void launch_fourstep_inv_first_lazy<uint32_t, 0>(int, const kern::LazyArgsT<uint32_t>&, hipStream_t, int);
 template void launch_fourstep_inv_rows_lazy<uint32_t, 0>(int, int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
 } }

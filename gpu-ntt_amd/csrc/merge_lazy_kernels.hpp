@@ -37,7 +37,7 @@ namespace gpuntt
             const T* mul_in;                 // GPU_PolyMul: canonical operand multiplied into the final forward store, or nullptr
             int lim;                         // 64-bit words: 0, or 8 / 4 = a 61- / 62-bit modulus in the call -> the LIMIT = 8 / 4 kernels (host-side switch)
             int n2_log;                      // 4-step transposing passes: log2 of the row stride of the transposed side
-            int row_log;                     // natural-order 4-step row passes (FST = 2): log2 of the row stride of the row-major side (n2); a.n stays the ring (twiddle indices)
+            int row_log;                     // natural-order 4-step row passes (Fst::nat_rows): log2 of the row stride of the row-major side (n2); a.n stays the ring (twiddle indices)
             int batch;                       // > 1: polynomials of the call, blocks are ordered poly-minor (big-ring contiguous passes)
             int col_log;                     // per-lane moduli (VQ, PerCoefficient RNS): log2 of the matrix row = number of columns
             int mod_shift;                   // per-lane moduli (VQ): log2 of the table stride per modulus (the ring size n_power)
@@ -256,10 +256,10 @@ namespace gpuntt
         // FST: the transposing passes of the 4-step entry points (reference FourStepForwardCoreT1..4 /
         // FourStepInverseCoreT1..4 + FourStepPartial*Core, src/lib/ntt_4step/ntt_4step.cu:68-743, 1049-1058, 1177-1872).
         // Every 4-step transform is the ring's own Merge plan with a transposition on the natural-order side (DESIGN.md
-        // 3.5): the forward one gathers the transposed input in its first strided pass (XP = 5 below /
-        // fourstep_first_lazy), the inverse one stores transposed from its first contiguous pass (FST = 3 /
-        // fourstep_inv_first_lazy); no W product, no W stream.  (FST = 1 was the W-multiplying phase 1 of rounds 1-3.)
-        // FST = 2, natural-order 4-step, last forward pass: CONTIG stages on the same 2^K-column range
+        // 3.5): the forward one gathers the transposed input in its first strided pass (Xp::first_gather below /
+        // fourstep_first_lazy), the inverse one stores transposed from its first contiguous pass (Fst::inv_first /
+        // fourstep_inv_first_lazy); no W product, no W stream.  (The W-multiplying phase 1 of rounds 1-3 is gone.)
+        // Fst::nat_rows, natural-order 4-step, last forward pass: CONTIG stages on the same 2^K-column range
         // of 2^(TL-K) consecutive rows (lazy input from the strided row passes, or canonical input
         // when the rows fit one pass), canonical output stored transposed (no W product).
         // streaming forms (global_load / global_store ... nt): the first pass reads input nobody reads again, the
@@ -293,17 +293,17 @@ namespace gpuntt
         // XP: the 4-step entry points on rings that fit ONE tile.  GPU_4STEP_NTT is the Merge transform of the ring with
         // a transposition on the natural-order side (prep.hip: prep_merge_from_fourstep), n1 = 32 for every such ring
         // (reference launch table src/lib/ntt_4step/ntt_4step.cu:2306-2330: 2^12 .. 2^14 are 32 x n2):
-        //   XP = 1 (forward):  the tile is read as it lies (n2 x 32, coalesced) and dropped into LDS transposed, i.e. at
+        //   Xp::small_fwd (forward):  the tile is read as it lies (n2 x 32, coalesced) and dropped into LDS transposed, i.e. at
         //                      its natural position  e = (i << log n2) | c  for  f = (c << 5) | i;
-        //   XP = 2 (inverse):  the natural-order result leaves through LDS transposed: o = (b << log n2) | a for
+        //   Xp::small_inv (inverse):  the natural-order result leaves through LDS transposed: o = (b << log n2) | a for
         //                      e = (a << 5) | b, and is stored as it lies (32 x n2, coalesced).
         // One HBM sweep instead of the reference's two kernels (FourStepForwardCoreT1 + FourStepPartialForwardCore).
         // LDS layout of the transposition: one pad element per n2-row, so the 32 lanes that write one column and the
         // lanes that read along a row both hit distinct banks.
-        //   XP = 3 (natural-order forward): natural-order input, the spectrum leaves transposed -- out[(a << 5) | b] =
+        //   Xp::small_nat_fwd (natural-order forward): natural-order input, the spectrum leaves transposed -- out[(a << 5) | b] =
         //                      y[(b << log n2) | a] (NTT_4STEP_CPU::ntt order): wave-local turn into the 64-contiguous
         //                      window, then through LDS at (o + (o >> 5)) and out as it lies;
-        //   XP = 4 (natural-order inverse): the mirror image on the way in.
+        //   Xp::small_nat_inv (natural-order inverse): the mirror image on the way in.
         constexpr int XP_L1 = 5;
         template <int K> __device__ __forceinline__ unsigned xp_swap_fwd(unsigned f) // f = (c << 5) | i  ->  (i << l2) | c
         {
@@ -316,7 +316,7 @@ namespace gpuntt
             return xp_swap_fwd<K>(e); // the same bit rotation: low five bits to the top of the ring index
         }
         template <int K> __device__ __forceinline__ unsigned xp_lds(unsigned e) { return e + (e >> (K - XP_L1)); }
-        // natural-order side of XP = 3 / 4: spectrum position e = (b << l2) | a  <->  o = (a << 5) | b; one pad element per
+        // natural-order side of Xp::small_nat_fwd / small_nat_inv: spectrum position e = (b << l2) | a  <->  o = (a << 5) | b; one pad element per
         // 32-element row of o, so the 64 lanes that hold consecutive a (stride 32 in o) hit distinct banks
         template <int K> __device__ __forceinline__ unsigned xp_nat_pos(unsigned e)
         {
@@ -395,7 +395,8 @@ namespace gpuntt
         // round-3 race.
         template <typename T, int N> __device__ __forceinline__ void relayout_barrier(T (&loaded)[N])
         {
-            relayout_barrier(loaded);
+            pin_loaded(loaded);
+            __syncthreads();
         }
 
         // VQ: per-lane moduli -- the PerCoefficient layout with an RNS stack (reference ForwardCoreTranspose /
@@ -943,7 +944,7 @@ namespace gpuntt
                     if constexpr (XP == Xp::small_inv)
                     {
                         // natural-order result -> LDS at its transposed position -> coalesced stores of the 32 x n2 tile
-                        relayout_barrier(v);   // (everything read from the e + (e >> 4) layout has arrived) // every wave is done with the e + (e >> 4) layout
+                        relayout_barrier(v); // every wave is done with the e + (e >> 4) layout
 #pragma unroll
                         for (int j = 0; j < EPT; j++)
                             lds[xp_lds<K>(xp_swap_inv<K>(static_cast<unsigned>(elem_of<WL>(t, j))))] = v[j];
@@ -961,14 +962,14 @@ namespace gpuntt
                     }
                     else if constexpr (HAS_FST && !(SEG && INV))
                     {
-                        // FST = 3: the tile is 2^(TL - TK) rows of 2^TK = n1 coefficients (TK = XP - 16), all TL stages of the
-                        // ring's inverse Merge plan done on it; FST = 2: rows of 2^K, K stages
+                        // Fst::inv_first: the tile is 2^(TL - TK) rows of 2^TK = n1 coefficients (TK = ROWLEN), all TL stages of the
+                        // ring's inverse Merge plan done on it; Fst::nat_rows: rows of 2^K, K stages
                         constexpr int TK = (FST == Fst::inv_first) ? ROWLEN : K;
                         static_assert(FST == Fst::nat_rows || FST == Fst::inv_first, "transposing store: natural-order last pass / inverse first pass");
                         static_assert(CONTIG && TK >= 4 && TK <= 9, "4-step row runs are 16..512 long");
                         static_assert(FST != Fst::inv_first || (INV && K == TL && !LAST), "Merge-form inverse first pass");
                         constexpr int RB = TL - TK; // log2 rows per tile
-                        relayout_barrier(v);           // all gathers from the e + (e >> 4) layout are done
+                        relayout_barrier(v); // all gathers from the e + (e >> 4) layout are done
 #pragma unroll
                         for (int j = 0; j < EPT; j++)
                             lds[lds_pad_t<TK>(elem_of<WL>(t, j))] = v[j];
@@ -1001,7 +1002,7 @@ namespace gpuntt
                                 const unsigned lane = (static_cast<unsigned>(t >> RB) << a.n2_log) + (t & ((1 << RB) - 1));
                                 const unsigned long long ubase =
                                     (static_cast<unsigned long long>((NT >> RB) * jr) << a.n2_log) + row0;
-                                // (FST = 2: canonical; FST = 3: lazy hand-over to the row passes)
+                                // (Fst::nat_rows: canonical; Fst::inv_first: lazy hand-over to the row passes)
                                 (a.out + ((fst_poly << a.poly_shift) + seg_base + ubase))[lane] = x[jj];
                             }
                         }
@@ -1299,7 +1300,7 @@ namespace gpuntt
         // a.row_log = log2 n2 (row length and stride of the row-major side), a.n2_log = log2 n1 (row stride of the
         // column-major side), a.n = log2 N: the stages are the low K stages of the Merge transform of the whole ring, so
         // the twiddles come from the ring's Merge table and depend on the row as well (4-step in Merge form)
-        template <typename T, int TLOG, int K, int IN_BOUND>
+        template <typename T, int TLOG, int K, int IN_BOUND, int LIM = 0>
         __global__ __launch_bounds__(LTile<TLOG>::NT, (LOcc<TLOG, T>::WAVES)) void fourstep_nat_last_lazy(LazyArgsT<T> a)
         {
             __shared__ T lds[LTile<TLOG>::LDS_ELEMS_FST];
@@ -1308,13 +1309,13 @@ namespace gpuntt
             unsigned poly, tile;
             nat_block(a, TLOG, poly, tile);
             const unsigned rb = tile & ((1u << rb_log) - 1u), seg = tile >> rb_log;
-            pass_body<T, TLOG, false, false, true, K, IN_BOUND, true, Fst::nat_rows>(a, lds, a.q, a.q_bit, a.q_mu, 0, poly, rb, -1, seg);
+            pass_body<T, TLOG, false, false, true, K, IN_BOUND, true, Fst::nat_rows, LIM>(a, lds, a.q, a.q_bit, a.q_mu, 0, poly, rb, -1, seg);
         }
 
         // natural-order 4-step, inverse direction (the forward passes run backwards):
         //   first pass  transposed load of the column-major input + the 2^K low row stages
         //               (Gentleman-Sande), stored row-major, lazy; block order as fourstep_nat_last_lazy
-        template <typename T, int TLOG, int K>
+        template <typename T, int TLOG, int K, int LIM = 0>
         __global__ __launch_bounds__(LTile<TLOG>::NT, (LOcc<TLOG, T>::WAVES)) void fourstep_nat_first_inv_lazy(LazyArgsT<T> a)
         {
             __shared__ T lds[LTile<TLOG>::LDS_ELEMS_FST];
@@ -1323,10 +1324,10 @@ namespace gpuntt
             unsigned poly, tile;
             nat_block(a, TLOG, poly, tile);
             const unsigned rb = tile & ((1u << rb_log) - 1u), seg = tile >> rb_log;
-            pass_body<T, TLOG, false, true, true, K, 1, false, Fst::nat_rows>(a, lds, a.q, a.q_bit, a.q_mu, 0, poly, rb, -1, seg);
+            pass_body<T, TLOG, false, true, true, K, 1, false, Fst::nat_rows, LIM>(a, lds, a.q, a.q_bit, a.q_mu, 0, poly, rb, -1, seg);
         }
 
-        // forward 4-step, first pass in Merge form with the transposed gather (XP = 5): the first strided pass of the ring's
+        // forward 4-step, first pass in Merge form with the transposed gather (Xp::first_gather): the first strided pass of the ring's
         // Merge plan, K >= log2 n1 stages, reading the n2 x n1 input; everything behind it is the Merge plan itself.
         // a.n = log2 N, a.p_lo = log2 N - K, a.n2_log = log2 n1; grid = batch * N / 4096 blocks in tile order
         template <typename T, int K, int LIM = 0>
@@ -1350,7 +1351,7 @@ namespace gpuntt
             });
         }
 
-        // inverse 4-step, first pass in Merge form (FST = 3).  With e = (a << l1) | b the natural index of the result x =
+        // inverse 4-step, first pass in Merge form (Fst::inv_first).  With e = (a << l1) | b the natural index of the result x =
         // MergeINTT_w(in), GPU_4STEP_NTT stores out[(b << l2) | a] = x[e]: the LOW l1 index bits go to the top.  The first
         // pass of the ring's inverse Merge plan -- 12 contiguous Gentleman-Sande stages on a tile that lies as it stands in
         // the spectrum -- holds all of b and the low 12 - l1 bits of a, so it can store the tile transposed: 2^l1 rows
@@ -1392,8 +1393,8 @@ namespace gpuntt
 
         // 4-step transform of a ring that fits one tile (2^12 .. 2^14): ONE contiguous Merge pass over the whole ring
         // with the transposition of the natural-order side done in LDS (XP above).  a.tw = Merge table of the ring.
-        // NAT: the natural-order extension (NTT_4STEP_CPU order on the spectrum side, XP = 3 / 4) instead of the
-        // reference layout (XP = 1 / 2)
+        // NAT: the natural-order extension (NTT_4STEP_CPU order on the spectrum side, Xp::small_nat_fwd / small_nat_inv) instead of the
+        // reference layout (Xp::small_fwd / small_inv)
         template <typename T, int TLOG, bool INV, int K, int LIM = 0, bool NAT = false>
         __global__ __launch_bounds__(LTile<TLOG>::NT, (LOcc<TLOG, T>::WAVES)) void fourstep_small_lazy(LazyArgsT<T> a)
         {

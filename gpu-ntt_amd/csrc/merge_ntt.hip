@@ -235,9 +235,9 @@ namespace gpuntt
             using TW = lazy::Tw<TU>;
             if (batch_size <= 0 || (batch_size & (batch_size - 1)) != 0)
                 return false; // (the generic path reports the error)
-            if (forced_path() == 1 || modulus.value < 3 || modulus.bit > TU(lazy::Mod<TU>::MAX_BIT) ||
-                (INV && ninv >= modulus.value))
+            if (forced_path() == 1 || !fast_modulus<TU>(modulus) || (INV && ninv >= modulus.value))
                 return false;
+            const bool wide = needs_lim<TU>(modulus) != 0; // 61- / 62-bit modulus (64-bit words): the 4 q strided kernels
             int log_w = 0;
             while ((1 << log_w) < batch_size)
                 log_w++;
@@ -287,7 +287,15 @@ namespace gpuntt
                     b.flags |= in_flags;
                 if (i == pl.count - 1)
                     b.flags |= out_flags;
-                host::launch_pass_lazy<TU, INV>(p, 12, i == 0, i == pl.count - 1, b, stream);
+                bool launched = false;
+                if constexpr (sizeof(TU) == 8)
+                    if (wide)
+                    {
+                        host::launch_pass_lazy_lim<INV, 4>(p, i == 0, i == pl.count - 1, b, stream);
+                        launched = true;
+                    }
+                if (!launched)
+                    host::launch_pass_lazy<TU, INV>(p, 12, i == 0, i == pl.count - 1, b, stream);
                 src = out;
             }
             return true;

@@ -156,16 +156,22 @@ def test_inverse_fourstep_plan_keeps_its_tile_when_the_option_changes(g):
 
 
 def _distinct_factors(widths, logn):
+    """distinct NTT primes of the given widths with (q, omega, psi) for a ring of 2^logn.  Searched for 2^max(logn, 12) and
+    brought down by squaring psi: the topmost primes = 1 mod 2^(logn + 1) of a small ring lie within double rounding of
+    the power of two, get an over-stated `bit` and (61 -> 62) a mu that does not fit the word (Modulus refuses them)."""
     out, seen = [], set()
+    lg = max(logn, 12)
     for w in widths:
         skip = 0
         while True:
-            f = find_ntt_factors(w, logn, skip)
-            if f[0] not in seen:
+            q, _, psi = find_ntt_factors(w, lg, skip)
+            if q not in seen:
                 break
             skip += 1
-        seen.add(f[0])
-        out.append(f)
+        seen.add(q)
+        psi = pow(psi, 1 << (lg - logn), q)
+        assert pow(psi, 1 << logn, q) == q - 1
+        out.append((q, psi * psi % q, psi))
     return out
 
 
@@ -311,5 +317,70 @@ def test_percoefficient_rns_on_the_lazy_kernels_with_per_lane_moduli(g, bits):
                 col = np.array([int(v) for v in want_i[:, p]], dtype=object)
                 centred = np.array([v - q if v > q // 2 else v for v in col], dtype=object)
                 assert all(int(a) == int(b) for a, b in zip(got[:, p], centred)), ("centred", bits, logn, p)
+    finally:
+        g.set_option("path", os.environ.get("GPUNTT_PATH", "default"))
+
+
+@pytest.mark.parametrize("qbits", [61, 62])
+def test_natural_order_fourstep_and_percoefficient_with_wide_single_modulus(g, qbits):
+    """the last two Barrett fall-backs inside the reference's domain (modular_arith.cuh:66-67) for a HOST-side modulus:
+    the natural-order 4-step extension and the single-modulus PerCoefficient layout with a 61- / 62-bit prime now run the
+    4 q lazy kernels (path = fast-strict throws if a call would need the generic kernels)."""
+    import torch
+    P = O.Port(64)
+    g.set_option("path", "fast-strict")
+    try:
+        # natural-order 4-step: 2^12 (one launch), 2^13 / 2^16 (strided + transposing row pass), 2^18 (two strided passes)
+        for logn, batch in ((12, 3), (13, 2), (16, 2), (18, 1)):
+            q, omega, psi = find_ntt_factors(qbits, logn)
+            m = g.Modulus(q, bits=64)
+            assert m.bit == qbits
+            shape = g.NTTParameters4Step(logn, 64)
+            n, n1, n2 = shape.n, shape.n1, shape.n2
+            oprm = P.merge_params(logn, O.X_N_minus, (q, omega, psi))
+            x = P.splitmix(5100 + logn + qbits, 0, batch * n, q)
+            y = P.merge_ntt(x, oprm)  # bit-reversed Merge spectrum; NTT_4STEP_CPU::ntt order is its n1 x n2 transpose
+            want = y.reshape(batch, n1, n2).transpose(0, 2, 1).reshape(-1)
+            tabs = {}
+            for inverse in (False, True):
+                r = pow(omega, -1, q) if inverse else omega
+                kind = g.INVERSE if inverse else g.FORWARD
+                w = torch.zeros(n, dtype=torch.int64, device="cuda")
+                t1 = torch.zeros(n1 >> 1, dtype=torch.int64, device="cuda")
+                t2 = torch.zeros(n2 >> 1, dtype=torch.int64, device="cuda")
+                g.GPU_Generate4StepW(w, r, m, logn, kind)
+                g.GPU_GeneratePowerTable(t1, pow(r, n // n1, q), m, int(np.log2(n1)) - 1, True)
+                g.GPU_GeneratePowerTable(t2, pow(r, n // n2, q), m, int(np.log2(n2)) - 1, True)
+                tabs[inverse] = (t1, t2, w)
+            d_in = g.to_device(x)
+            d_out = torch.zeros_like(d_in)
+            g.GPU_4STEP_NTT_NaturalOrder(d_in, d_out, *tabs[False], m, g.ntt4step_configuration(n_power=logn, ntt_type=g.FORWARD), batch)
+            torch.cuda.synchronize()
+            assert np.array_equal(g.to_host(d_out), want), ("natural forward", qbits, logn)
+            d_back = torch.zeros_like(d_out)
+            ci = g.ntt4step_configuration(n_power=logn, ntt_type=g.INVERSE, mod_inverse=pow(n, -1, q))
+            g.GPU_4STEP_NTT_NaturalOrder(d_out, d_back, *tabs[True], m, ci, batch)
+            torch.cuda.synchronize()
+            assert np.array_equal(g.to_host(d_back), x), ("natural inverse", qbits, logn)
+        # PerCoefficient layout, single wide modulus: one- and two-pass shapes
+        for logn, w, poly in ((9, 1024, O.X_N_plus), (8, 256, O.X_N_minus), (5, 4096, O.X_N_plus)):
+            f = _distinct_factors([qbits], logn)[0]
+            c = MergeCase(g, 64, logn, poly, f)
+            assert c.prm.modulus.bit == qbits
+            n = c.n
+            cols = c.random(w, 5300 + logn + w).reshape(w, n)
+            mat = np.ascontiguousarray(cols.T)
+            want_f = np.ascontiguousarray(c.P.merge_ntt(cols.reshape(-1), c.oprm).reshape(w, n).T)
+            cfg = g.ntt_configuration(n_power=logn, ntt_layout=g.PerCoefficient, reduction_poly=poly)
+            d = g.to_device(mat.reshape(-1))
+            o = torch.zeros_like(d)
+            g.GPU_NTT(d, o, c.fwd_dev, c.prm.modulus, cfg, w)
+            torch.cuda.synchronize()
+            assert np.array_equal(g.to_host(o).reshape(n, w), want_f), ("percoefficient fwd", qbits, logn, w)
+            icfg = g.ntt_configuration(n_power=logn, ntt_type=g.INVERSE, ntt_layout=g.PerCoefficient, reduction_poly=poly,
+                                       mod_inverse=c.prm.n_inv)
+            g.GPU_INTT_Inplace(o, c.inv_dev, c.prm.modulus, icfg, w)
+            torch.cuda.synchronize()
+            assert np.array_equal(g.to_host(o).reshape(n, w), mat), ("percoefficient inv", qbits, logn, w)
     finally:
         g.set_option("path", os.environ.get("GPUNTT_PATH", "default"))
