@@ -467,9 +467,9 @@ namespace gpuntt
                 return dispatch_tl<T, 12, INV>(p, in_first, last, a, stream);
             if (tile_log == 14 && (sizeof(T) == 4 || p.contig))
                 return dispatch_tl<T, 14, INV>(p, in_first, last, a, stream);
-            if constexpr (sizeof(T) == 8)
-                if (tile_log == 13 && p.contig)
-                    return dispatch_tl<T, 13, INV>(p, in_first, last, a, stream);
+            // 8192-coefficient tile: 64-bit contiguous passes (2^13, 2^21); 32-bit: the single pass of the ring 2^13
+            if (tile_log == 13 && p.contig)
+                return dispatch_tl<T, 13, INV>(p, in_first, last, a, stream);
             throw std::invalid_argument("internal: unsupported tile size in the fast path");
         }
     } // namespace host

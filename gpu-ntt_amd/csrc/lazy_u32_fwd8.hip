@@ -9,6 +9,8 @@ void launch_pass_lazy_u32w<false>(const Pass& p, int tile_log, bool in_first, bo
         return dispatch_tl<uint32_t, 12, false, 8>(p, in_first, last, a, stream);
     if (tile_log == 14)
         return dispatch_tl<uint32_t, 14, false, 8>(p, in_first, last, a, stream);
+    if (tile_log == 13 && p.contig)
+        return dispatch_tl<uint32_t, 13, false, 8>(p, in_first, last, a, stream);
     throw std::invalid_argument("internal: unsupported tile size in the fast path");
 }
 } }

@@ -9,6 +9,8 @@ void launch_pass_lazy_u32w<true>(const Pass& p, int tile_log, bool in_first, boo
         return dispatch_tl<uint32_t, 12, true, 8>(p, in_first, last, a, stream);
     if (tile_log == 14)
         return dispatch_tl<uint32_t, 14, true, 8>(p, in_first, last, a, stream);
+    if (tile_log == 13 && p.contig)
+        return dispatch_tl<uint32_t, 13, true, 8>(p, in_first, last, a, stream);
     throw std::invalid_argument("internal: unsupported tile size in the fast path");
 }
 template void launch_fourstep_inv_first_lazy<uint32_t, 8>(int, const kern::LazyArgsT<uint32_t>&, hipStream_t, int);

@@ -424,6 +424,7 @@ namespace gpuntt
                 std::atomic<int> reverse{1};    // consecutive passes walk the batch in opposite directions
                 std::atomic<int> big_tiles{14}; // largest 64-bit ring done in one big tile
                 std::atomic<int> u32_tile{0};   // 12 | 14: 32-bit tile above 2^14
+                std::atomic<int> u32_ring13_batch{16}; // 32-bit ring 2^13: calls of at most this many polynomials take the 8192 tile
                 std::atomic<int> no_scratch{0}; // test hook: behave as if the twiddle scratch could not be allocated
                 std::atomic<int> validate_4step{0}; // GPU_4STEP_NTT: spot-check the caller's n2 / W tables against the derived powers
                 std::atomic<int> q59{1};         // 64-bit moduli 2^59 + c, c < 2^32: the shift form of the quotient product
@@ -477,6 +478,12 @@ namespace gpuntt
                     return false;
                 g_opt.u32_tile = iv;
             }
+            else if (k == "u32_ring13_batch")
+            {
+                if (!is_num || lv < 0 || lv > 1000000)
+                    return false;
+                g_opt.u32_ring13_batch = iv;
+            }
             else if (k == "xcd_order" || k == "lim31" || k == "reverse" || k == "no_scratch" || k == "validate_4step_tables" ||
                      k == "q59" || k == "unit_skip" || k == "fuse_batch1")
             {
@@ -520,6 +527,10 @@ namespace gpuntt
         bool lazy_reverse_passes() { return g_opt.reverse.load(std::memory_order_relaxed) != 0; }
         int lazy_u64_big_tiles() { return g_opt.big_tiles.load(std::memory_order_relaxed); }
         int lazy_u32_tile_override() { return g_opt.u32_tile.load(std::memory_order_relaxed); }
+        unsigned long long lazy_u32_small_batch()
+        {
+            return static_cast<unsigned long long>(g_opt.u32_ring13_batch.load(std::memory_order_relaxed));
+        }
         bool validate_4step_tables() { return g_opt.validate_4step.load(std::memory_order_relaxed) != 0; }
         bool lazy_q59_enabled() { return g_opt.q59.load(std::memory_order_relaxed) != 0; }
         bool lazy_unit_skip_enabled() { return g_opt.unit_skip.load(std::memory_order_relaxed) != 0; }
