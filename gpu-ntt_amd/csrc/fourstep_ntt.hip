@@ -102,10 +102,11 @@ namespace gpuntt
         void fourstep_run(T* in, T* out, const T* n1_table, const T* n2_table, const T* w_table,
                           const Modulus<T>* mods, Modulus<T> mod, int mod_count, const T* ninv_arr,
                           T ninv, int n_power, int log_n1, int log_n2, int batch_size,
-                          hipStream_t stream, const unsigned* skip_flag = nullptr)
+                          hipStream_t stream, const unsigned* skip_flag = nullptr, unsigned skip_value = 0u)
         {
             kern::PassArgs<T> a{};
             a.skip_flag = skip_flag;
+            a.skip_value = skip_value;
             a.in = in;
             a.out = out;
             a.roots = n1_table;
@@ -182,18 +183,23 @@ namespace gpuntt
                                const Modulus<T>& mod, T ninv, int n_power, int log_n1, int log_n2,
                                int batch_size, hipStream_t stream, const Modulus<T>* mods_dev = nullptr,
                                const T* ninv_dev = nullptr, const unsigned** go_flag_out = nullptr,
-                               const PlanUse<T>& plan = PlanUse<T>(), int dev_family = 0)
+                               const PlanUse<T>& plan = PlanUse<T>(), int dev_family = 0, unsigned* host_state = nullptr)
         {
             using TW = lazy::Tw<T>;
             if (plan.mode != PLAN_NONE && mods_dev != nullptr)
                 return false;
-            // dev_family = 8 / 4 (64-bit words, device-side modulus): a FURTHER enqueue of the call -- the 8 q / 4 q kernels that
-            // own it when the go-flag says GO_LAZY_8Q / GO_LAZY_4Q (61- / 62-bit modulus).  The table was prepared by the first enqueue
-            // (prep_merge_from_fourstep permutes it for the family that will run); only the kernels are launched here.
-            const bool do_prep = plan.mode != PLAN_EXECUTE && dev_family == 0;
+            // device-side modulus (the RNS overload with one modulus), dev_family:
+            //    0  preparation + the kernels of the default lazy family
+            //   -1  preparation only (the host predicts another family for this modulus, host::RnsGuess; host_state = the
+            //       host-mapped word the preparation kernel reports the state to)
+            //   8 / 4 (64-bit words)  the kernels of the 8 q / 4 q family, no preparation: they own the call when the go-flag
+            //       says GO_LAZY_8Q / GO_LAZY_4Q (61- / 62-bit modulus); the table was permuted on the device for the family
+            //       that will run (prep_merge_from_fourstep)
+            const bool do_prep = plan.mode != PLAN_EXECUTE && dev_family <= 0;
+            const bool prep_only = (dev_family == -1);
             // host-side modulus: 61- / 62-bit moduli run the same plans on the LIMIT = 8 / 4 kernels (the whole
             // documented domain of the reference, modular_arith.cuh:66-67), like the Merge entry points
-            int lim = (mods_dev != nullptr) ? dev_family : 0;
+            int lim = (mods_dev != nullptr && dev_family > 0) ? dev_family : 0;
             if (mods_dev == nullptr)
             {
                 if (!host::modulus_fast<T>(mod) || (INV && ninv >= mod.value))
@@ -238,10 +244,10 @@ namespace gpuntt
                     host::launch_prep_merge_from_fourstep<T>(n1_table, w_table, ws_w, log_n1, log_n2,
                                                              (n_power >= small_tl) ? small_tl : 0, INV, INV, mod.value, ninv,
                                                              mods_dev, (INV && mods_dev) ? ninv_dev : nullptr, ws_ninv, go_flag,
-                                                             norm_arr, stream);
+                                                             norm_arr, stream, host_state);
                 if (go_flag_out != nullptr)
                     *go_flag_out = go_flag;
-                if (plan.mode == PLAN_PREPARE)
+                if (plan.mode == PLAN_PREPARE || prep_only)
                     return true;
                 kern::LazyArgsT<T> s{};
                 s.in = in;
@@ -292,10 +298,10 @@ namespace gpuntt
                     if (do_prep)
                         host::launch_prep_merge_from_fourstep<T>(n1_table, w_table, ws_w, log_n1, log_n2, tlf, false, false,
                                                                  mod.value, T(0), mods_dev, nullptr, nullptr, go_flag,
-                                                                 norm_arr, stream);
+                                                                 norm_arr, stream, host_state);
                     if (go_flag_out != nullptr)
                         *go_flag_out = go_flag;
-                    if (plan.mode == PLAN_PREPARE)
+                    if (plan.mode == PLAN_PREPARE || prep_only)
                         return true;
                     kern::LazyArgsT<T> f{};
                     f.in = in;
@@ -364,10 +370,10 @@ namespace gpuntt
                     if (do_prep)
                         host::launch_prep_merge_from_fourstep<T>(n1_table, w_table, ws_w, log_n1, log_n2, tli, true, true,
                                                                  mod.value, ninv, mods_dev, mods_dev ? ninv_dev : nullptr,
-                                                                 ws_ninv, go_flag, norm_arr, stream);
+                                                                 ws_ninv, go_flag, norm_arr, stream, host_state);
                     if (go_flag_out != nullptr)
                         *go_flag_out = go_flag;
-                    if (plan.mode == PLAN_PREPARE)
+                    if (plan.mode == PLAN_PREPARE || prep_only)
                         return true;
                     const bool rows512 = (k_a == 0); // 2^15 / 2^16: one partial contiguous pass over the 512-long rows
                     const int passes = k_b != 0 ? 3 : 2;
@@ -705,6 +711,7 @@ namespace gpuntt
             if ((static_cast<unsigned long long>(batch_size) << n_power) >> kern::TL > 0x7fffffffull)
                 throw std::invalid_argument("batch_size * N too large for one launch");
             const unsigned* skip_flag = nullptr;
+            host::RnsGuess guess{kern::GO_LAZY, true, nullptr};
             if (mods != nullptr && mod_count == 1 && host::forced_path() == 4)
             {
                 // test hook: the generic kernels as they run behind a go-flag that says "yours" (what a
@@ -715,26 +722,28 @@ namespace gpuntt
             }
             else if (mods != nullptr && mod_count == 1)
             {
-                // one device-side modulus: fast kernels + generic kernels behind the go-flag
-                if (ntt_type == FORWARD)
-                    fourstep_run_lazy<T, false>(in, out, n1_table, n2_table, w_table, Modulus<T>(), T(0), n_power, l1,
-                                                l2, batch_size, stream, mods, ninv_arr, &skip_flag);
-                else
-                    fourstep_run_lazy<T, true>(in, out, n1_table, n2_table, w_table, Modulus<T>(), T(0), n_power, l1,
-                                               l2, batch_size, stream, mods, ninv_arr, &skip_flag);
-                // 64-bit words: the 8 q / 4 q families behind the same flag (a 61- / 62-bit modulus), no second preparation
+                // one device-side modulus: the lazy family this modulus needed last time (host::RnsGuess) -- or every family
+                // -- and the generic kernels behind the go-flag
+                guess = host::rns_guess(mods, 1, static_cast<int>(sizeof(T)));
+                auto enqueue = [&](int family, const unsigned** flag_out) {
+                    if (ntt_type == FORWARD)
+                        return fourstep_run_lazy<T, false>(in, out, n1_table, n2_table, w_table, Modulus<T>(), T(0), n_power, l1, l2,
+                                                           batch_size, stream, mods, ninv_arr, flag_out, PlanUse<T>(), family,
+                                                           guess.state_out);
+                    return fourstep_run_lazy<T, true>(in, out, n1_table, n2_table, w_table, Modulus<T>(), T(0), n_power, l1, l2,
+                                                      batch_size, stream, mods, ninv_arr, flag_out, PlanUse<T>(), family,
+                                                      guess.state_out);
+                };
+                const bool only_default = !guess.all_families && guess.state == kern::GO_LAZY;
+                // the first enqueue prepares the table and publishes the flag; with it the default family unless another
+                // one is predicted
+                enqueue((guess.all_families || only_default) ? 0 : -1, &skip_flag);
                 if constexpr (sizeof(T) == 8)
                 {
                     if (skip_flag != nullptr)
                         for (int fam : {8, 4})
-                        {
-                            if (ntt_type == FORWARD)
-                                fourstep_run_lazy<T, false>(in, out, n1_table, n2_table, w_table, Modulus<T>(), T(0), n_power,
-                                                            l1, l2, batch_size, stream, mods, ninv_arr, nullptr, PlanUse<T>(), fam);
-                            else
-                                fourstep_run_lazy<T, true>(in, out, n1_table, n2_table, w_table, Modulus<T>(), T(0), n_power,
-                                                           l1, l2, batch_size, stream, mods, ninv_arr, nullptr, PlanUse<T>(), fam);
-                        }
+                            if (guess.all_families || guess.state == (fam == 8 ? kern::GO_LAZY_8Q : kern::GO_LAZY_4Q))
+                                enqueue(fam, nullptr);
                 }
             }
             if (mods != nullptr && mod_count == 1 && skip_flag != nullptr && host::forced_path() == 3)
@@ -752,12 +761,21 @@ namespace gpuntt
                 if (host::forced_path() == 3) // test hook, like the Merge entry points
                     throw std::invalid_argument("fast path unavailable for this call (path = fast-strict)");
             }
+            // behind lazy families: "return if one of them owns the call" (merge_kernels.hpp: PassArgs::skip_value)
+            unsigned skip_value = 0u;
+            if (skip_flag != nullptr && !guess.all_families)
+            {
+                if (guess.state == kern::GO_GENERIC)
+                    skip_flag = nullptr;
+                else
+                    skip_value = guess.state;
+            }
             if (ntt_type == FORWARD)
                 fourstep_run<T, false>(in, out, n1_table, n2_table, w_table, mods, mod, mod_count,
-                                       ninv_arr, ninv, n_power, l1, l2, batch_size, stream, skip_flag);
+                                       ninv_arr, ninv, n_power, l1, l2, batch_size, stream, skip_flag, skip_value);
             else
                 fourstep_run<T, true>(in, out, n1_table, n2_table, w_table, mods, mod, mod_count,
-                                      ninv_arr, ninv, n_power, l1, l2, batch_size, stream, skip_flag);
+                                      ninv_arr, ninv, n_power, l1, l2, batch_size, stream, skip_flag, skip_value);
         }
     } // namespace
 

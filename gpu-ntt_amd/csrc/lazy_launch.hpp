@@ -96,15 +96,34 @@ namespace gpuntt
                          bool negacyclic, int perm_tile_log, const T* ninv_arr, lazy::Tw<T>* ws_ninv,
                          unsigned* go_flag, lazy::NormConst* norm_arr, hipStream_t stream,
                          const int* mod_order = nullptr, const T* fold_ninv_single = nullptr,
-                         bool fold_ninv_rns = false);
+                         bool fold_ninv_rns = false, unsigned* host_state = nullptr);
+
+        // Drop-in RNS calls keep their moduli in device memory; the preparation kernel classifies them (four-state go-flag,
+        // merge_lazy_kernels.hpp).  Enqueueing EVERY kernel family behind that flag costs a kernel boundary (~1.5 us) per
+        // family and pass although one family runs, so the host PREDICTS the family from what the same stack -- same
+        // device, moduli pointer and mod_count -- needed the last time: the preparation kernel also writes the state to a
+        // host-mapped word (`state_out`), read here WITHOUT any synchronisation (an older value is as good).  Only the
+        // predicted lazy family is enqueued, and behind it the generic kernels with "return if the flag names the predicted
+        // state": a wrong or stale prediction (first call, moduli rewritten in place, a captured graph replayed after the
+        // moduli changed) is served by the Barrett kernels -- slower, never wrong -- and corrected on the next call.  A
+        // stack that misses twice keeps the all-families form.  all_families: enqueue every lazy family + the generic
+        // kernels behind "return if the flag is not GO_GENERIC" (also: option rns_predict = 0, path = fast-strict, a full
+        // prediction table).
+        struct RnsGuess
+        {
+            unsigned state;      // predicted go-flag state (kern::GO_*); meaningful when !all_families
+            bool all_families;
+            unsigned* state_out; // device pointer of the host-mapped word for the preparation kernel, or nullptr
+        };
+        RnsGuess rns_guess(const void* moduli_device, int mod_count, int word_bytes);
         extern template void launch_prep<uint64_t>(const uint64_t*, lazy::Tw64*, const Modulus<uint64_t>*,
                                                    uint64_t, int, int, bool, int, const uint64_t*,
                                                    lazy::Tw64*, unsigned*, lazy::NormConst*, hipStream_t, const int*,
-                                                   const uint64_t*, bool);
+                                                   const uint64_t*, bool, unsigned*);
         extern template void launch_prep<uint32_t>(const uint32_t*, lazy::Tw32*, const Modulus<uint32_t>*,
                                                    uint32_t, int, int, bool, int, const uint32_t*,
                                                    lazy::Tw32*, unsigned*, lazy::NormConst*, hipStream_t, const int*,
-                                                   const uint32_t*, bool);
+                                                   const uint32_t*, bool, unsigned*);
 
         // 4-step transform of a ring that fits one tile in one launch: 64-bit 2^12 (tile 12), 2^13 (tile 13), 2^14 forward
         // (tile 14); 32-bit 2^12 (tile 12), 2^13 (tile 13), 2^14 (tile 14).  a.tw = Merge table of the ring
@@ -214,15 +233,18 @@ namespace gpuntt
         void launch_prep_merge_from_fourstep(const T* n1_table, const T* w_table, lazy::Tw<T>* ws, int log_n1, int log_n2,
                                              int perm_tile_log, bool inverse, bool fold, T q, T ninv,
                                              const Modulus<T>* mods, const T* ninv_dev, lazy::Tw<T>* ws_ninv,
-                                             unsigned* go_flag, lazy::NormConst* norm_arr, hipStream_t stream);
+                                             unsigned* go_flag, lazy::NormConst* norm_arr, hipStream_t stream,
+                                             unsigned* host_state = nullptr);
         extern template void launch_prep_merge_from_fourstep<uint64_t>(const uint64_t*, const uint64_t*, lazy::Tw64*, int,
                                                                        int, int, bool, bool, uint64_t, uint64_t,
                                                                        const Modulus<uint64_t>*, const uint64_t*,
-                                                                       lazy::Tw64*, unsigned*, lazy::NormConst*, hipStream_t);
+                                                                       lazy::Tw64*, unsigned*, lazy::NormConst*, hipStream_t,
+                                                                       unsigned*);
         extern template void launch_prep_merge_from_fourstep<uint32_t>(const uint32_t*, const uint32_t*, lazy::Tw32*, int,
                                                                        int, int, bool, bool, uint32_t, uint32_t,
                                                                        const Modulus<uint32_t>*, const uint32_t*,
-                                                                       lazy::Tw32*, unsigned*, lazy::NormConst*, hipStream_t);
+                                                                       lazy::Tw32*, unsigned*, lazy::NormConst*, hipStream_t,
+                                                                       unsigned*);
         // option validate_4step_tables: one launch + one stream synchronisation; throws std::invalid_argument when the
         // caller's tables are not the NTTParameters4Step tables of one root of order N (prep.hip)
         template <typename T>
@@ -281,9 +303,6 @@ namespace gpuntt
 
         bool lazy_reverse_passes();
         bool validate_4step_tables();     // option validate_4step_tables (default off)
-        bool lazy_q59_enabled();          // option q59 (default on; A/B switch)
-        bool lazy_unit_skip_enabled();    // option unit_skip (default on; A/B switch)
-        bool lazy_fuse_batch1_enabled();  // option fuse_batch1 (default on; A/B switch)
         // forward 4-step in Merge form: stages of the first pass (the one that reads the transposed input) -- the first
         // strided pass of the ring's Merge plan on tile `tl`, widened to log2 n1 where that is larger (5 .. 8)
         inline int fourstep_first_k(int n_power, int log_n1, int tl)

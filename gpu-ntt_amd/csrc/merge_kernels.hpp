@@ -64,7 +64,10 @@ namespace gpuntt
             const T* ninv_arr;      // device array (RNS) or nullptr
             T ninv;
             const T* w_table;       // 4-step W matrix (F_FOURSTEP_T) or nullptr
-            const unsigned* skip_flag; // device word or nullptr: != 0 -> the fast path owns this call
+            const unsigned* skip_flag; // device word or nullptr: the go-flag of a drop-in RNS call (prep.hip)
+            unsigned skip_value;       // 0: return when *skip_flag != 0 (a lazy family owns the call); s > 0: return when
+                                       // *skip_flag == s (only the lazy family of state s was enqueued in front of this
+                                       // launch -- every other state is this kernel's job, lazy_launch.hpp: RnsGuess)
             const int* mod_order;  // *_Modulus_Ordered: polynomial p uses prime mod_order[p % mod_count]
             const int* poly_order; // *_Poly_Ordered: polynomial p lives in slot poly_order[p] of in/out
             unsigned long long total; // batch * N coefficients
@@ -276,8 +279,12 @@ namespace gpuntt
             using S = typename std::make_signed<T>::type;
             __shared__ T lds[LDS_ELEMS];
 
-            if (a.skip_flag != nullptr && *a.skip_flag != 0u)
-                return;
+            if (a.skip_flag != nullptr)
+            {
+                const unsigned st = *a.skip_flag;
+                if (a.skip_value == 0u ? (st != 0u) : (st == a.skip_value))
+                    return;
+            }
             const int t = threadIdx.x;
             // one tile per block, except for the shadow launches of RNS calls (skip_flag set), which
             // use a capped grid that walks the tiles so that a skipped launch costs ~1 us, not ~7

@@ -130,7 +130,7 @@ namespace gpuntt
                                             const Modulus<TU>* mods, int mod_count, const TU* ninv_dev,
                                             int n_power, ReductionPolynomial poly, int batch_size,
                                             hipStream_t stream, const int* mod_order = nullptr,
-                                            const TU* ninv_single = nullptr)
+                                            const TU* ninv_single = nullptr, unsigned* host_state = nullptr)
         {
             using TW = lazy::Tw<TU>;
             const bool neg = (poly == ReductionPolynomial::X_N_plus);
@@ -158,7 +158,7 @@ namespace gpuntt
             auto* norm_arr = mods ? reinterpret_cast<lazy::NormConst*>(tail_p + 16) : nullptr;
             host::launch_prep<TU>(roots, ws, mods, m.value, mod_count, n_power, neg, perm_tile_log, ninv_dev,
                                   ninv_dev ? ws_ninv : nullptr, go_flag, norm_arr, stream, mod_order, ninv_single,
-                                  ninv_dev != nullptr);
+                                  ninv_dev != nullptr, mods ? host_state : nullptr);
             kern::LazyArgsT<TU> a{};
             a.in = in;
             a.out = out;
@@ -191,17 +191,39 @@ namespace gpuntt
         // kernels behind them (capped shadow grid) are left with moduli outside the documented domain.
         template <typename TU, bool INV>
         inline void run_transform_lazy_rns(const kern::LazyArgsT<TU>& la, unsigned in_flags, unsigned out_flags,
-                                           hipStream_t stream)
+                                           hipStream_t stream, const host::RnsGuess& guess)
         {
-            host::run_transform_lazy<TU, INV>(la, in_flags, out_flags, stream);
+            // the family the stack needed last time (host::RnsGuess), or every family
+            if (guess.all_families || guess.state == kern::GO_LAZY)
+                host::run_transform_lazy<TU, INV>(la, in_flags, out_flags, stream);
             if constexpr (sizeof(TU) == 8)
             {
                 kern::LazyArgsT<TU> wide = la;
-                wide.lim = 8; // widest modulus 61 bit (measured: a C5-shaped stack with one 61-bit prime 0.30 ms on the
-                              // 4 q kernels against 0.22 ms on the 8 q ones)
-                host::run_transform_lazy<TU, INV>(wide, in_flags, out_flags, stream);
-                wide.lim = 4; // widest modulus 62 bit
-                host::run_transform_lazy<TU, INV>(wide, in_flags, out_flags, stream);
+                if (guess.all_families || guess.state == kern::GO_LAZY_8Q)
+                {
+                    wide.lim = 8; // widest modulus 61 bit (measured: a C5-shaped stack with one 61-bit prime 0.30 ms on the
+                                  // 4 q kernels against 0.22 ms on the 8 q ones)
+                    host::run_transform_lazy<TU, INV>(wide, in_flags, out_flags, stream);
+                }
+                if (guess.all_families || guess.state == kern::GO_LAZY_4Q)
+                {
+                    wide.lim = 4; // widest modulus 62 bit
+                    host::run_transform_lazy<TU, INV>(wide, in_flags, out_flags, stream);
+                }
+            }
+        }
+        // the generic kernels behind the lazy families of a drop-in RNS call: "return if a lazy family owns the call"
+        template <typename TU>
+        inline void generic_behind(kern::PassArgs<TU>& a, const unsigned* go_flag, const host::RnsGuess& guess)
+        {
+            a.skip_flag = go_flag;
+            a.skip_value = 0u; // every family was enqueued: any state but GO_GENERIC is theirs
+            if (go_flag != nullptr && !guess.all_families)
+            {
+                if (guess.state == kern::GO_GENERIC)
+                    a.skip_flag = nullptr; // nothing was enqueued in front: the whole call is this launch's
+                else
+                    a.skip_value = guess.state; // only that family was enqueued: every other state is this launch's
             }
         }
 
@@ -561,6 +583,7 @@ namespace gpuntt
             throw std::invalid_argument("Invalid mod_count!");
         const unsigned in_flags = std::is_signed<T>::value ? kern::F_SIGNED_IN : 0u;
         const unsigned* skip_flag = nullptr;
+        host::RnsGuess guess{kern::GO_LAZY, true, nullptr}; // all families unless a prediction is made below
         if (cfg.ntt_layout == PerCoefficient)
         {
             kern::PassArgs<TU> a = base_args<TU>(device_in, device_out, root_of_unity_table, cfg.n_power,
@@ -584,10 +607,12 @@ namespace gpuntt
             skip_flag = zeroed_flag(cfg.stream); // test hook: the generic kernels as they run behind a go-flag that names them
         else if (batch_size > 0 && lazy_eligible<TU>(cfg.n_power, batch_size, mod_count, cfg.stream))
         {
+            guess = host::rns_guess(modulus, mod_count, static_cast<int>(sizeof(TU)));
             kern::LazyArgsT<TU> la =
                 lazy_args<TU>(device_in, device_out, root_of_unity_table, Modulus<TU>(), modulus, mod_count,
-                              nullptr, cfg.n_power, cfg.reduction_poly, batch_size, cfg.stream);
-            run_transform_lazy_rns<TU, false>(la, in_flags, 0u, cfg.stream);
+                              nullptr, cfg.n_power, cfg.reduction_poly, batch_size, cfg.stream, nullptr, nullptr,
+                              guess.state_out);
+            run_transform_lazy_rns<TU, false>(la, in_flags, 0u, cfg.stream, guess);
             skip_flag = la.go_flag;
             if (forced_path() == 3)
                 return; // test hook (path = fast-strict): no generic shadow launches -- the lazy families must own the call
@@ -596,7 +621,7 @@ namespace gpuntt
                                              cfg.reduction_poly, batch_size);
         a.mods = modulus;
         a.mod_count = mod_count;
-        a.skip_flag = skip_flag;
+        generic_behind(a, skip_flag, guess);
         set_multi(a);
         host::run_transform<TU, false>(a, in_flags, 0u, cfg.stream);
     }
@@ -616,6 +641,7 @@ namespace gpuntt
         const unsigned out_flags =
             kern::F_SCALE | (std::is_signed<T>::value ? kern::F_CENTERED : 0u);
         const unsigned* skip_flag = nullptr;
+        host::RnsGuess guess{kern::GO_LAZY, true, nullptr}; // all families unless a prediction is made below
         if (cfg.ntt_layout == PerCoefficient)
         {
             kern::PassArgs<TU> a =
@@ -643,11 +669,12 @@ namespace gpuntt
         else if (batch_size > 0 && cfg.mod_inverse != nullptr &&
             lazy_eligible<TU>(cfg.n_power, batch_size, mod_count, cfg.stream))
         {
+            guess = host::rns_guess(modulus, mod_count, static_cast<int>(sizeof(TU)));
             kern::LazyArgsT<TU> la =
                 lazy_args<TU>(device_in, reinterpret_cast<TU*>(device_out), root_of_unity_table,
                               Modulus<TU>(), modulus, mod_count, cfg.mod_inverse, cfg.n_power,
-                              cfg.reduction_poly, batch_size, cfg.stream);
-            run_transform_lazy_rns<TU, true>(la, 0u, out_flags, cfg.stream);
+                              cfg.reduction_poly, batch_size, cfg.stream, nullptr, nullptr, guess.state_out);
+            run_transform_lazy_rns<TU, true>(la, 0u, out_flags, cfg.stream, guess);
             skip_flag = la.go_flag;
             if (forced_path() == 3)
                 return; // test hook (path = fast-strict): no generic shadow launches
@@ -658,7 +685,7 @@ namespace gpuntt
         a.mods = modulus;
         a.mod_count = mod_count;
         a.ninv_arr = cfg.mod_inverse;
-        a.skip_flag = skip_flag;
+        generic_behind(a, skip_flag, guess);
         set_multi(a);
         host::run_transform<TU, true>(a, 0u, out_flags, cfg.stream);
     }
@@ -691,11 +718,16 @@ namespace gpuntt
         __global__ __launch_bounds__(256) void pointwise_mul(const T* a, const T* b, T* out,
                                                              const Modulus<T>* __restrict__ mods, Modulus<T> mod,
                                                              int mod_count, int n, unsigned long long total,
-                                                             const unsigned* __restrict__ skip_flag)
+                                                             const unsigned* __restrict__ skip_flag, unsigned skip_value)
         {
-            // GPU_PolyMul, RNS form: the fast forward kernels already multiplied on their final store
-            if (skip_flag != nullptr && *skip_flag != 0u)
-                return;
+            // GPU_PolyMul, RNS form: the fast forward kernels already multiplied on their final store (same test as the
+            // generic transform in front of this launch, merge_kernels.hpp: PassArgs::skip_value)
+            if (skip_flag != nullptr)
+            {
+                const unsigned st = *skip_flag;
+                if (skip_value == 0u ? (st != 0u) : (st == skip_value))
+                    return;
+            }
             // V elements per access: 16 bytes when the buffers are 16-byte aligned, else 1 element
             struct alignas(V * sizeof(T)) Vec
             {
@@ -723,7 +755,8 @@ namespace gpuntt
     {
         template <typename T>
         void pointwise_launch(T* a, T* b, T* out, const Modulus<T>* mods, Modulus<T> mod, int mod_count,
-                              int n_power, int batch_size, hipStream_t stream, const unsigned* skip_flag = nullptr)
+                              int n_power, int batch_size, hipStream_t stream, const unsigned* skip_flag = nullptr,
+                              unsigned skip_value = 0u)
         {
             if (n_power <= 0 || n_power >= 29)
                 throw std::invalid_argument("Invalid n_power range!");
@@ -741,10 +774,10 @@ namespace gpuntt
                 blocks = 16384; // 64 blocks per CU, grid-stride beyond
             if (wide)
                 hipLaunchKernelGGL((kern::pointwise_mul<T, VW>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0,
-                                   stream, a, b, out, mods, mod, mod_count, n_power, total, skip_flag);
+                                   stream, a, b, out, mods, mod, mod_count, n_power, total, skip_flag, skip_value);
             else
                 hipLaunchKernelGGL((kern::pointwise_mul<T, 1>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0,
-                                   stream, a, b, out, mods, mod, mod_count, n_power, total, skip_flag);
+                                   stream, a, b, out, mods, mod, mod_count, n_power, total, skip_flag, skip_value);
             GPUNTT_HIP_CHECK(hipGetLastError());
         }
     } // namespace
@@ -842,25 +875,26 @@ namespace gpuntt
         // moduli live on the device: fast kernels (multiplying on their final store) and generic
         // kernels + pointwise_mul are both enqueued, the go-flag decides which family runs
         const unsigned* skip_flag = nullptr;
+        host::RnsGuess guess{kern::GO_LAZY, true, nullptr};
         if (lazy_eligible<T>(cfg.n_power, batch_size, mod_count, cfg.stream))
         {
+            guess = host::rns_guess(modulus, mod_count, static_cast<int>(sizeof(T)));
             kern::LazyArgsT<T> la = lazy_args<T>(second, device_out, forward_table, Modulus<T>(), modulus, mod_count,
-                                                 nullptr, cfg.n_power, cfg.reduction_poly, batch_size, cfg.stream);
+                                                 nullptr, cfg.n_power, cfg.reduction_poly, batch_size, cfg.stream, nullptr,
+                                                 nullptr, guess.state_out);
             la.mul_in = first;
-            run_transform_lazy_rns<T, false>(la, 0u, 0u, cfg.stream);
+            run_transform_lazy_rns<T, false>(la, 0u, 0u, cfg.stream, guess);
             skip_flag = la.go_flag;
         }
-        {
-            kern::PassArgs<T> a = base_args<T>(second, device_out, forward_table, cfg.n_power, cfg.reduction_poly,
-                                               batch_size);
-            a.mods = modulus;
-            a.mod_count = mod_count;
-            a.skip_flag = skip_flag;
-            set_multi(a);
-            host::run_transform<T, false>(a, 0u, 0u, cfg.stream);
-        }
+        kern::PassArgs<T> a = base_args<T>(second, device_out, forward_table, cfg.n_power, cfg.reduction_poly, batch_size);
+        a.mods = modulus;
+        a.mod_count = mod_count;
+        generic_behind(a, skip_flag, guess);
+        set_multi(a);
+        host::run_transform<T, false>(a, 0u, 0u, cfg.stream);
+        // the pointwise product runs exactly when the generic transform did (the lazy kernels multiply on their final store)
         pointwise_launch<T>(first, device_out, device_out, modulus, Modulus<T>(), mod_count, cfg.n_power, batch_size,
-                            cfg.stream, skip_flag);
+                            cfg.stream, a.skip_flag, a.skip_value);
         f.ntt_type = INVERSE;
         GPU_INTT<T>(device_out, device_out, inverse_table, modulus, f, batch_size, mod_count);
     }
@@ -1141,19 +1175,21 @@ namespace gpuntt
                 return;
             const bool inv = (cfg.ntt_type == INVERSE);
             const unsigned* skip_flag = nullptr;
+            host::RnsGuess guess{kern::GO_LAZY, true, nullptr};
             // fast path: whole tiles inside one polynomial
             if (cfg.n_power >= host::lazy_tile_log<T>(cfg.n_power) &&
                 lazy_eligible<T>(cfg.n_power, batch_size, mod_count, cfg.stream) && (!inv || cfg.mod_inverse != nullptr))
             {
+                guess = host::rns_guess(modulus, mod_count, static_cast<int>(sizeof(T)));
                 kern::LazyArgsT<T> la =
                     lazy_args<T>(device_in, device_out, table, Modulus<T>(), modulus, mod_count,
                                  inv ? cfg.mod_inverse : nullptr, cfg.n_power, cfg.reduction_poly,
-                                 batch_size, cfg.stream, mod_order);
+                                 batch_size, cfg.stream, mod_order, nullptr, guess.state_out);
                 la.poly_order = poly_order;
                 if (inv)
-                    run_transform_lazy_rns<T, true>(la, 0u, kern::F_SCALE, cfg.stream);
+                    run_transform_lazy_rns<T, true>(la, 0u, kern::F_SCALE, cfg.stream, guess);
                 else
-                    run_transform_lazy_rns<T, false>(la, 0u, 0u, cfg.stream);
+                    run_transform_lazy_rns<T, false>(la, 0u, 0u, cfg.stream, guess);
                 skip_flag = la.go_flag;
             }
             kern::PassArgs<T> a = base_args<T>(device_in, device_out, table, cfg.n_power,
@@ -1161,7 +1197,7 @@ namespace gpuntt
             a.mods = modulus;
             a.mod_count = mod_count;
             a.ninv_arr = cfg.mod_inverse;
-            a.skip_flag = skip_flag;
+            generic_behind(a, skip_flag, guess);
             a.mod_order = mod_order;
             a.poly_order = poly_order;
             set_multi(a);

@@ -15,6 +15,7 @@
 #include <initializer_list>
 #include <string>
 #include <map>
+#include <tuple>
 #include <mutex>
 #include <vector>
 
@@ -97,7 +98,8 @@ namespace gpuntt
                                                              unsigned* __restrict__ go_flag,
                                                              lazy::NormConst* __restrict__ norm_arr,
                                                              const int* __restrict__ mod_order,
-                                                             T ninv_single, int fold_ninv)
+                                                             T ninv_single, int fold_ninv,
+                                                             unsigned* __restrict__ host_state)
         {
             const unsigned long long gid = blockIdx.x * 256ull + threadIdx.x;
             // RNS stacks (moduli in device memory): classify the stack -- kern::GO_GENERIC (a modulus outside the fast
@@ -134,6 +136,9 @@ namespace gpuntt
                         norm_arr[i] = lazy::make_norm_const(md.value, md.bit);
                     }
                 *go_flag = state;
+                // host-mapped word (or nullptr): what the host predicts the NEXT call of this stack from (RnsGuess)
+                if (host_state != nullptr)
+                    *host_state = state;
             }
             const unsigned long long per_mod = 1ull << n;
             // RNS stacks: the reciprocal of the block's modulus is derived once per block (a block
@@ -208,7 +213,7 @@ namespace gpuntt
             const T* __restrict__ n1_table, const T* __restrict__ w_table, lazy::Tw<T>* __restrict__ ws, int log_n1,
             int log_n2, int perm_tile_log, int inverse, int fold, T q_single, T rinv_single, T ninv_single,
             const Modulus<T>* __restrict__ mods, const T* __restrict__ ninv_dev, lazy::Tw<T>* __restrict__ ws_ninv,
-            unsigned* __restrict__ go_flag, lazy::NormConst* __restrict__ norm_arr)
+            unsigned* __restrict__ go_flag, lazy::NormConst* __restrict__ norm_arr, unsigned* __restrict__ host_state)
         {
             const unsigned long long gid = blockIdx.x * 256ull + threadIdx.x;
             __shared__ T s_rinv;
@@ -234,6 +239,8 @@ namespace gpuntt
                 {
                     if (go_flag != nullptr)
                         *go_flag = state;
+                    if (host_state != nullptr)
+                        *host_state = state;
                     if (norm_arr != nullptr)
                         norm_arr[0] = lazy::make_norm_const(md.value, md.bit);
                 }
@@ -397,6 +404,78 @@ namespace gpuntt
             }
         }
 
+        // ---- which lazy family will a drop-in RNS call need?  (RnsGuess, lazy_launch.hpp) ------------------------------
+        namespace
+        {
+            struct GuessSlot
+            {
+                unsigned* host_word = nullptr; // host-mapped pinned word the preparation kernel writes the state to
+                unsigned* dev_word = nullptr;
+                unsigned predicted = kern::GO_LAZY;
+                bool have_prediction = false;
+                int mispredicts = 0;
+            };
+            std::mutex g_guess_mutex;
+            std::map<std::tuple<int, const void*, int, int>, GuessSlot> g_guess; // (device, moduli, mod_count, word size)
+            constexpr size_t GUESS_MAX_KEYS = 256;
+            constexpr unsigned STATE_UNKNOWN = 0xffffffffu;
+        } // namespace
+
+        static bool rns_predict_enabled(); // option rns_predict (defined with the options below)
+        RnsGuess rns_guess(const void* moduli_device, int mod_count, int word_bytes)
+        {
+            RnsGuess gss{kern::GO_LAZY, true, nullptr};
+            if (!rns_predict_enabled() || forced_path() == 3)
+                return gss; // every family (path = fast-strict: the tests want the lazy families to own the call)
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess)
+                return gss;
+            std::lock_guard<std::mutex> lock(g_guess_mutex);
+            const auto key = std::make_tuple(dev, moduli_device, mod_count, word_bytes);
+            auto it = g_guess.find(key);
+            if (it == g_guess.end())
+            {
+                if (g_guess.size() >= GUESS_MAX_KEYS)
+                    return gss; // table full: this stack keeps the all-families form
+                GuessSlot slot;
+                void* hp = nullptr;
+                if (hipHostMalloc(&hp, sizeof(unsigned), hipHostMallocMapped) != hipSuccess)
+                {
+                    (void) hipGetLastError();
+                    return gss;
+                }
+                void* dp = nullptr;
+                if (hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess)
+                {
+                    (void) hipGetLastError();
+                    (void) hipHostFree(hp);
+                    return gss;
+                }
+                slot.host_word = static_cast<unsigned*>(hp);
+                slot.dev_word = static_cast<unsigned*>(dp);
+                *reinterpret_cast<volatile unsigned*>(slot.host_word) = STATE_UNKNOWN;
+                it = g_guess.emplace(key, slot).first; // (slots live as long as the process: captured graphs keep writing to them)
+            }
+            GuessSlot& s = it->second;
+            const unsigned seen = *reinterpret_cast<volatile unsigned*>(s.host_word);
+            if (seen != STATE_UNKNOWN && seen <= kern::GO_LAZY_4Q)
+            {
+                // the state some earlier call of this stack found (the last one that has finished).  It differs from what was
+                // predicted for it: the caller rewrites this buffer with stacks of different widths -- after the second miss
+                // the stack keeps the all-families form (always the right lazy kernels, a few empty launches more)
+                if (s.have_prediction && seen != s.predicted)
+                    s.mispredicts++;
+                s.predicted = seen;
+                s.have_prediction = true;
+            }
+            gss.state_out = s.dev_word;
+            if (s.mispredicts >= 2)
+                return gss;
+            gss.all_families = false;
+            gss.state = s.predicted;
+            return gss;
+        }
+
         // host twin of kern::recip_norm
         template <typename T> static T recip_norm_host(T q)
         {
@@ -427,9 +506,7 @@ namespace gpuntt
                 std::atomic<int> u32_ring13_batch{16}; // 32-bit ring 2^13: calls of at most this many polynomials take the 8192 tile
                 std::atomic<int> no_scratch{0}; // test hook: behave as if the twiddle scratch could not be allocated
                 std::atomic<int> validate_4step{0}; // GPU_4STEP_NTT: spot-check the caller's n2 / W tables against the derived powers
-                std::atomic<int> q59{1};         // 64-bit moduli 2^59 + c, c < 2^32: the shift form of the quotient product
-                std::atomic<int> unit_skip{1};   // cyclic transforms: block-uniform twiddles equal to 1 skip their product
-                std::atomic<int> fuse_batch1{1}; // small calls: both passes of a two-pass plan in one launch
+                std::atomic<int> rns_predict{1}; // drop-in RNS calls: enqueue only the lazy family the stack needed last time
             } g_opt;
         } // namespace
 
@@ -485,7 +562,7 @@ namespace gpuntt
                 g_opt.u32_ring13_batch = iv;
             }
             else if (k == "xcd_order" || k == "lim31" || k == "reverse" || k == "no_scratch" || k == "validate_4step_tables" ||
-                     k == "q59" || k == "unit_skip" || k == "fuse_batch1")
+                     k == "rns_predict")
             {
                 if (!one_of({0, 1}))
                     return false;
@@ -494,9 +571,7 @@ namespace gpuntt
                                         : k == "reverse"               ? g_opt.reverse
                                         : k == "no_scratch"            ? g_opt.no_scratch
                                         : k == "validate_4step_tables" ? g_opt.validate_4step
-                                        : k == "q59"                   ? g_opt.q59
-                                        : k == "unit_skip"             ? g_opt.unit_skip
-                                                                       : g_opt.fuse_batch1;
+                                                                       : g_opt.rns_predict;
                 dst = iv;
             }
             else
@@ -505,6 +580,7 @@ namespace gpuntt
         }
 
         int forced_path() { return g_opt.path.load(std::memory_order_relaxed); }
+        static bool rns_predict_enabled() { return g_opt.rns_predict.load(std::memory_order_relaxed) != 0; }
 
         int lazy_contig_k(int n)
         {
@@ -532,9 +608,6 @@ namespace gpuntt
             return static_cast<unsigned long long>(g_opt.u32_ring13_batch.load(std::memory_order_relaxed));
         }
         bool validate_4step_tables() { return g_opt.validate_4step.load(std::memory_order_relaxed) != 0; }
-        bool lazy_q59_enabled() { return g_opt.q59.load(std::memory_order_relaxed) != 0; }
-        bool lazy_unit_skip_enabled() { return g_opt.unit_skip.load(std::memory_order_relaxed) != 0; }
-        bool lazy_fuse_batch1_enabled() { return g_opt.fuse_batch1.load(std::memory_order_relaxed) != 0; }
 
         void* lazy_workspace(hipStream_t stream, size_t bytes, bool or_null)
         {
@@ -592,14 +665,14 @@ namespace gpuntt
         void launch_prep(const T* roots, lazy::Tw<T>* ws, const Modulus<T>* mods, T q, int mod_count, int n,
                          bool negacyclic, int perm_tile_log, const T* ninv_arr, lazy::Tw<T>* ws_ninv,
                          unsigned* go_flag, lazy::NormConst* norm_arr, hipStream_t stream, const int* mod_order,
-                         const T* fold_ninv_single, bool fold_ninv_rns)
+                         const T* fold_ninv_single, bool fold_ninv_rns, unsigned* host_state)
         {
             const unsigned long long entries = static_cast<unsigned long long>(mod_count) << n;
             const unsigned grid = static_cast<unsigned>((entries + 255) / 256);
             hipLaunchKernelGGL((kern::prep_twiddles<T>), dim3(grid), dim3(256), 0, stream, roots, ws, mods, q,
                                (mods == nullptr) ? recip_norm_host<T>(q) : static_cast<T>(0), mod_count, n, negacyclic ? 1 : 0, perm_tile_log, ninv_arr, ws_ninv, go_flag, norm_arr, mod_order,
                                fold_ninv_single ? *fold_ninv_single : static_cast<T>(0),
-                               (fold_ninv_single != nullptr || (fold_ninv_rns && ninv_arr != nullptr)) ? 1 : 0);
+                               (fold_ninv_single != nullptr || (fold_ninv_rns && ninv_arr != nullptr)) ? 1 : 0, host_state);
             GPUNTT_HIP_CHECK(hipGetLastError());
         }
         template <typename T>
@@ -640,31 +713,32 @@ namespace gpuntt
         void launch_prep_merge_from_fourstep(const T* n1_table, const T* w_table, lazy::Tw<T>* ws, int log_n1, int log_n2,
                                              int perm_tile_log, bool inverse, bool fold, T q, T ninv,
                                              const Modulus<T>* mods, const T* ninv_dev, lazy::Tw<T>* ws_ninv,
-                                             unsigned* go_flag, lazy::NormConst* norm_arr, hipStream_t stream)
+                                             unsigned* go_flag, lazy::NormConst* norm_arr, hipStream_t stream,
+                                             unsigned* host_state)
         {
             const unsigned long long count = 1ull << (log_n1 + log_n2);
             const unsigned grid = static_cast<unsigned>((count + 255) / 256);
             hipLaunchKernelGGL((kern::prep_merge_from_fourstep<T>), dim3(grid), dim3(256), 0, stream, n1_table, w_table, ws,
                                log_n1, log_n2, perm_tile_log, inverse ? 1 : 0, fold ? 1 : 0, q,
                                mods ? static_cast<T>(0) : recip_norm_host<T>(q), ninv, mods, ninv_dev, ws_ninv, go_flag,
-                               norm_arr);
+                               norm_arr, host_state);
             GPUNTT_HIP_CHECK(hipGetLastError());
         }
         template void launch_prep_merge_from_fourstep<uint64_t>(const uint64_t*, const uint64_t*, lazy::Tw64*, int, int, int,
                                                                 bool, bool, uint64_t, uint64_t, const Modulus<uint64_t>*,
                                                                 const uint64_t*, lazy::Tw64*, unsigned*, lazy::NormConst*,
-                                                                hipStream_t);
+                                                                hipStream_t, unsigned*);
         template void launch_prep_merge_from_fourstep<uint32_t>(const uint32_t*, const uint32_t*, lazy::Tw32*, int, int, int,
                                                                 bool, bool, uint32_t, uint32_t, const Modulus<uint32_t>*,
                                                                 const uint32_t*, lazy::Tw32*, unsigned*, lazy::NormConst*,
-                                                                hipStream_t);
+                                                                hipStream_t, unsigned*);
 
 
         template void launch_prep<uint64_t>(const uint64_t*, lazy::Tw64*, const Modulus<uint64_t>*, uint64_t, int,
                                             int, bool, int, const uint64_t*, lazy::Tw64*, unsigned*, lazy::NormConst*, hipStream_t, const int*,
-                                            const uint64_t*, bool);
+                                            const uint64_t*, bool, unsigned*);
         template void launch_prep<uint32_t>(const uint32_t*, lazy::Tw32*, const Modulus<uint32_t>*, uint32_t, int,
                                             int, bool, int, const uint32_t*, lazy::Tw32*, unsigned*, lazy::NormConst*, hipStream_t, const int*,
-                                            const uint32_t*, bool);
+                                            const uint32_t*, bool, unsigned*);
     } // namespace host
 } // namespace gpuntt

@@ -209,11 +209,9 @@ namespace gpuntt
     //                            (they run on the generic kernels, which need none)
     //   validate_4step_tables 0 | 1   GPU_4STEP_NTT / FourStepPlan: spot-check the caller's n2 / W tables against the powers
     //                            the fast path derives (ntt_4step/ntt_4step.cuh, "table contract"); default 0
-    //   q59            0 | 1     64-bit moduli of the form 2^59 + c, c < 2^32 (every prime of the reference's pools): shift form
-    //                            of one quotient product (default 1; A/B switch)
-    //   unit_skip      0 | 1     cyclic transforms: block-uniform twiddles equal to 1 skip their product (default 1; A/B switch)
-    //   fuse_batch1    0 | 1     calls small enough to be resident at once: both passes of a two-pass plan in ONE launch
-    //                            (default 1; A/B switch)
+    //   rns_predict    0 | 1     drop-in RNS calls enqueue only the lazy kernel family their stack of moduli (same device,
+    //                            moduli pointer, mod_count) needed the last time, with the generic kernels behind it for
+    //                            every other case (default 1); 0: every family behind the go-flag on every call
     // Returns false for an unknown name or a value outside the sets above (the whole string must parse: "abc", contig_k = 7,
     // u32_tile = 13 are refused, nothing is silently mapped to a default).  Plans keep the choice made when they were created.
     bool GPU_NTT_SetOption(const char* name, const char* value);

@@ -413,3 +413,70 @@ def test_u32_ring_2_13_small_calls_on_their_own_tile(g):
         assert np.array_equal(c.gpu_forward(x), c.P.merge_ntt(x, c.oprm))
     finally:
         g.set_option("u32_ring13_batch", "16")
+
+
+def test_rns_family_prediction_survives_moduli_rewritten_in_place(g):
+    """Drop-in RNS calls enqueue only the lazy family their stack needed LAST time (host::RnsGuess: the preparation kernel
+    reports the classification to a host-mapped word the next call reads without synchronising) plus the generic kernels
+    behind "return if the flag names the predicted state".  The stateless contract must survive the worst caller: ONE
+    device buffer of moduli rewritten between calls with stacks of different widths (every prediction stale or wrong),
+    with and without a synchronisation in between, option rns_predict off, and the 4-step RNS overload the same way."""
+    import torch
+    logn, batch = 13, 9
+    n = 1 << logn
+    stacks = {}
+    for name, widths in (("w60", (60, 60, 60)), ("w61", (60, 61, 60)), ("w62", (62, 60, 61))):
+        cases = [MergeCase(g, 64, logn, O.X_N_plus, f) for f in _distinct_factors(widths, logn)]
+        fwd = np.zeros(3 * n, dtype=np.uint64)
+        for i, c in enumerate(cases):
+            fwd[i * n:i * n + c.prm.root_of_unity_size] = c.prm.forward_table_device_order
+        x = np.concatenate([cases[p % 3].P.splitmix(97000 + p, 0, n, cases[p % 3].q) for p in range(batch)])
+        want = np.concatenate([cases[p % 3].P.merge_ntt(x[p * n:(p + 1) * n], cases[p % 3].oprm) for p in range(batch)])
+        stacks[name] = (g.modulus_array_to_device([c.prm.modulus for c in cases], 64), g.to_device(fwd), x, want)
+    mods = torch.zeros_like(stacks["w60"][0])  # THE buffer every call below passes
+    cfg = g.ntt_rns_configuration(n_power=logn, reduction_poly=O.X_N_plus)
+    order = ["w60", "w60", "w61", "w61", "w61", "w60", "w62", "w62", "w60", "w61", "w62", "w60", "w60"]
+    for predict in ("1", "0"):
+        g.set_option("rns_predict", predict)
+        try:
+            for sync in (True, False):
+                for i, name in enumerate(order):
+                    src, table, x, want = stacks[name]
+                    mods.copy_(src)
+                    d = g.to_device(x)
+                    o = torch.zeros_like(d)
+                    g.GPU_NTT(d, o, table, mods, cfg, batch, 3)
+                    if sync:
+                        torch.cuda.synchronize()
+                    assert np.array_equal(g.to_host(o), want), (predict, sync, i, name)
+        finally:
+            g.set_option("rns_predict", "1")
+    # the 4-step RNS overload, one device-side modulus rewritten in place: 60 -> 62 -> 62 -> 61 -> 60 bits
+    P = O.Port(64)
+    logn, batch = 13, 3
+    shape = g.NTTParameters4Step(logn, 64)
+    n, n1, n2 = shape.n, shape.n1, shape.n2
+    mod_buf = None
+    for step, qbits in enumerate((60, 62, 62, 61, 60, 60)):
+        q, omega, psi = _distinct_factors([qbits], logn)[0]
+        m = g.Modulus(q, bits=64)
+        oprm = P.merge_params(logn, O.X_N_minus, (q, omega, psi))
+        x = P.splitmix(97500 + step, 0, batch * n, q)
+        y = P.merge_ntt(x, oprm)
+        w = torch.zeros(n, dtype=torch.int64, device="cuda")
+        t1 = torch.zeros(n1 >> 1, dtype=torch.int64, device="cuda")
+        t2 = torch.zeros(n2 >> 1, dtype=torch.int64, device="cuda")
+        g.GPU_Generate4StepW(w, omega, m, logn, g.FORWARD)
+        g.GPU_GeneratePowerTable(t1, pow(omega, n // n1, q), m, int(np.log2(n1)) - 1, True)
+        g.GPU_GeneratePowerTable(t2, pow(omega, n // n2, q), m, int(np.log2(n2)) - 1, True)
+        src = g.modulus_array_to_device([m], 64)
+        if mod_buf is None:
+            mod_buf = torch.zeros_like(src)
+        mod_buf.copy_(src)
+        ninv = g.to_device(np.array([pow(n, -1, q)], dtype=np.uint64))
+        cfg4 = g.ntt4step_rns_configuration(n_power=logn, ntt_type=g.FORWARD, mod_inverse=ninv)
+        d_in = g.to_device(x.reshape(batch, n1, n2).transpose(0, 2, 1).reshape(-1).copy())
+        d_out = torch.zeros_like(d_in)
+        g.GPU_4STEP_NTT(d_in, d_out, t1, t2, w, mod_buf, cfg4, batch, 1)
+        torch.cuda.synchronize()
+        assert np.array_equal(g.to_host(d_out), y), ("4-step", step, qbits)

@@ -155,12 +155,13 @@ def test_options_replace_environment_switches(g):
                         ("reverse", "0"), ("reverse", "1"), ("u64_big_tiles", "13"), ("u64_big_tiles", "14"),
                         ("u32_tile", "12"), ("u32_tile", "0"), ("no_scratch", "1"), ("no_scratch", "0")):
         g.set_option(name, value)
-    for name, value in (("validate_4step_tables", "1"), ("validate_4step_tables", "0"), ("q59", "0"), ("q59", "1"),
-                        ("unit_skip", "0"), ("unit_skip", "1"), ("fuse_batch1", "0"), ("fuse_batch1", "1")):
+    for name, value in (("validate_4step_tables", "1"), ("validate_4step_tables", "0"), ("rns_predict", "0"),
+                        ("rns_predict", "1"), ("u32_ring13_batch", "0"), ("u32_ring13_batch", "16")):
         g.set_option(name, value)
     # unknown names, and values outside the documented sets, are refused -- never silently mapped to a default
     for name, value in (("path", "sideways"), ("no_such_option", "1"), ("u64_big_tiles", "abc"), ("contig_k", "7"),
-                        ("u32_tile", "13"), ("contig_k", "11x"), ("lim31", "2"), ("reverse", ""), ("u64_big_tiles", "12")):
+                        ("u32_tile", "13"), ("contig_k", "11x"), ("lim31", "2"), ("reverse", ""), ("u64_big_tiles", "12"),
+                        ("q59", "1"), ("rns_predict", "yes"), ("u32_ring13_batch", "-1")):
         assert lib.gpuntt_set_option(name.encode(), value.encode()) != 0, (name, value)
     assert lib.gpuntt_set_option(None, None) != 0
     import subprocess
