@@ -18,6 +18,6 @@ unset GPUNTT_LIB
 echo "# per-kernel averages (rocprofv3 --kernel-trace --stats), one run each"
 for lib in product q59; do
   if [ $lib = q59 ]; then export GPUNTT_LIB=$PWD/tools/_exp_q59.so; else unset GPUNTT_LIB; fi
-  rm -rf /tmp/prof_$lib; (cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats -d /tmp/prof_$lib -o p -- python $PWD/bench.py --steps 200 --warmup 20 --no-traffic --no-cpu-baseline --no-power > /dev/null 2>&1)
+  rm -rf /tmp/prof_$lib; (R=$PWD; cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats -d /tmp/prof_$lib -o p -- python $R/bench.py --steps 200 --warmup 20 --no-traffic --no-cpu-baseline --no-power > /dev/null 2>&1)
   echo "## $lib"; python tools/rocprof_summary.py /tmp/prof_$lib 2>/dev/null | head -n 8
 done
