@@ -724,7 +724,7 @@ namespace gpuntt
             {
                 // one device-side modulus: the lazy family this modulus needed last time (host::RnsGuess) -- or every family
                 // -- and the generic kernels behind the go-flag
-                guess = host::rns_guess(mods, 1, static_cast<int>(sizeof(T)));
+                guess = host::rns_guess(mods, 1, static_cast<int>(sizeof(T)) | 0x40, ntt_type == INVERSE); // (0x40: the 4-step entry keeps its own slot)
                 auto enqueue = [&](int family, const unsigned** flag_out) {
                     if (ntt_type == FORWARD)
                         return fourstep_run_lazy<T, false>(in, out, n1_table, n2_table, w_table, Modulus<T>(), T(0), n_power, l1, l2,

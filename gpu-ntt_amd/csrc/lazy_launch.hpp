@@ -96,7 +96,7 @@ namespace gpuntt
                          bool negacyclic, int perm_tile_log, const T* ninv_arr, lazy::Tw<T>* ws_ninv,
                          unsigned* go_flag, lazy::NormConst* norm_arr, hipStream_t stream,
                          const int* mod_order = nullptr, const T* fold_ninv_single = nullptr,
-                         bool fold_ninv_rns = false, unsigned* host_state = nullptr);
+                         bool fold_ninv_rns = false, unsigned* host_state = nullptr, bool allow_31q = false);
 
         // Drop-in RNS calls keep their moduli in device memory; the preparation kernel classifies them (four-state go-flag,
         // merge_lazy_kernels.hpp).  Enqueueing EVERY kernel family behind that flag costs a kernel boundary (~1.5 us) per
@@ -115,15 +115,15 @@ namespace gpuntt
             bool all_families;
             unsigned* state_out; // device pointer of the host-mapped word for the preparation kernel, or nullptr
         };
-        RnsGuess rns_guess(const void* moduli_device, int mod_count, int word_bytes);
+        RnsGuess rns_guess(const void* moduli_device, int mod_count, int word_bytes, bool inverse);
         extern template void launch_prep<uint64_t>(const uint64_t*, lazy::Tw64*, const Modulus<uint64_t>*,
                                                    uint64_t, int, int, bool, int, const uint64_t*,
                                                    lazy::Tw64*, unsigned*, lazy::NormConst*, hipStream_t, const int*,
-                                                   const uint64_t*, bool, unsigned*);
+                                                   const uint64_t*, bool, unsigned*, bool);
         extern template void launch_prep<uint32_t>(const uint32_t*, lazy::Tw32*, const Modulus<uint32_t>*,
                                                    uint32_t, int, int, bool, int, const uint32_t*,
                                                    lazy::Tw32*, unsigned*, lazy::NormConst*, hipStream_t, const int*,
-                                                   const uint32_t*, bool, unsigned*);
+                                                   const uint32_t*, bool, unsigned*, bool);
 
         // 4-step transform of a ring that fits one tile in one launch: 64-bit 2^12 (tile 12), 2^13 (tile 13), 2^14 forward
         // (tile 14); 32-bit 2^12 (tile 12), 2^13 (tile 13), 2^14 (tile 14).  a.tw = Merge table of the ring

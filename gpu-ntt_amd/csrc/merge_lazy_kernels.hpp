@@ -1147,13 +1147,16 @@ namespace gpuntt
         }
 
         // Drop-in RNS calls keep their moduli in device memory, so the host cannot pick the kernel family: the preparation
-        // kernel classifies the stack and publishes a four-state go-flag (prep.hip: 0 = generic Barrett kernels, 1 = the
-        // default lazy range of the word size, 2 / 3 = 64-bit words whose widest modulus has 61 / 62 bits: the 8 q / 4 q
-        // range), every family is enqueued and the ones the flag does not name return at once.
-        constexpr unsigned GO_GENERIC = 0u, GO_LAZY = 1u, GO_LAZY_8Q = 2u, GO_LAZY_4Q = 3u;
+        // kernel classifies the stack and publishes a go-flag (prep.hip: 0 = generic Barrett kernels, 1 = the default lazy
+        // range of the word size, 2 / 3 = 64-bit words whose widest modulus has 61 / 62 bits: the 8 q / 4 q range, 4 below);
+        // the kernels of a family the flag does not name return at once.
+        // GO_LAZY_31Q (forward Merge calls of 64-bit words only): every modulus of the stack has 31 q < 2^64 -- the 31 q
+        // kernels (a range correction every fourth stage), what NTTPlan picks from host moduli for the same stack
+        constexpr unsigned GO_GENERIC = 0u, GO_LAZY = 1u, GO_LAZY_8Q = 2u, GO_LAZY_4Q = 3u, GO_LAZY_31Q = 4u;
         template <typename T, int LIM> __device__ __forceinline__ bool not_my_call(const unsigned* go_flag)
         {
-            constexpr unsigned mine = (sizeof(T) == 8 && LIM == 4) ? GO_LAZY_4Q : ((sizeof(T) == 8 && LIM == 8) ? GO_LAZY_8Q : GO_LAZY);
+            constexpr unsigned mine = sizeof(T) != 8 ? GO_LAZY
+                                      : (LIM == 4 ? GO_LAZY_4Q : (LIM == 8 ? GO_LAZY_8Q : (LIM == 31 ? GO_LAZY_31Q : GO_LAZY)));
             return go_flag != nullptr && *go_flag != mine;
         }
 

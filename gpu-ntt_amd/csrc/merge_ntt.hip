@@ -158,7 +158,9 @@ namespace gpuntt
             auto* norm_arr = mods ? reinterpret_cast<lazy::NormConst*>(tail_p + 16) : nullptr;
             host::launch_prep<TU>(roots, ws, mods, m.value, mod_count, n_power, neg, perm_tile_log, ninv_dev,
                                   ninv_dev ? ws_ninv : nullptr, go_flag, norm_arr, stream, mod_order, ninv_single,
-                                  ninv_dev != nullptr, mods ? host_state : nullptr);
+                                  ninv_dev != nullptr, mods ? host_state : nullptr,
+                                  /* allow_31q: the Merge RNS entry points enqueue that family (run_transform_lazy_rns) */
+                                  mods != nullptr && host::lazy_lim31_enabled());
             kern::LazyArgsT<TU> a{};
             a.in = in;
             a.out = out;
@@ -199,6 +201,12 @@ namespace gpuntt
             if constexpr (sizeof(TU) == 8)
             {
                 kern::LazyArgsT<TU> wide = la;
+                if constexpr (!INV)
+                    if (host::lazy_lim31_enabled() && (guess.all_families || guess.state == kern::GO_LAZY_31Q))
+                    {
+                        wide.lim = 31; // every modulus has 31 q < 2^64 (the reference's pool primes): forward transforms
+                        host::run_transform_lazy<TU, INV>(wide, in_flags, out_flags, stream);
+                    }
                 if (guess.all_families || guess.state == kern::GO_LAZY_8Q)
                 {
                     wide.lim = 8; // widest modulus 61 bit (measured: a C5-shaped stack with one 61-bit prime 0.30 ms on the
@@ -607,7 +615,7 @@ namespace gpuntt
             skip_flag = zeroed_flag(cfg.stream); // test hook: the generic kernels as they run behind a go-flag that names them
         else if (batch_size > 0 && lazy_eligible<TU>(cfg.n_power, batch_size, mod_count, cfg.stream))
         {
-            guess = host::rns_guess(modulus, mod_count, static_cast<int>(sizeof(TU)));
+            guess = host::rns_guess(modulus, mod_count, static_cast<int>(sizeof(TU)), false);
             kern::LazyArgsT<TU> la =
                 lazy_args<TU>(device_in, device_out, root_of_unity_table, Modulus<TU>(), modulus, mod_count,
                               nullptr, cfg.n_power, cfg.reduction_poly, batch_size, cfg.stream, nullptr, nullptr,
@@ -669,7 +677,7 @@ namespace gpuntt
         else if (batch_size > 0 && cfg.mod_inverse != nullptr &&
             lazy_eligible<TU>(cfg.n_power, batch_size, mod_count, cfg.stream))
         {
-            guess = host::rns_guess(modulus, mod_count, static_cast<int>(sizeof(TU)));
+            guess = host::rns_guess(modulus, mod_count, static_cast<int>(sizeof(TU)), true);
             kern::LazyArgsT<TU> la =
                 lazy_args<TU>(device_in, reinterpret_cast<TU*>(device_out), root_of_unity_table,
                               Modulus<TU>(), modulus, mod_count, cfg.mod_inverse, cfg.n_power,
@@ -878,7 +886,7 @@ namespace gpuntt
         host::RnsGuess guess{kern::GO_LAZY, true, nullptr};
         if (lazy_eligible<T>(cfg.n_power, batch_size, mod_count, cfg.stream))
         {
-            guess = host::rns_guess(modulus, mod_count, static_cast<int>(sizeof(T)));
+            guess = host::rns_guess(modulus, mod_count, static_cast<int>(sizeof(T)), false);
             kern::LazyArgsT<T> la = lazy_args<T>(second, device_out, forward_table, Modulus<T>(), modulus, mod_count,
                                                  nullptr, cfg.n_power, cfg.reduction_poly, batch_size, cfg.stream, nullptr,
                                                  nullptr, guess.state_out);
@@ -1180,7 +1188,7 @@ namespace gpuntt
             if (cfg.n_power >= host::lazy_tile_log<T>(cfg.n_power) &&
                 lazy_eligible<T>(cfg.n_power, batch_size, mod_count, cfg.stream) && (!inv || cfg.mod_inverse != nullptr))
             {
-                guess = host::rns_guess(modulus, mod_count, static_cast<int>(sizeof(T)));
+                guess = host::rns_guess(modulus, mod_count, static_cast<int>(sizeof(T)), inv);
                 kern::LazyArgsT<T> la =
                     lazy_args<T>(device_in, device_out, table, Modulus<T>(), modulus, mod_count,
                                  inv ? cfg.mod_inverse : nullptr, cfg.n_power, cfg.reduction_poly,

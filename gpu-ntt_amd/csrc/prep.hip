@@ -99,7 +99,7 @@ namespace gpuntt
                                                              lazy::NormConst* __restrict__ norm_arr,
                                                              const int* __restrict__ mod_order,
                                                              T ninv_single, int fold_ninv,
-                                                             unsigned* __restrict__ host_state)
+                                                             unsigned* __restrict__ host_state, int allow_31q)
         {
             const unsigned long long gid = blockIdx.x * 256ull + threadIdx.x;
             // RNS stacks (moduli in device memory): classify the stack -- kern::GO_GENERIC (a modulus outside the fast
@@ -110,7 +110,7 @@ namespace gpuntt
             unsigned state = GO_LAZY;
             if (mods != nullptr && (perm_tile_log > 12 || blockIdx.x == 0))
             {
-                bool bad = false, w61 = false, w62 = false;
+                bool bad = false, w61 = false, w62 = false, over31 = false;
                 for (int i = static_cast<int>(threadIdx.x); i < mod_count; i += 256)
                 {
                     const Modulus<T> md = mods[mod_order != nullptr ? mod_order[i] : i];
@@ -120,12 +120,17 @@ namespace gpuntt
                         w62 = true;
                     else if (sizeof(T) == 8 && md.bit == static_cast<T>(61))
                         w61 = true;
+                    if (sizeof(T) == 8 && static_cast<unsigned long long>(md.value) > 0xffffffffffffffffull / 31)
+                        over31 = true;
                 }
                 const int any_bad = __syncthreads_or(bad ? 1 : 0), any62 = __syncthreads_or(w62 ? 1 : 0),
-                          any61 = __syncthreads_or(w61 ? 1 : 0);
-                state = any_bad ? GO_GENERIC : (any62 ? GO_LAZY_4Q : (any61 ? GO_LAZY_8Q : GO_LAZY));
+                          any61 = __syncthreads_or(w61 ? 1 : 0), any_over31 = __syncthreads_or(over31 ? 1 : 0);
+                // forward calls (no n^-1 folded) of 64-bit words whose every modulus has 31 q < 2^64: the 31 q kernels
+                const bool wide_range = sizeof(T) == 8 && allow_31q != 0 && fold_ninv == 0 && !any_over31;
+                state = any_bad ? GO_GENERIC
+                                : (any62 ? GO_LAZY_4Q : (any61 ? GO_LAZY_8Q : (wide_range ? GO_LAZY_31Q : GO_LAZY)));
             }
-            if (state >= GO_LAZY_8Q && perm_tile_log > 12)
+            if ((state == GO_LAZY_8Q || state == GO_LAZY_4Q) && perm_tile_log > 12)
                 perm_tile_log = 12;
             if (gid == 0 && go_flag != nullptr)
             {
@@ -233,7 +238,7 @@ namespace gpuntt
                                            : ((sizeof(T) == 8 && md.bit == static_cast<T>(62))
                                                   ? GO_LAZY_4Q
                                                   : ((sizeof(T) == 8 && md.bit == static_cast<T>(61)) ? GO_LAZY_8Q : GO_LAZY));
-                if (state >= GO_LAZY_8Q && perm_tile_log > 12)
+                if ((state == GO_LAZY_8Q || state == GO_LAZY_4Q) && perm_tile_log > 12)
                     perm_tile_log = 12;
                 if (gid == 0)
                 {
@@ -416,13 +421,15 @@ namespace gpuntt
                 int mispredicts = 0;
             };
             std::mutex g_guess_mutex;
-            std::map<std::tuple<int, const void*, int, int>, GuessSlot> g_guess; // (device, moduli, mod_count, word size)
+            // (device, moduli, mod_count, word size | direction << 8): forward and inverse calls of one stack may need
+            // different families (31 q serves forward transforms only)
+            std::map<std::tuple<int, const void*, int, int>, GuessSlot> g_guess;
             constexpr size_t GUESS_MAX_KEYS = 256;
             constexpr unsigned STATE_UNKNOWN = 0xffffffffu;
         } // namespace
 
         static bool rns_predict_enabled(); // option rns_predict (defined with the options below)
-        RnsGuess rns_guess(const void* moduli_device, int mod_count, int word_bytes)
+        RnsGuess rns_guess(const void* moduli_device, int mod_count, int word_bytes, bool inverse)
         {
             RnsGuess gss{kern::GO_LAZY, true, nullptr};
             if (!rns_predict_enabled() || forced_path() == 3)
@@ -431,7 +438,7 @@ namespace gpuntt
             if (hipGetDevice(&dev) != hipSuccess)
                 return gss;
             std::lock_guard<std::mutex> lock(g_guess_mutex);
-            const auto key = std::make_tuple(dev, moduli_device, mod_count, word_bytes);
+            const auto key = std::make_tuple(dev, moduli_device, mod_count, word_bytes | (inverse ? 0x100 : 0));
             auto it = g_guess.find(key);
             if (it == g_guess.end())
             {
@@ -458,7 +465,7 @@ namespace gpuntt
             }
             GuessSlot& s = it->second;
             const unsigned seen = *reinterpret_cast<volatile unsigned*>(s.host_word);
-            if (seen != STATE_UNKNOWN && seen <= kern::GO_LAZY_4Q)
+            if (seen != STATE_UNKNOWN && seen <= kern::GO_LAZY_31Q)
             {
                 // the state some earlier call of this stack found (the last one that has finished).  It differs from what was
                 // predicted for it: the caller rewrites this buffer with stacks of different widths -- after the second miss
@@ -665,14 +672,15 @@ namespace gpuntt
         void launch_prep(const T* roots, lazy::Tw<T>* ws, const Modulus<T>* mods, T q, int mod_count, int n,
                          bool negacyclic, int perm_tile_log, const T* ninv_arr, lazy::Tw<T>* ws_ninv,
                          unsigned* go_flag, lazy::NormConst* norm_arr, hipStream_t stream, const int* mod_order,
-                         const T* fold_ninv_single, bool fold_ninv_rns, unsigned* host_state)
+                         const T* fold_ninv_single, bool fold_ninv_rns, unsigned* host_state, bool allow_31q)
         {
             const unsigned long long entries = static_cast<unsigned long long>(mod_count) << n;
             const unsigned grid = static_cast<unsigned>((entries + 255) / 256);
             hipLaunchKernelGGL((kern::prep_twiddles<T>), dim3(grid), dim3(256), 0, stream, roots, ws, mods, q,
                                (mods == nullptr) ? recip_norm_host<T>(q) : static_cast<T>(0), mod_count, n, negacyclic ? 1 : 0, perm_tile_log, ninv_arr, ws_ninv, go_flag, norm_arr, mod_order,
                                fold_ninv_single ? *fold_ninv_single : static_cast<T>(0),
-                               (fold_ninv_single != nullptr || (fold_ninv_rns && ninv_arr != nullptr)) ? 1 : 0, host_state);
+                               (fold_ninv_single != nullptr || (fold_ninv_rns && ninv_arr != nullptr)) ? 1 : 0, host_state,
+                               allow_31q ? 1 : 0);
             GPUNTT_HIP_CHECK(hipGetLastError());
         }
         template <typename T>
@@ -736,9 +744,9 @@ namespace gpuntt
 
         template void launch_prep<uint64_t>(const uint64_t*, lazy::Tw64*, const Modulus<uint64_t>*, uint64_t, int,
                                             int, bool, int, const uint64_t*, lazy::Tw64*, unsigned*, lazy::NormConst*, hipStream_t, const int*,
-                                            const uint64_t*, bool, unsigned*);
+                                            const uint64_t*, bool, unsigned*, bool);
         template void launch_prep<uint32_t>(const uint32_t*, lazy::Tw32*, const Modulus<uint32_t>*, uint32_t, int,
                                             int, bool, int, const uint32_t*, lazy::Tw32*, unsigned*, lazy::NormConst*, hipStream_t, const int*,
-                                            const uint32_t*, bool, unsigned*);
+                                            const uint32_t*, bool, unsigned*, bool);
     } // namespace host
 } // namespace gpuntt

@@ -425,8 +425,14 @@ def test_rns_family_prediction_survives_moduli_rewritten_in_place(g):
     logn, batch = 13, 9
     n = 1 << logn
     stacks = {}
-    for name, widths in (("w60", (60, 60, 60)), ("w61", (60, 61, 60)), ("w62", (62, 60, 61))):
-        cases = [MergeCase(g, 64, logn, O.X_N_plus, f) for f in _distinct_factors(widths, logn)]
+    import json
+    c5 = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rns_c5.json")))["primes"]
+    pool = []  # primes of the reference's pools (2^59 + small: 31 q < 2^64 -> the 31 q family on forward calls)
+    for e in c5[:3]:
+        psi = pow(e["psi"], 1 << (16 - logn), e["q"])
+        pool.append((e["q"], psi * psi % e["q"], psi))
+    for name, widths in (("w60", (60, 60, 60)), ("w61", (60, 61, 60)), ("w62", (62, 60, 61)), ("pool", None)):
+        cases = [MergeCase(g, 64, logn, O.X_N_plus, f) for f in (pool if widths is None else _distinct_factors(widths, logn))]
         fwd = np.zeros(3 * n, dtype=np.uint64)
         for i, c in enumerate(cases):
             fwd[i * n:i * n + c.prm.root_of_unity_size] = c.prm.forward_table_device_order
@@ -435,7 +441,7 @@ def test_rns_family_prediction_survives_moduli_rewritten_in_place(g):
         stacks[name] = (g.modulus_array_to_device([c.prm.modulus for c in cases], 64), g.to_device(fwd), x, want)
     mods = torch.zeros_like(stacks["w60"][0])  # THE buffer every call below passes
     cfg = g.ntt_rns_configuration(n_power=logn, reduction_poly=O.X_N_plus)
-    order = ["w60", "w60", "w61", "w61", "w61", "w60", "w62", "w62", "w60", "w61", "w62", "w60", "w60"]
+    order = ["w60", "w60", "pool", "pool", "w61", "w61", "w61", "pool", "w60", "w62", "w62", "w60", "w61", "w62", "pool", "pool"]
     for predict in ("1", "0"):
         g.set_option("rns_predict", predict)
         try:
