@@ -414,18 +414,29 @@ namespace gpuntt
         {
             struct GuessSlot
             {
-                unsigned* host_word = nullptr; // host-mapped pinned word the preparation kernel writes the state to
-                unsigned* dev_word = nullptr;
+                int word = -1; // index of the slot's word in its device's pool of host-mapped words
                 unsigned predicted = kern::GO_LAZY;
                 bool have_prediction = false;
                 int mispredicts = 0;
+                unsigned long long last_use = 0;
             };
-            std::mutex g_guess_mutex;
-            // (device, moduli, mod_count, word size | direction << 8): forward and inverse calls of one stack may need
-            // different families (31 q serves forward transforms only)
-            std::map<std::tuple<int, const void*, int, int>, GuessSlot> g_guess;
+            // one pinned, device-mapped allocation per device: GUESS_MAX_KEYS words, one cache line apart.  Never freed
+            // (captured graphs keep writing their state to the word they were captured with; a word that has been handed to
+            // another stack meanwhile only costs that stack a wrong prediction, which the generic kernels behind it absorb)
+            struct GuessPool
+            {
+                unsigned* host = nullptr;
+                unsigned* dev = nullptr;
+            };
             constexpr size_t GUESS_MAX_KEYS = 256;
+            constexpr size_t GUESS_STRIDE = 16; // words
             constexpr unsigned STATE_UNKNOWN = 0xffffffffu;
+            std::mutex g_guess_mutex;
+            std::map<int, GuessPool> g_guess_pool;
+            // (device, moduli, mod_count, word size | entry point | direction): forward and inverse calls of one stack may
+            // need different families (31 q serves forward transforms only)
+            std::map<std::tuple<int, const void*, int, int>, GuessSlot> g_guess;
+            unsigned long long g_guess_clock = 0;
         } // namespace
 
         static bool rns_predict_enabled(); // option rns_predict (defined with the options below)
@@ -438,33 +449,51 @@ namespace gpuntt
             if (hipGetDevice(&dev) != hipSuccess)
                 return gss;
             std::lock_guard<std::mutex> lock(g_guess_mutex);
+            GuessPool& pool = g_guess_pool[dev];
+            if (pool.host == nullptr)
+            {
+                void* hp = nullptr;
+                void* dp = nullptr;
+                if (hipHostMalloc(&hp, sizeof(unsigned) * GUESS_STRIDE * GUESS_MAX_KEYS, hipHostMallocMapped) != hipSuccess ||
+                    hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess)
+                {
+                    (void) hipGetLastError(); // (not during a stream capture, or no pinned memory left): every family
+                    if (hp != nullptr)
+                        (void) hipHostFree(hp);
+                    return gss;
+                }
+                pool.host = static_cast<unsigned*>(hp);
+                pool.dev = static_cast<unsigned*>(dp);
+                for (size_t i = 0; i < GUESS_MAX_KEYS; i++)
+                    reinterpret_cast<volatile unsigned*>(pool.host)[i * GUESS_STRIDE] = STATE_UNKNOWN;
+            }
             const auto key = std::make_tuple(dev, moduli_device, mod_count, word_bytes | (inverse ? 0x100 : 0));
             auto it = g_guess.find(key);
             if (it == g_guess.end())
             {
-                if (g_guess.size() >= GUESS_MAX_KEYS)
-                    return gss; // table full: this stack keeps the all-families form
                 GuessSlot slot;
-                void* hp = nullptr;
-                if (hipHostMalloc(&hp, sizeof(unsigned), hipHostMallocMapped) != hipSuccess)
+                size_t on_dev = 0;
+                auto oldest = g_guess.end();
+                for (auto jt = g_guess.begin(); jt != g_guess.end(); ++jt)
+                    if (std::get<0>(jt->first) == dev)
+                    {
+                        on_dev++;
+                        if (oldest == g_guess.end() || jt->second.last_use < oldest->second.last_use)
+                            oldest = jt;
+                    }
+                if (on_dev < GUESS_MAX_KEYS)
+                    slot.word = static_cast<int>(on_dev); // words are handed out in order and only recycled below
+                else
                 {
-                    (void) hipGetLastError();
-                    return gss;
+                    slot.word = oldest->second.word; // table full: the least recently used stack gives up its word
+                    g_guess.erase(oldest);
                 }
-                void* dp = nullptr;
-                if (hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess)
-                {
-                    (void) hipGetLastError();
-                    (void) hipHostFree(hp);
-                    return gss;
-                }
-                slot.host_word = static_cast<unsigned*>(hp);
-                slot.dev_word = static_cast<unsigned*>(dp);
-                *reinterpret_cast<volatile unsigned*>(slot.host_word) = STATE_UNKNOWN;
-                it = g_guess.emplace(key, slot).first; // (slots live as long as the process: captured graphs keep writing to them)
+                reinterpret_cast<volatile unsigned*>(pool.host)[slot.word * GUESS_STRIDE] = STATE_UNKNOWN;
+                it = g_guess.emplace(key, slot).first;
             }
             GuessSlot& s = it->second;
-            const unsigned seen = *reinterpret_cast<volatile unsigned*>(s.host_word);
+            s.last_use = ++g_guess_clock;
+            const unsigned seen = reinterpret_cast<volatile unsigned*>(pool.host)[s.word * GUESS_STRIDE];
             if (seen != STATE_UNKNOWN && seen <= kern::GO_LAZY_31Q)
             {
                 // the state some earlier call of this stack found (the last one that has finished).  It differs from what was
@@ -475,7 +504,7 @@ namespace gpuntt
                 s.predicted = seen;
                 s.have_prediction = true;
             }
-            gss.state_out = s.dev_word;
+            gss.state_out = pool.dev + s.word * GUESS_STRIDE;
             if (s.mispredicts >= 2)
                 return gss;
             gss.all_families = false;
