@@ -486,3 +486,61 @@ def test_rns_family_prediction_survives_moduli_rewritten_in_place(g):
         g.GPU_4STEP_NTT(d_in, d_out, t1, t2, w, mod_buf, cfg4, batch, 1)
         torch.cuda.synchronize()
         assert np.array_equal(g.to_host(d_out), y), ("4-step", step, qbits)
+
+
+def test_rns_calls_from_four_host_threads_share_one_prediction_slot(g):
+    """four host threads, each on its own stream, call the drop-in RNS entry points with the SAME device moduli (one
+    prediction slot, one mutex: host::rns_guess) -- forward, inverse, repeatedly, while a fifth stack is used from the main
+    thread; every result equal to the oracle.  (ctypes releases the GIL: the library calls really overlap on the host.)"""
+    import threading
+    import torch
+    logn, batch, mc = 14, 6, 3
+    n = 1 << logn
+    cases = [MergeCase(g, 64, logn, O.X_N_plus, f) for f in _distinct_factors((60, 61, 60), logn)]
+    fwd = np.zeros(mc * n, dtype=np.uint64)
+    inv = np.zeros_like(fwd)
+    for i, c in enumerate(cases):
+        fwd[i * n:i * n + c.prm.root_of_unity_size] = c.prm.forward_table_device_order
+        inv[i * n:i * n + c.prm.root_of_unity_size] = c.prm.inverse_table_device_order
+    d_fwd, d_inv = g.to_device(fwd), g.to_device(inv)
+    mods = g.modulus_array_to_device([c.prm.modulus for c in cases], 64)
+    ninv = g.to_device(np.array([c.prm.n_inv for c in cases], dtype=np.uint64))
+    xs = [np.concatenate([cases[p % mc].P.splitmix(98000 + 100 * t + p, 0, n, cases[p % mc].q) for p in range(batch)])
+          for t in range(4)]
+    wants = [np.concatenate([cases[p % mc].P.merge_ntt(x[p * n:(p + 1) * n], cases[p % mc].oprm) for p in range(batch)])
+             for x in xs]
+    errors = []
+
+    def worker(t):
+        try:
+            s = torch.cuda.Stream()
+            cf = g.ntt_rns_configuration(n_power=logn, reduction_poly=O.X_N_plus, stream=s)
+            ci = g.ntt_rns_configuration(n_power=logn, ntt_type=g.INVERSE, reduction_poly=O.X_N_plus, mod_inverse=ninv, stream=s)
+            with torch.cuda.stream(s):
+                d = g.to_device(xs[t])
+            s.synchronize()
+            for it in range(25):
+                g.GPU_NTT_Inplace(d, d_fwd, mods, cf, batch, mc)
+                if it % 5 == 0:
+                    s.synchronize()
+                    if not np.array_equal(g.to_host(d), wants[t]):
+                        errors.append(("forward", t, it))
+                g.GPU_INTT_Inplace(d, d_inv, mods, ci, batch, mc)
+            s.synchronize()
+            if not np.array_equal(g.to_host(d), xs[t]):
+                errors.append(("round trip", t))
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    torch.cuda.synchronize()
+    for th in threads:
+        th.start()
+    # meanwhile, another stack from the main thread (default stream)
+    c5 = MergeCase(g, 64, 13, O.X_N_minus)
+    x5 = c5.random(4, 98900)
+    for _ in range(10):
+        assert np.array_equal(c5.gpu_forward(x5), c5.P.merge_ntt(x5, c5.oprm))
+    for th in threads:
+        th.join()
+    assert not errors, errors
