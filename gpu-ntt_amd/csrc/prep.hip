@@ -122,6 +122,11 @@ namespace gpuntt
                         w61 = true;
                     if (sizeof(T) == 8 && static_cast<unsigned long long>(md.value) > 0xffffffffffffffffull / 31)
                         over31 = true;
+                    // normalisation constants of modulus i (one 64-bit division each): one LANE per modulus instead of a
+                    // serial loop in thread 0 (it matters for long stacks only: an 8-prime preparation stays at 9.8 us, which
+                    // is launch + modulus load -> reciprocal -> barrier -> table load -> store, a chain of latencies)
+                    if (blockIdx.x == 0 && norm_arr != nullptr && go_flag != nullptr)
+                        norm_arr[i] = lazy::make_norm_const(md.value, md.bit);
                 }
                 const int any_bad = __syncthreads_or(bad ? 1 : 0), any62 = __syncthreads_or(w62 ? 1 : 0),
                           any61 = __syncthreads_or(w61 ? 1 : 0), any_over31 = __syncthreads_or(over31 ? 1 : 0);
@@ -134,12 +139,6 @@ namespace gpuntt
                 perm_tile_log = 12;
             if (gid == 0 && go_flag != nullptr)
             {
-                if (norm_arr != nullptr)
-                    for (int i = 0; i < mod_count; i++)
-                    {
-                        const Modulus<T> md = mods[mod_order != nullptr ? mod_order[i] : i];
-                        norm_arr[i] = lazy::make_norm_const(md.value, md.bit);
-                    }
                 *go_flag = state;
                 // host-mapped word (or nullptr): what the host predicts the NEXT call of this stack from (RnsGuess)
                 if (host_state != nullptr)
