@@ -56,11 +56,16 @@ namespace gpuntt
             }
             if (n <= 12)
                 return 12;
-            // 32-bit ring 2^13, a handful of polynomials: a 8192-coefficient tile of its own instead of half of a
-            // 16384-coefficient one (batch 1: 12.7 us against 12.0 us for the ring TWICE its size; the
-            // kernel is the one the one-launch 4-step of this ring runs on)
-            if (n == 13 && polys != 0 && polys <= lazy_u32_small_batch())
-                return 13;
+            // 32-bit ring 2^13: a 8192-coefficient tile of its own instead of half of a 16384-coefficient one -- equal or
+            // faster at every batch size (tools/ab_u32_ring13.py, round 4: batch 16 10.6 vs 12.2 us, 8192 inverse 0.137 vs
+            // 0.146 ms, 16384 0.265 vs 0.282 ms; batch 1 was slower than the ring TWICE its size).  The
+            // kernel is the one the one-launch 4-step of this ring runs on.  Option u32_ring13_batch = N restricts it to
+            // calls of at most N polynomials (0: never); polys = 0 asks "for any batch" (eligibility checks).
+            {
+                const unsigned long long small = lazy_u32_small_batch();
+                if (n == 13 && small != 0 && (polys == 0 ? small >= 0x7fffffffull : polys <= small))
+                    return 13;
+            }
             if (n <= 14)
                 return 14;
             const int forced = lazy_u32_tile_override();

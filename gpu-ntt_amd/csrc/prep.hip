@@ -538,7 +538,7 @@ namespace gpuntt
                 std::atomic<int> reverse{1};    // consecutive passes walk the batch in opposite directions
                 std::atomic<int> big_tiles{14}; // largest 64-bit ring done in one big tile
                 std::atomic<int> u32_tile{0};   // 12 | 14: 32-bit tile above 2^14
-                std::atomic<int> u32_ring13_batch{16}; // 32-bit ring 2^13: calls of at most this many polynomials take the 8192 tile
+                std::atomic<int> u32_ring13_batch{0x7fffffff}; // 32-bit ring 2^13: calls of at most this many polynomials take the 8192 tile
                 std::atomic<int> no_scratch{0}; // test hook: behave as if the twiddle scratch could not be allocated
                 std::atomic<int> validate_4step{0}; // GPU_4STEP_NTT: spot-check the caller's n2 / W tables against the derived powers
                 std::atomic<int> rns_predict{1}; // drop-in RNS calls: enqueue only the lazy family the stack needed last time
@@ -592,7 +592,7 @@ namespace gpuntt
             }
             else if (k == "u32_ring13_batch")
             {
-                if (!is_num || lv < 0 || lv > 1000000)
+                if (!is_num || lv < 0 || lv > 0x7fffffffl)
                     return false;
                 g_opt.u32_ring13_batch = iv;
             }

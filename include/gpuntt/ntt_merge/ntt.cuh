@@ -204,7 +204,8 @@ namespace gpuntt
     //   reverse        0 | 1     consecutive passes walk the batch in opposite directions (default 1)
     //   u64_big_tiles  0|13|14   largest 64-bit ring transformed inside one big tile (default 14)
     //   u32_tile       0|12|14   32-bit tile size above 2^14 (default 0: built-in choice)
-    //   u32_ring13_batch  n      32-bit ring 2^13: calls of at most n polynomials run on a 8192-coefficient tile (default 16; 0: never)
+    //   u32_ring13_batch  n      32-bit ring 2^13: calls of at most n polynomials run on a 8192-coefficient tile of their own
+    //                            (default 2147483647 = always; 0: never, the ring shares a 16384-coefficient tile)
     //   no_scratch     0 | 1     test hook: the drop-in calls behave as if their twiddle scratch could not be allocated
     //                            (they run on the generic kernels, which need none)
     //   validate_4step_tables 0 | 1   GPU_4STEP_NTT / FourStepPlan: spot-check the caller's n2 / W tables against the powers

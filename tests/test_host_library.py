@@ -156,7 +156,7 @@ def test_options_replace_environment_switches(g):
                         ("u32_tile", "12"), ("u32_tile", "0"), ("no_scratch", "1"), ("no_scratch", "0")):
         g.set_option(name, value)
     for name, value in (("validate_4step_tables", "1"), ("validate_4step_tables", "0"), ("rns_predict", "0"),
-                        ("rns_predict", "1"), ("u32_ring13_batch", "0"), ("u32_ring13_batch", "16")):
+                        ("rns_predict", "1"), ("u32_ring13_batch", "0"), ("u32_ring13_batch", "2147483647")):
         g.set_option(name, value)
     # unknown names, and values outside the documented sets, are refused -- never silently mapped to a default
     for name, value in (("path", "sideways"), ("no_such_option", "1"), ("u64_big_tiles", "abc"), ("contig_k", "7"),
