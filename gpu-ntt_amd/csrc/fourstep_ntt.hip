@@ -34,9 +34,13 @@ namespace gpuntt
         template <typename T>
         __global__ __launch_bounds__(256) void transpose_batch(const T* __restrict__ in,
                                                               T* __restrict__ out, int row, int col,
-                                                              unsigned long long poly_elems)
+                                                              unsigned long long poly_elems,
+                                                              const unsigned* __restrict__ skip_flag)
         {
             __shared__ T tile[32][33];
+            // behind the fast natural-order kernels: "return unless the table check handed the call to the generic kernels"
+            if (skip_flag != nullptr && *skip_flag != GO_GENERIC)
+                return;
             const unsigned long long base = static_cast<unsigned long long>(blockIdx.z) * poly_elems;
             const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // 32 x 8
             const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
@@ -61,7 +65,8 @@ namespace gpuntt
     namespace
     {
         template <typename T>
-        void transpose_on(T* in, T* out, int row, int col, int n_power, int batch_size, hipStream_t stream)
+        void transpose_on(T* in, T* out, int row, int col, int n_power, int batch_size, hipStream_t stream,
+                          const unsigned* skip_flag = nullptr)
         {
             if (batch_size <= 0 || row <= 0 || col <= 0)
                 return;
@@ -72,7 +77,7 @@ namespace gpuntt
                 const dim3 grid((col + 31) / 32, (row + 31) / 32, part);
                 const unsigned long long off = static_cast<unsigned long long>(done) << n_power;
                 hipLaunchKernelGGL((kern::transpose_batch<T>), grid, dim3(256), 0, stream, in + off, out + off, row,
-                                   col, 1ull << n_power);
+                                   col, 1ull << n_power, skip_flag);
                 GPUNTT_HIP_CHECK(hipGetLastError());
             }
         }
@@ -171,6 +176,24 @@ namespace gpuntt
                               // (fixed at PLAN_PREPARE: the u64_big_tiles option may change before execute())
         };
 
+        // bytes of the drop-in calls' scratch: pairs (n1 table | W | n2 table | n^-1), go-flag (16 B), normalisation constants
+        template <typename T> inline size_t fourstep_ws_bytes(int log_n1, int log_n2)
+        {
+            const size_t pairs = (size_t(1) << log_n1) + (size_t(1) << (log_n1 + log_n2)) + (size_t(1) << log_n2) + 2;
+            return sizeof(lazy::Tw<T>) * pairs + 16 + sizeof(lazy::NormConst);
+        }
+        // the veto word of a drop-in 4-step call on `stream` (lazy_launch.hpp: FourStepVeto); word == nullptr when the
+        // fast path cannot run anyway (no scratch, option path = generic)
+        template <typename T> inline host::FourStepVeto fourstep_veto(int log_n1, int log_n2, hipStream_t stream)
+        {
+            host::FourStepVeto v;
+            if (host::forced_path() == 1 || host::lazy_workspace(stream, fourstep_ws_bytes<T>(log_n1, log_n2), true) == nullptr)
+                return v;
+            host::lazy_workspace_veto(stream, &v.word, &v.epoch);
+            v.check = host::check_4step_tables();
+            return v;
+        }
+
         // fast path: single modulus with lazy headroom.  Workspace layout (Shoup pairs):
         //   [0, n1)  unused | [n1, n1 + N)  the ring's Merge table | [.., + n2)  unused  (layout of rounds 1-3 kept)
         // mods_dev != nullptr: the RNS overload with ONE modulus (how the reference's own example calls
@@ -183,7 +206,8 @@ namespace gpuntt
                                const Modulus<T>& mod, T ninv, int n_power, int log_n1, int log_n2,
                                int batch_size, hipStream_t stream, const Modulus<T>* mods_dev = nullptr,
                                const T* ninv_dev = nullptr, const unsigned** go_flag_out = nullptr,
-                               const PlanUse<T>& plan = PlanUse<T>(), int dev_family = 0, unsigned* host_state = nullptr)
+                               const PlanUse<T>& plan = PlanUse<T>(), int dev_family = 0, unsigned* host_state = nullptr,
+                               const host::FourStepVeto& veto = host::FourStepVeto())
         {
             using TW = lazy::Tw<T>;
             if (plan.mode != PLAN_NONE && mods_dev != nullptr)
@@ -210,17 +234,12 @@ namespace gpuntt
                 return false;
             if (host::forced_path() == 1)
                 return false;
-            // table contract (ntt_4step.cuh): the plans below derive every twiddle from n1_table and one row of W
-            if (do_prep && host::validate_4step_tables())
-                host::validate_fourstep_tables_or_throw<T>(n1_table, n2_table, w_table, log_n1, log_n2, INV, mod.value, mods_dev,
-                                                           stream);
             const size_t n1 = size_t(1) << log_n1, n2 = size_t(1) << log_n2, n = size_t(1) << n_power;
             // pairs: n1 table | W | n2 table | n^-1 ; then go-flag (16 B) and the normalisation constants
             const size_t pairs = n1 + n + n2 + 2;
             auto* ws = plan.mode != PLAN_NONE
                            ? plan.ws
-                           : static_cast<TW*>(
-                                 host::lazy_workspace(stream, sizeof(TW) * pairs + 16 + sizeof(lazy::NormConst), true));
+                           : static_cast<TW*>(host::lazy_workspace(stream, fourstep_ws_bytes<T>(log_n1, log_n2), true));
             if (ws == nullptr)
                 return false; // no device memory for the scratch: the generic kernels need none
             // (the n1 / n2 regions held the stage tables of the two-phase W form of rounds 1-3; every plan now reads the
@@ -228,7 +247,11 @@ namespace gpuntt
             TW* ws_w = ws + n1;
             TW* ws_ninv = ws + n1 + n + n2;
             unsigned char* tail = reinterpret_cast<unsigned char*>(ws + pairs);
-            unsigned* go_flag = mods_dev ? reinterpret_cast<unsigned*>(tail) : nullptr;
+            // the call's go-flag: the state half of its veto word (the preparation kernel publishes the state there and
+            // checks the caller's tables, prep.hip), else -- device-side modulus, no veto -- a word of the workspace tail
+            unsigned* go_flag = veto.word != nullptr ? veto.flag() : (mods_dev ? reinterpret_cast<unsigned*>(tail) : nullptr);
+            // host-side modulus: the kernel families are the host's choice, the flag can only take the call away
+            const unsigned vf = (go_flag != nullptr && mods_dev == nullptr) ? static_cast<unsigned>(kern::F_VETO_ONLY) : 0u;
             auto* norm_arr = mods_dev ? reinterpret_cast<lazy::NormConst*>(tail + 16) : nullptr;
             // Rings that fit one tile (2^12 .. 2^14): the 4-step transform is the Merge transform of the ring with its
             // natural-order side transposed, so ONE contiguous pass does it -- Merge table rebuilt from the caller's
@@ -244,7 +267,7 @@ namespace gpuntt
                     host::launch_prep_merge_from_fourstep<T>(n1_table, w_table, ws_w, log_n1, log_n2,
                                                              (n_power >= small_tl) ? small_tl : 0, INV, INV, mod.value, ninv,
                                                              mods_dev, (INV && mods_dev) ? ninv_dev : nullptr, ws_ninv, go_flag,
-                                                             norm_arr, stream, host_state);
+                                                             norm_arr, stream, host_state, veto, n2_table);
                 if (go_flag_out != nullptr)
                     *go_flag_out = go_flag;
                 if (plan.mode == PLAN_PREPARE || prep_only)
@@ -269,6 +292,7 @@ namespace gpuntt
                 s.n = n_power;
                 s.poly_shift = n_power;
                 s.mod_count = 1;
+                s.flags = vf;
                 if constexpr (sizeof(T) == 8)
                 {
                     if (lim == 8)
@@ -298,7 +322,7 @@ namespace gpuntt
                     if (do_prep)
                         host::launch_prep_merge_from_fourstep<T>(n1_table, w_table, ws_w, log_n1, log_n2, tlf, false, false,
                                                                  mod.value, T(0), mods_dev, nullptr, nullptr, go_flag,
-                                                                 norm_arr, stream, host_state);
+                                                                 norm_arr, stream, host_state, veto, n2_table);
                     if (go_flag_out != nullptr)
                         *go_flag_out = go_flag;
                     if (plan.mode == PLAN_PREPARE || prep_only)
@@ -321,7 +345,7 @@ namespace gpuntt
                     f.p_lo = n_power - k1;
                     f.poly_shift = n_power;
                     f.mod_count = 1;
-                    f.flags = host::lazy_order_flags();
+                    f.flags = host::lazy_order_flags() | vf;
                     {
                         // consecutive sweeps walk the batch in opposite directions, the LAST one forwards
                         const int pn = n_power - k1;
@@ -342,7 +366,7 @@ namespace gpuntt
                         host::launch_fourstep_first_lazy<T>(k1, f, stream);
                     kern::LazyArgsT<T> r = f;
                     r.in = out;
-                    r.flags = host::lazy_order_flags();
+                    r.flags = host::lazy_order_flags() | vf;
                     r.lim = lim;
                     if constexpr (sizeof(T) == 8)
                         if (lim == 0 && mods_dev == nullptr && host::lazy_lim31_enabled() && host::lazy_lim31_modulus(mod.value))
@@ -370,7 +394,7 @@ namespace gpuntt
                     if (do_prep)
                         host::launch_prep_merge_from_fourstep<T>(n1_table, w_table, ws_w, log_n1, log_n2, tli, true, true,
                                                                  mod.value, ninv, mods_dev, mods_dev ? ninv_dev : nullptr,
-                                                                 ws_ninv, go_flag, norm_arr, stream, host_state);
+                                                                 ws_ninv, go_flag, norm_arr, stream, host_state, veto, n2_table);
                     if (go_flag_out != nullptr)
                         *go_flag_out = go_flag;
                     if (plan.mode == PLAN_PREPARE || prep_only)
@@ -397,7 +421,7 @@ namespace gpuntt
                     f.mod_count = 1;
                     // from 2^20 the per-lane twiddles of the pass are tens of MiB per polynomial: poly-minor block order
                     f.batch = (n_power >= 20 && batch_size >= 2) ? batch_size : 0;
-                    f.flags = host::lazy_order_flags();
+                    f.flags = host::lazy_order_flags() | vf;
                     if (rev && ((passes - 1) & 1) != 0) // the last sweep walks the batch forwards, the one before it backwards, ...
                         f.flags |= kern::F_REVERSE;
                     bool wide32 = false;
@@ -431,7 +455,7 @@ namespace gpuntt
                         r.ninv_arr = ws_ninv;
                     if (rows512)
                     {
-                        r.flags = host::lazy_order_flags();
+                        r.flags = host::lazy_order_flags() | vf;
                         if constexpr (sizeof(T) == 4)
                         {
                             if (wide32)
@@ -457,7 +481,7 @@ namespace gpuntt
                         kern::LazyArgsT<T> x = r;
                         const host::Pass& p = (i == 1) ? pa : pb;
                         x.p_lo = p.p_lo;
-                        x.flags = host::lazy_order_flags();
+                        x.flags = host::lazy_order_flags() | vf;
                         if (rev && ((passes - 1 - i) & 1) != 0)
                             x.flags |= kern::F_REVERSE;
                         const bool last = (i == passes - 1);
@@ -525,10 +549,10 @@ namespace gpuntt
         bool fourstep_natural_forward_lazy(T* in, T* out, const T* n1_table, const T* n2_table,
                                            const T* w_table, const Modulus<T>& mod, int n_power, int log_n1,
                                            int log_n2, int batch_size, hipStream_t stream,
-                                           const PlanUse<T>& plan = PlanUse<T>())
+                                           const PlanUse<T>& plan = PlanUse<T>(),
+                                           const host::FourStepVeto& veto = host::FourStepVeto())
         {
             using TW = lazy::Tw<T>;
-            (void) n2_table;
             // 61- / 62-bit moduli (64-bit words): the same sweeps on the 4 q kernels (round 4; Barrett kernels between two
             // transposes before)
             if (!host::modulus_fast<T>(mod))
@@ -536,13 +560,10 @@ namespace gpuntt
             const bool wide = host::modulus_lim<T>(mod) != 0;
             if (host::forced_path() == 1)
                 return false;
-            if (plan.mode != PLAN_EXECUTE && host::validate_4step_tables())
-                host::validate_fourstep_tables_or_throw<T>(n1_table, n2_table, w_table, log_n1, log_n2, false, mod.value, nullptr,
-                                                           stream);
-            const size_t n1 = size_t(1) << log_n1, n2 = size_t(1) << log_n2, n = size_t(1) << n_power;
+            const size_t n1 = size_t(1) << log_n1;
             auto* ws = plan.mode != PLAN_NONE
                            ? plan.ws
-                           : static_cast<TW*>(host::lazy_workspace(stream, sizeof(TW) * (n1 + n + n2 + 2), true));
+                           : static_cast<TW*>(host::lazy_workspace(stream, fourstep_ws_bytes<T>(log_n1, log_n2), true));
             if (ws == nullptr)
                 return false; // no device memory for the scratch: the generic kernels need none
             TW* ws_merge = ws + n1; // the W region of the workspace holds the ring's Merge table
@@ -555,12 +576,18 @@ namespace gpuntt
                 small_tl = 0; // the 4 q kernels exist for 4096-coefficient tiles only
             if (plan.mode != PLAN_EXECUTE)
                 host::launch_prep_merge_from_fourstep<T>(n1_table, w_table, ws_merge, log_n1, log_n2, small_tl, false, false,
-                                                         mod.value, T(0), nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+                                                         mod.value, T(0), nullptr, nullptr, nullptr, nullptr, nullptr, stream,
+                                                         nullptr, veto, n2_table);
             if (plan.mode == PLAN_PREPARE)
                 return true;
 
             kern::LazyArgsT<T> a{};
             natural_args<T>(a, ws_merge, mod, n_power, log_n1, log_n2, batch_size);
+            if (veto.word != nullptr && plan.mode == PLAN_NONE)
+            {
+                a.go_flag = veto.flag();
+                a.flags |= kern::F_VETO_ONLY;
+            }
             if (small_tl != 0)
             {
                 a.in = in;
@@ -611,22 +638,19 @@ namespace gpuntt
         bool fourstep_natural_inverse_lazy(T* in, T* out, const T* n1_table, const T* n2_table,
                                            const T* w_table, const Modulus<T>& mod, T ninv, int n_power,
                                            int log_n1, int log_n2, int batch_size, hipStream_t stream,
-                                           const PlanUse<T>& plan = PlanUse<T>())
+                                           const PlanUse<T>& plan = PlanUse<T>(),
+                                           const host::FourStepVeto& veto = host::FourStepVeto())
         {
             using TW = lazy::Tw<T>;
-            (void) n2_table;
             if (!host::modulus_fast<T>(mod) || ninv >= mod.value)
                 return false;
             const bool wide = host::modulus_lim<T>(mod) != 0; // 61- / 62-bit moduli: the 4 q kernels
             if (host::forced_path() == 1)
                 return false;
-            if (plan.mode != PLAN_EXECUTE && host::validate_4step_tables())
-                host::validate_fourstep_tables_or_throw<T>(n1_table, n2_table, w_table, log_n1, log_n2, true, mod.value, nullptr,
-                                                           stream);
-            const size_t n1 = size_t(1) << log_n1, n2 = size_t(1) << log_n2, n = size_t(1) << n_power;
+            const size_t n1 = size_t(1) << log_n1;
             auto* ws = plan.mode != PLAN_NONE
                            ? plan.ws
-                           : static_cast<TW*>(host::lazy_workspace(stream, sizeof(TW) * (n1 + n + n2 + 2), true));
+                           : static_cast<TW*>(host::lazy_workspace(stream, fourstep_ws_bytes<T>(log_n1, log_n2), true));
             if (ws == nullptr)
                 return false; // no device memory for the scratch: the generic kernels need none
             TW* ws_merge = ws + n1;
@@ -638,12 +662,18 @@ namespace gpuntt
             // inverse Merge table of the ring, N^-1 folded into the single twiddle of the final stage (slot 1)
             if (plan.mode != PLAN_EXECUTE)
                 host::launch_prep_merge_from_fourstep<T>(n1_table, w_table, ws_merge, log_n1, log_n2, small_tl, true, true,
-                                                         mod.value, ninv, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+                                                         mod.value, ninv, nullptr, nullptr, nullptr, nullptr, nullptr, stream,
+                                                         nullptr, veto, n2_table);
             if (plan.mode == PLAN_PREPARE)
                 return true;
 
             kern::LazyArgsT<T> a{};
             natural_args<T>(a, ws_merge, mod, n_power, log_n1, log_n2, batch_size);
+            if (veto.word != nullptr && plan.mode == PLAN_NONE)
+            {
+                a.go_flag = veto.flag();
+                a.flags |= kern::F_VETO_ONLY;
+            }
             if (small_tl != 0)
             {
                 a.in = in;
@@ -723,16 +753,19 @@ namespace gpuntt
             else if (mods != nullptr && mod_count == 1)
             {
                 // one device-side modulus: the lazy family this modulus needed last time (host::RnsGuess) -- or every family
-                // -- and the generic kernels behind the go-flag
+                // -- and the generic kernels behind the go-flag.  The flag is the call's veto word: the preparation kernel
+                // also checks the caller's tables and hands the call to the generic kernels when they are not the tables of
+                // one root (prep.hip)
+                const host::FourStepVeto veto = fourstep_veto<T>(l1, l2, stream);
                 guess = host::rns_guess(mods, 1, static_cast<int>(sizeof(T)) | 0x40, ntt_type == INVERSE); // (0x40: the 4-step entry keeps its own slot)
                 auto enqueue = [&](int family, const unsigned** flag_out) {
                     if (ntt_type == FORWARD)
                         return fourstep_run_lazy<T, false>(in, out, n1_table, n2_table, w_table, Modulus<T>(), T(0), n_power, l1, l2,
                                                            batch_size, stream, mods, ninv_arr, flag_out, PlanUse<T>(), family,
-                                                           guess.state_out);
+                                                           guess.state_out, veto);
                     return fourstep_run_lazy<T, true>(in, out, n1_table, n2_table, w_table, Modulus<T>(), T(0), n_power, l1, l2,
                                                       batch_size, stream, mods, ninv_arr, flag_out, PlanUse<T>(), family,
-                                                      guess.state_out);
+                                                      guess.state_out, veto);
                 };
                 const bool only_default = !guess.all_families && guess.state == kern::GO_LAZY;
                 // the first enqueue prepares the table and publishes the flag; with it the default family unless another
@@ -750,15 +783,20 @@ namespace gpuntt
                 return; // test hook (path = fast-strict): no generic shadow launches -- the lazy families must own the call
             if (mods == nullptr)
             {
+                // host-side modulus: the fast kernels, and -- unless option check_4step_tables is off -- the generic
+                // kernels behind the veto word, which run only when the table check took the call away from them
+                const host::FourStepVeto veto = fourstep_veto<T>(l1, l2, stream);
                 const bool done =
                     (ntt_type == FORWARD)
-                        ? fourstep_run_lazy<T, false>(in, out, n1_table, n2_table, w_table, mod, ninv, n_power,
-                                                      l1, l2, batch_size, stream)
-                        : fourstep_run_lazy<T, true>(in, out, n1_table, n2_table, w_table, mod, ninv, n_power,
-                                                     l1, l2, batch_size, stream);
+                        ? fourstep_run_lazy<T, false>(in, out, n1_table, n2_table, w_table, mod, ninv, n_power, l1, l2, batch_size,
+                                                      stream, nullptr, nullptr, nullptr, PlanUse<T>(), 0, nullptr, veto)
+                        : fourstep_run_lazy<T, true>(in, out, n1_table, n2_table, w_table, mod, ninv, n_power, l1, l2, batch_size,
+                                                     stream, nullptr, nullptr, nullptr, PlanUse<T>(), 0, nullptr, veto);
+                if (done && (!veto.check || host::forced_path() == 3))
+                    return; // (fast-strict: test hook, no generic shadow launches)
                 if (done)
-                    return;
-                if (host::forced_path() == 3) // test hook, like the Merge entry points
+                    skip_flag = veto.flag(); // all families = "return unless the state is GO_GENERIC"
+                else if (host::forced_path() == 3) // test hook, like the Merge entry points
                     throw std::invalid_argument("fast path unavailable for this call (path = fast-strict)");
             }
             // behind lazy families: "return if one of them owns the call" (merge_kernels.hpp: PassArgs::skip_value)
@@ -830,27 +868,31 @@ namespace gpuntt
         if ((static_cast<unsigned long long>(batch_size) << cfg.n_power) >> kern::TL > 0x7fffffffull)
             throw std::invalid_argument("batch_size * N too large for one launch");
         const int n1 = 1 << l1, n2 = 1 << l2;
-        if (cfg.ntt_type == FORWARD)
-        {
-            if (fourstep_natural_forward_lazy<T>(device_in, device_out, n1_root_of_unity_table,
-                                                 n2_root_of_unity_table, W_root_of_unity_table, modulus,
-                                                 cfg.n_power, l1, l2, batch_size, cfg.stream))
-                return;
-            transpose_on<T>(device_in, device_out, n1, n2, cfg.n_power, batch_size, cfg.stream);
-        }
+        // the fast sweeps, and behind the call's veto word the reference examples' own composition on the generic kernels
+        // (every launch of it returns at once unless the table check handed the call over; prep.hip)
+        const host::FourStepVeto veto = fourstep_veto<T>(l1, l2, cfg.stream);
+        const bool fwd = (cfg.ntt_type == FORWARD);
+        const bool done = fwd ? fourstep_natural_forward_lazy<T>(device_in, device_out, n1_root_of_unity_table,
+                                                                 n2_root_of_unity_table, W_root_of_unity_table, modulus,
+                                                                 cfg.n_power, l1, l2, batch_size, cfg.stream, PlanUse<T>(), veto)
+                              : fourstep_natural_inverse_lazy<T>(device_in, device_out, n1_root_of_unity_table,
+                                                                 n2_root_of_unity_table, W_root_of_unity_table, modulus,
+                                                                 cfg.mod_inverse, cfg.n_power, l1, l2, batch_size, cfg.stream,
+                                                                 PlanUse<T>(), veto);
+        if (done && (!veto.check || host::forced_path() == 3))
+            return;
+        const unsigned* skip = done ? veto.flag() : nullptr;
+        // forward: GPU_Transpose(in, out, n1, n2); inverse: NTT_4STEP_CPU::intt_first_transpose, flat[i*n2+j] = x[i + j*n1]
+        transpose_on<T>(device_in, device_out, fwd ? n1 : n2, fwd ? n2 : n1, cfg.n_power, batch_size, cfg.stream, skip);
+        if (fwd)
+            fourstep_run<T, false>(device_out, device_in, n1_root_of_unity_table, n2_root_of_unity_table, W_root_of_unity_table,
+                                   nullptr, modulus, 1, nullptr, cfg.mod_inverse, cfg.n_power, l1, l2, batch_size, cfg.stream,
+                                   skip, 0u);
         else
-        {
-            if (fourstep_natural_inverse_lazy<T>(device_in, device_out, n1_root_of_unity_table,
-                                                 n2_root_of_unity_table, W_root_of_unity_table, modulus,
-                                                 cfg.mod_inverse, cfg.n_power, l1, l2, batch_size, cfg.stream))
-                return;
-            // NTT_4STEP_CPU::intt_first_transpose: flat[i*n2+j] = x[i + j*n1]
-            transpose_on<T>(device_in, device_out, n2, n1, cfg.n_power, batch_size, cfg.stream);
-        }
-        fourstep_dispatch<T>(device_out, device_in, n1_root_of_unity_table, n2_root_of_unity_table,
-                             W_root_of_unity_table, nullptr, modulus, 1, nullptr, cfg.mod_inverse, cfg.n_power,
-                             cfg.ntt_type, batch_size, cfg.stream);
-        transpose_on<T>(device_in, device_out, n1, n2, cfg.n_power, batch_size, cfg.stream);
+            fourstep_run<T, true>(device_out, device_in, n1_root_of_unity_table, n2_root_of_unity_table, W_root_of_unity_table,
+                                  nullptr, modulus, 1, nullptr, cfg.mod_inverse, cfg.n_power, l1, l2, batch_size, cfg.stream,
+                                  skip, 0u);
+        transpose_on<T>(device_in, device_out, n1, n2, cfg.n_power, batch_size, cfg.stream, skip);
     }
 
     // ------------------------------------------------------------------ FourStepPlan ----
@@ -921,24 +963,36 @@ namespace gpuntt
                 host::fourstep_small_tile<T>(p->n, p->inverse, static_cast<unsigned long long>(batch_hint), natural_order);
             if (p->inverse && !natural_order)
                 p->use.inv_tile = host::fourstep_inv_tile<T>(p->n, host::modulus_lim<T>(modulus));
+            // the plan's own veto word: the head of the (unused) n1 region of its workspace.  The preparation kernel checks
+            // the caller's three tables once, here (option check_4step_tables); tables that are not those of one root make
+            // the plan a generic one -- execute() then runs the element-by-element kernels, like the drop-in call would
+            host::FourStepVeto veto;
+            veto.word = reinterpret_cast<unsigned long long*>(p->use.ws);
+            veto.check = host::check_4step_tables();
+            GPUNTT_HIP_CHECK(hipMemsetAsync(veto.word, 0xff, 16, cfg.stream));
             // the eligibility checks of the fast paths decide (modulus width, n^-1 canonical, option "path")
             if (natural_order)
                 p->fast = p->inverse ? fourstep_natural_inverse_lazy<T>(nullptr, nullptr, p->n1_table, p->n2_table,
                                                                         p->w_table, p->mod, p->ninv, p->n, l1, l2, 1,
-                                                                        cfg.stream, p->use)
+                                                                        cfg.stream, p->use, veto)
                                      : fourstep_natural_forward_lazy<T>(nullptr, nullptr, p->n1_table, p->n2_table,
                                                                         p->w_table, p->mod, p->n, l1, l2, 1, cfg.stream,
-                                                                        p->use);
+                                                                        p->use, veto);
             else
                 p->fast = p->inverse ? fourstep_run_lazy<T, true>(nullptr, nullptr, p->n1_table, p->n2_table, p->w_table,
                                                                   p->mod, p->ninv, p->n, l1, l2, 1, cfg.stream, nullptr,
-                                                                  nullptr, nullptr, p->use)
+                                                                  nullptr, nullptr, p->use, 0, nullptr, veto)
                                      : fourstep_run_lazy<T, false>(nullptr, nullptr, p->n1_table, p->n2_table,
                                                                    p->w_table, p->mod, p->ninv, p->n, l1, l2, 1,
-                                                                   cfg.stream, nullptr, nullptr, nullptr, p->use);
+                                                                   cfg.stream, nullptr, nullptr, nullptr, p->use, 0, nullptr,
+                                                                   veto);
             p->use.mode = PLAN_EXECUTE;
             // complete when the constructor returns: execute() may run on any stream (one host wait per plan)
+            unsigned long long verdict = 0;
+            GPUNTT_HIP_CHECK(hipMemcpyAsync(&verdict, veto.word, sizeof(verdict), hipMemcpyDeviceToHost, cfg.stream));
             GPUNTT_HIP_CHECK(hipStreamSynchronize(cfg.stream));
+            if (p->fast && static_cast<unsigned>(verdict) == kern::GO_GENERIC)
+                p->fast = false;
         }
         catch (...)
         {

@@ -74,14 +74,19 @@ namespace gpuntt
             return (n >= 20 && n <= 22) ? 14 : 12;
         }
 
-        // per-(device, stream) scratch for prepared twiddles; grows on demand, stream-ordered reuse.
-        // Inside a WorkspaceScope (every public entry point opens one) the calling thread keeps the
-        // buffer's lock until the scope ends, i.e. from the preparation launch to the last kernel launch
-        // of the call: two host threads on one stream can no longer interleave A.prep, B.prep, A.kernels.
+        // Library-owned scratch for the prepared twiddles of the drop-in calls: one chain of buffers per (device, stream)
+        // for eager calls, one per (device, stream, capture) for calls made while the stream is being captured into a
+        // hipGraph; stream-ordered reuse inside a chain.  A buffer is never freed or synchronised on before
+        // GPU_NTT_ReleaseWorkspaces(): growth allocates a new buffer and retires the old one, because kernels already
+        // enqueued -- or captured into a graph that is replayed later -- still read it (prep.hip).
+        // Inside a WorkspaceScope (every public entry point opens one) the calling thread keeps the chain's lock until
+        // the scope ends, i.e. from the preparation launch to the last kernel launch of the call: two host threads on
+        // one stream cannot interleave A.prep, B.prep, A.kernels.
         // or_null: nullptr instead of a HipException when the device has no memory left for the buffer (the entry
-        // points then run the generic kernels, which need no scratch).  The buffers are retained per (device, stream)
-        // until GPU_NTT_ReleaseWorkspaces().
+        // points then run the generic kernels, which need no scratch).
         void* lazy_workspace(hipStream_t stream, size_t bytes, bool or_null = false);
+        // veto word of the chain lazy_workspace(stream, ...) just served + a fresh epoch for it (4-step table check)
+        void lazy_workspace_veto(hipStream_t stream, unsigned long long** word, unsigned* epoch);
         struct WorkspaceScope
         {
             WorkspaceScope();
@@ -232,6 +237,18 @@ namespace gpuntt
         extern template void launch_fourstep_nat_first_inv_lazy<uint64_t, 0>(int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
         extern template void launch_fourstep_nat_first_inv_lazy<uint32_t, 0>(int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
         extern template void launch_fourstep_nat_first_inv_lazy<uint64_t, 4>(int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
+        // The veto word of a 4-step call (prep.hip: publish_state): the preparation kernel publishes the call's go-flag state
+        // through it and -- check -- verifies ALL of the caller's three tables against the one-root structure the fast
+        // path relies on; any mismatch publishes kern::GO_GENERIC, the fast kernels return and the element-by-element
+        // Barrett kernels behind them serve the call.  word == nullptr: no veto (option check_4step_tables = 0, plans
+        // after their construction).  The kernels read the low half of the word as their go-flag.
+        struct FourStepVeto
+        {
+            unsigned long long* word = nullptr;
+            unsigned epoch = 0;
+            bool check = false;
+            unsigned* flag() const { return reinterpret_cast<unsigned*>(word); } // little endian: the state half
+        };
         // Merge table of the 4-step ring (bit-reversed powers of its root), rebuilt from the caller's 4-step tables
         // straight into the Merge kernels' stage layout (prep.hip: prep_merge_from_fourstep)
         template <typename T>
@@ -239,28 +256,18 @@ namespace gpuntt
                                              int perm_tile_log, bool inverse, bool fold, T q, T ninv,
                                              const Modulus<T>* mods, const T* ninv_dev, lazy::Tw<T>* ws_ninv,
                                              unsigned* go_flag, lazy::NormConst* norm_arr, hipStream_t stream,
-                                             unsigned* host_state = nullptr);
+                                             unsigned* host_state = nullptr, const FourStepVeto& veto = FourStepVeto(),
+                                             const T* n2_table = nullptr);
         extern template void launch_prep_merge_from_fourstep<uint64_t>(const uint64_t*, const uint64_t*, lazy::Tw64*, int,
                                                                        int, int, bool, bool, uint64_t, uint64_t,
                                                                        const Modulus<uint64_t>*, const uint64_t*,
                                                                        lazy::Tw64*, unsigned*, lazy::NormConst*, hipStream_t,
-                                                                       unsigned*);
+                                                                       unsigned*, const FourStepVeto&, const uint64_t*);
         extern template void launch_prep_merge_from_fourstep<uint32_t>(const uint32_t*, const uint32_t*, lazy::Tw32*, int,
                                                                        int, int, bool, bool, uint32_t, uint32_t,
                                                                        const Modulus<uint32_t>*, const uint32_t*,
                                                                        lazy::Tw32*, unsigned*, lazy::NormConst*, hipStream_t,
-                                                                       unsigned*);
-        // option validate_4step_tables: one launch + one stream synchronisation; throws std::invalid_argument when the
-        // caller's tables are not the NTTParameters4Step tables of one root of order N (prep.hip)
-        template <typename T>
-        void validate_fourstep_tables_or_throw(const T* n1_table, const T* n2_table, const T* w_table, int log_n1, int log_n2,
-                                               bool inverse, T q, const Modulus<T>* mods, hipStream_t stream);
-        extern template void validate_fourstep_tables_or_throw<uint64_t>(const uint64_t*, const uint64_t*, const uint64_t*,
-                                                                         int, int, bool, uint64_t, const Modulus<uint64_t>*,
-                                                                         hipStream_t);
-        extern template void validate_fourstep_tables_or_throw<uint32_t>(const uint32_t*, const uint32_t*, const uint32_t*,
-                                                                         int, int, bool, uint32_t, const Modulus<uint32_t>*,
-                                                                         hipStream_t);
+                                                                       unsigned*, const FourStepVeto&, const uint32_t*);
         // host Shoup companion floor(w * 2^W / q)
         inline uint64_t shoup_host(uint64_t w, uint64_t q)
         {
@@ -307,7 +314,7 @@ namespace gpuntt
         int lazy_contig_k(int n);
 
         bool lazy_reverse_passes();
-        bool validate_4step_tables();     // option validate_4step_tables (default off)
+        bool check_4step_tables();        // option check_4step_tables (default on)
         // forward 4-step in Merge form: stages of the first pass (the one that reads the transposed input) -- the first
         // strided pass of the ring's Merge plan on tile `tl`, widened to log2 n1 where that is larger (5 .. 8)
         inline int fourstep_first_k(int n_power, int log_n1, int tl)

@@ -51,7 +51,9 @@ namespace gpuntt
             F_MULTI = 32u, // a tile may span polynomials with different moduli (RNS, N < tile)
             F_REVERSE = 128u, // fast kernels: walk the tiles from the last to the first (see run_transform_lazy)
             F_COLMOD = 64u, // PerCoefficient RNS: the modulus follows the COLUMN (flat & (2^n2_log - 1)) % mod_count
-            F_PLAIN_ORDER = 256u // fast kernels: poly-minor block order without the XCD grouping (GPUNTT_XCD_ORDER=0, A/B timing)
+            F_PLAIN_ORDER = 256u, // fast kernels: poly-minor block order without the XCD grouping (GPUNTT_XCD_ORDER=0, A/B timing)
+            F_VETO_ONLY = 512u // fast kernels: the go-flag only carries a veto (4-step calls with a host-side modulus: the
+                               // host picked the kernel families, the table check may still hand the call to the generic kernels)
         };
 
         template <typename T> struct PassArgs

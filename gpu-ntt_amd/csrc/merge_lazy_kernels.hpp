@@ -1153,11 +1153,16 @@ namespace gpuntt
         // GO_LAZY_31Q (forward Merge calls of 64-bit words only): every modulus of the stack has 31 q < 2^64 -- the 31 q
         // kernels (a range correction every fourth stage), what NTTPlan picks from host moduli for the same stack
         constexpr unsigned GO_GENERIC = 0u, GO_LAZY = 1u, GO_LAZY_8Q = 2u, GO_LAZY_4Q = 3u, GO_LAZY_31Q = 4u;
-        template <typename T, int LIM> __device__ __forceinline__ bool not_my_call(const unsigned* go_flag)
+        template <typename T, int LIM> __device__ __forceinline__ bool not_my_call(const unsigned* go_flag, unsigned flags = 0u)
         {
             constexpr unsigned mine = sizeof(T) != 8 ? GO_LAZY
                                       : (LIM == 4 ? GO_LAZY_4Q : (LIM == 8 ? GO_LAZY_8Q : (LIM == 31 ? GO_LAZY_31Q : GO_LAZY)));
-            return go_flag != nullptr && *go_flag != mine;
+            if (go_flag == nullptr)
+                return false;
+            const unsigned st = *go_flag;
+            // F_VETO_ONLY: the host chose this kernel (host-side modulus); only the table check of a 4-step call can
+            // still take the call away (GO_GENERIC)
+            return (flags & F_VETO_ONLY) ? (st == GO_GENERIC) : (st != mine);
         }
 
         // The 8 q and 4 q families of 64-bit words are enqueued behind EVERY drop-in RNS call as shadows of the default family
@@ -1220,7 +1225,7 @@ namespace gpuntt
 
             // RNS calls: the twiddle-prep kernel publishes which kernel family the stack of moduli needs (not_my_call);
             // the other families, launched alongside, return here
-            if (not_my_call<T, LIM>(a.go_flag))
+            if (not_my_call<T, LIM>(a.go_flag, a.flags))
                 return;
             for_each_block<WalksTiles<T, LIM>::value>(
                 static_cast<unsigned>((a.total + LTile<TLOG>::TILE - 1) >> TLOG), [&](unsigned bidx, unsigned nblk) {
@@ -1307,6 +1312,8 @@ namespace gpuntt
         __global__ __launch_bounds__(LTile<TLOG>::NT, (LOcc<TLOG, T>::WAVES)) void fourstep_nat_last_lazy(LazyArgsT<T> a)
         {
             __shared__ T lds[LTile<TLOG>::LDS_ELEMS_FST];
+            if (not_my_call<T, LIM>(a.go_flag, a.flags))
+                return;
             constexpr int RB = TLOG - K;
             const int rb_log = a.n2_log - RB;
             unsigned poly, tile;
@@ -1322,6 +1329,8 @@ namespace gpuntt
         __global__ __launch_bounds__(LTile<TLOG>::NT, (LOcc<TLOG, T>::WAVES)) void fourstep_nat_first_inv_lazy(LazyArgsT<T> a)
         {
             __shared__ T lds[LTile<TLOG>::LDS_ELEMS_FST];
+            if (not_my_call<T, LIM>(a.go_flag, a.flags))
+                return;
             constexpr int RB = TLOG - K;
             const int rb_log = a.n2_log - RB;
             unsigned poly, tile;
@@ -1337,7 +1346,7 @@ namespace gpuntt
         __global__ __launch_bounds__(LTile<12>::NT, (LOcc<12, T>::WAVES)) void fourstep_first_lazy(LazyArgsT<T> a)
         {
             __shared__ T lds[LTile<12>::LDS_ELEMS];
-            if (not_my_call<T, LIM>(a.go_flag))
+            if (not_my_call<T, LIM>(a.go_flag, a.flags))
                 return;
             T qv = a.q, qb = a.q_bit, qm = a.q_mu;
             if (a.mods != nullptr)
@@ -1368,7 +1377,7 @@ namespace gpuntt
         __global__ __launch_bounds__(LTile<TLOG>::NT, (LOcc<TLOG, T>::WAVES)) void fourstep_inv_first_lazy(LazyArgsT<T> a)
         {
             __shared__ T lds[LTile<TLOG>::LDS_ELEMS_FST];
-            if (not_my_call<T, LIM>(a.go_flag))
+            if (not_my_call<T, LIM>(a.go_flag, a.flags))
                 return;
             T qv = a.q, qb = a.q_bit, qm = a.q_mu;
             if (a.mods != nullptr)
@@ -1403,7 +1412,7 @@ namespace gpuntt
         {
             static_assert(K >= 12 && K == TLOG, "one-tile 4-step rings fill their tile: 32 x n2 with n2 >= 128");
             __shared__ T lds[LTile<TLOG>::LDS_ELEMS];
-            if (not_my_call<T, LIM>(a.go_flag))
+            if (not_my_call<T, LIM>(a.go_flag, a.flags))
                 return;
             T qv = a.q, qb = a.q_bit, qm = a.q_mu;
             if (a.mods != nullptr)

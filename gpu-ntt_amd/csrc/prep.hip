@@ -17,6 +17,7 @@
 #include <map>
 #include <tuple>
 #include <mutex>
+#include <stdexcept>
 #include <vector>
 
 #include "lazy_launch.hpp"
@@ -202,6 +203,117 @@ namespace gpuntt
             ws[dst] = lazy::Tw<T>{w, shoup_quotient_r<T>(w, q, rinv)};
         }
 
+        // a^e (mod q) by square and multiply (table check, plan construction)
+        template <typename T> __device__ __forceinline__ T powmod_r(T base, unsigned long long e, T q, T rinv)
+        {
+            T r = 1, b = base;
+            while (e != 0ull)
+            {
+                if (e & 1ull)
+                    r = mulmod_r<T>(r, b, q, rinv);
+                b = mulmod_r<T>(b, b, q, rinv);
+                e >>= 1;
+            }
+            return r;
+        }
+
+        // ---- table check of the 4-step entry points (on by default, no host involvement) ---------------------------------
+        // The fast 4-step path derives every twiddle from n1_table and ONE row of W (prep_merge_from_fourstep below) where
+        // the reference multiplies by W[address] element by element and runs the rows through n2_table
+        // (src/lib/ntt_4step/ntt_4step.cu:1049-1058, 776-779).  The two agree iff the three tables are the ones
+        // NTTParameters4Step generates for ONE root g of order N (src/lib/common/nttparameters.cu:356-444):
+        //   forward  W[r * n2 + j] = g^(brev(r, log n1) * j)      inverse  W[r * n2 + c] = g^(r * brev(c, log n2))
+        //   n1_table[i] = (g^n2)^brev(i, log n1 - 1)              n2_table[i] = (g^n1)^brev(i, log n2 - 1)
+        // Thread gid of the preparation kernel verifies entry gid of W (and of the small tables) with ONE modular product
+        // against its neighbours, which pins ALL N + n1/2 + n2/2 words:
+        //   a table t of bit-reversed powers (t[i] = b^brev(i, L)):  t[0] = 1,  t[2^k + i'] = t[i'] * t[2^k],
+        //       t[2^k] = t[2^(k+1)]^2,  t[2^(L-1)] = b                                          (brev_powers_ok)
+        //   forward W: column 1 is such a table (b = g: the entry that DEFINES g), row r is geometric with ratio W[r*n2 + 1];
+        //   inverse W: row 1 is such a table (L = log n2), column c is geometric with ratio W[n2 + c];
+        //   g^(N/2) = -1: the entry holding g^(N/4) squares to q - 1;   the bases g^n2, g^n1 of the small tables are W entries.
+        // A thread that finds a mismatch publishes kern::GO_GENERIC through the call's veto word (publish_state): the
+        // fast kernels of the call return, the element-by-element Barrett kernels enqueued behind them run -- whatever
+        // the tables say, like the reference, only slower.
+        __device__ __forceinline__ void publish_state(unsigned long long* word, unsigned epoch, unsigned state)
+        {
+            // smallest high half = latest call of the chain; within a call the smallest state wins (GO_GENERIC = 0)
+            atomicMin(word, (static_cast<unsigned long long>(~epoch) << 32) | state);
+        }
+        // t[i * stride], i < 2^L, are b^brev(i, L); `top` = b, or nullptr when t[2^(L-1)] itself defines b
+        template <typename T>
+        __device__ __forceinline__ bool brev_powers_ok(const T* __restrict__ t, unsigned long long stride, unsigned i, int L,
+                                                       const T* top, T q, T rinv)
+        {
+            const T x = t[i * stride];
+            if (x >= q)
+                return false;
+            if (i == 0u)
+                return x == static_cast<T>(1);
+            const int k = 31 - __clz(i);
+            const unsigned rest = i - (1u << k);
+            if (rest != 0u)
+            {
+                const T u = t[rest * stride], v = t[(static_cast<unsigned long long>(1u) << k) * stride];
+                return u < q && v < q && x == mulmod_r<T>(u, v, q, rinv);
+            }
+            if (k == L - 1)
+                return top == nullptr || x == *top;
+            const T y = t[(static_cast<unsigned long long>(2u) << k) * stride];
+            return y < q && x == mulmod_r<T>(y, y, q, rinv);
+        }
+        template <typename T>
+        __device__ __forceinline__ bool fourstep_tables_ok(const T* __restrict__ n1_table, const T* __restrict__ n2_table,
+                                                           const T* __restrict__ w, unsigned gid, int l1, int l2, int inverse,
+                                                           T q, T rinv)
+        {
+            const unsigned long long n2 = 1ull << l2;
+            const unsigned r = gid >> l2, c = gid & static_cast<unsigned>(n2 - 1ull);
+            const T x = w[gid];
+            bool ok = x < q;
+            if (!inverse)
+            {
+                if (c == 0u)
+                    ok = ok && x == static_cast<T>(1);
+                else if (c == 1u)
+                    ok = ok && brev_powers_ok<T>(w + 1, n2, r, l1, nullptr, q, rinv);
+                else
+                {
+                    const T u = w[gid - 1u], v = w[(static_cast<unsigned long long>(r) << l2) + 1u];
+                    ok = ok && u < q && v < q && x == mulmod_r<T>(u, v, q, rinv);
+                }
+            }
+            else
+            {
+                if (r == 0u)
+                    ok = ok && x == static_cast<T>(1);
+                else if (r == 1u)
+                    ok = ok && brev_powers_ok<T>(w + n2, 1ull, c, l2, nullptr, q, rinv);
+                else
+                {
+                    const T u = w[gid - n2], v = w[n2 + c];
+                    ok = ok && u < q && v < q && x == mulmod_r<T>(u, v, q, rinv);
+                }
+            }
+            if (gid == 0u)
+            {
+                // g^(N/4): forward row 1 has ratio g^(n1/2), entry n2/2; inverse row n1/2, column 1 (brev = n2/2)
+                const T h = inverse ? w[(n2 << (l1 - 1)) + 1ull] : w[n2 + (n2 >> 1)];
+                ok = ok && h < q && mulmod_r<T>(h, h, q, rinv) == q - 1;
+            }
+            // small tables: bases g^n2 and g^n1 are entries of W (forward: row 1 = powers of g^(n1/2); inverse: W[r*n2+c] = g^(r*brev(c)))
+            if (gid < (1u << (l1 - 1)))
+            {
+                const T* top = inverse ? (w + 2ull * n2 + 1ull) : (w + n2 + (2ull << (l2 - l1)));
+                ok = ok && *top < q && brev_powers_ok<T>(n1_table, 1ull, gid, l1 - 1, top, q, rinv);
+            }
+            if (gid < (1u << (l2 - 1)))
+            {
+                const T* top = inverse ? (w + n2 + (1ull << (l2 - 1 - l1))) : (w + n2 + 2ull);
+                ok = ok && *top < q && brev_powers_ok<T>(n2_table, 1ull, gid, l2 - 1, top, q, rinv);
+            }
+            return ok;
+        }
+
         // The 4-step transform IS the Merge transform of the same ring with one transposition on the natural-order
         // side (forward: GPU_4STEP_NTT(in) = MergeNTT(in read as the n2 x n1 transpose of x); inverse: the output is
         // stored transposed), so the Merge kernels can run it from a MERGE table of the ring -- bit-reversed powers of
@@ -212,16 +324,20 @@ namespace gpuntt
         //   inverse  Wrow(j) = W[n2 + brev(j, log n2)]       (W[r * n2 + c] = w^-(r * brev(c, log n2)))
         // (reference table generators: src/lib/common/nttparameters.cu:356-444).  fold: n^-1 into the single twiddle of
         // the final inverse stage (slot 1).  mods != nullptr: one device-side modulus, classified like prep_twiddles does for an RNS stack.
+        // veto != nullptr (drop-in calls, plan construction): the state goes out through the veto word, and with
+        // n2_table != nullptr every thread also checks its share of the caller's tables (fourstep_tables_ok).
         template <typename T>
         __global__ __launch_bounds__(256) void prep_merge_from_fourstep(
             const T* __restrict__ n1_table, const T* __restrict__ w_table, lazy::Tw<T>* __restrict__ ws, int log_n1,
             int log_n2, int perm_tile_log, int inverse, int fold, T q_single, T rinv_single, T ninv_single,
             const Modulus<T>* __restrict__ mods, const T* __restrict__ ninv_dev, lazy::Tw<T>* __restrict__ ws_ninv,
-            unsigned* __restrict__ go_flag, lazy::NormConst* __restrict__ norm_arr, unsigned* __restrict__ host_state)
+            unsigned* __restrict__ go_flag, lazy::NormConst* __restrict__ norm_arr, unsigned* __restrict__ host_state,
+            const T* __restrict__ n2_table, unsigned long long* __restrict__ veto, unsigned epoch)
         {
             const unsigned long long gid = blockIdx.x * 256ull + threadIdx.x;
             __shared__ T s_rinv;
             T q = q_single, rinv = rinv_single;
+            unsigned state = GO_LAZY; // host-side modulus: the host picked the kernels, the word only carries the veto
             if (mods != nullptr)
             {
                 const Modulus<T> md = mods[0];
@@ -232,11 +348,11 @@ namespace gpuntt
                 rinv = s_rinv;
                 // four-state go-flag, like prep_twiddles; a 61- / 62-bit modulus runs the 8 q / 4 q family on 4096-coefficient
                 // tiles, so the table takes that tile's permutation
-                const unsigned state = (md.value < 3 || md.bit > static_cast<T>(sizeof(T) == 8 ? 62 : lazy::Mod<T>::MAX_BIT))
-                                           ? GO_GENERIC
-                                           : ((sizeof(T) == 8 && md.bit == static_cast<T>(62))
-                                                  ? GO_LAZY_4Q
-                                                  : ((sizeof(T) == 8 && md.bit == static_cast<T>(61)) ? GO_LAZY_8Q : GO_LAZY));
+                state = (md.value < 3 || md.bit > static_cast<T>(sizeof(T) == 8 ? 62 : lazy::Mod<T>::MAX_BIT))
+                            ? GO_GENERIC
+                            : ((sizeof(T) == 8 && md.bit == static_cast<T>(62))
+                                   ? GO_LAZY_4Q
+                                   : ((sizeof(T) == 8 && md.bit == static_cast<T>(61)) ? GO_LAZY_8Q : GO_LAZY));
                 if ((state == GO_LAZY_8Q || state == GO_LAZY_4Q) && perm_tile_log > 12)
                     perm_tile_log = 12;
                 if (gid == 0)
@@ -249,12 +365,17 @@ namespace gpuntt
                         norm_arr[0] = lazy::make_norm_const(md.value, md.bit);
                 }
             }
+            if (gid == 0 && veto != nullptr)
+                publish_state(veto, epoch, state);
             const T ninv = (ninv_dev != nullptr) ? ninv_dev[0] : ninv_single;
             if (gid == 0 && ninv_dev != nullptr && ws_ninv != nullptr)
                 ws_ninv[0] = lazy::Tw<T>{ninv, shoup_quotient_r<T>(ninv, q, rinv)};
             const int n = log_n1 + log_n2;
             if (gid >= (1ull << n))
                 return;
+            if (veto != nullptr && n2_table != nullptr && state != GO_GENERIC &&
+                !fourstep_tables_ok<T>(n1_table, n2_table, w_table, static_cast<unsigned>(gid), log_n1, log_n2, inverse, q, rinv))
+                publish_state(veto, epoch, GO_GENERIC);
             const unsigned slot = static_cast<unsigned>(gid);
             if (slot == 0)
             {
@@ -286,92 +407,80 @@ namespace gpuntt
             ws[slot] = lazy::Tw<T>{w, shoup_quotient_r<T>(w, q, rinv)};
         }
 
-        // option validate_4step_tables: the fast 4-step path derives every twiddle from n1_table and ONE row of W (forward:
-        // row n1/2, inverse: row 1; prep_merge_from_fourstep above) where the reference multiplies by W[address] element
-        // by element and runs the rows through n2_table (src/lib/ntt_4step/ntt_4step.cu:1049-1058).  The results agree iff
-        // the tables are the ones NTTParameters4Step generates for ONE root w of order N (nttparameters.cu:356-444):
-        //   forward  W[r * n2 + j] = w^(brev(r, log n1) * j)      inverse  W[r * n2 + c] = w^(r * brev(c, log n2))
-        //   n2_table[i] = (w^n1)^brev(i, log n2 - 1)              n1_table[i] = (w^n2)^brev(i, log n1 - 1)
-        // This kernel takes w from the row the fast path reads (its entry with exponent 1), checks w^(N/2) = -1, and compares
-        // 128 pseudo-random W entries, 64 n2_table entries and up to 64 n1_table entries with the powers; *bad counts mismatches.
-        template <typename T> __device__ __forceinline__ T powmod_r(T base, unsigned long long e, T q, T rinv)
-        {
-            T r = 1, b = base;
-            while (e != 0ull)
-            {
-                if (e & 1ull)
-                    r = mulmod_r<T>(r, b, q, rinv);
-                b = mulmod_r<T>(b, b, q, rinv);
-                e >>= 1;
-            }
-            return r;
-        }
-        template <typename T>
-        __global__ __launch_bounds__(256) void validate_fourstep_tables(const T* __restrict__ n1_table,
-                                                                        const T* __restrict__ n2_table,
-                                                                        const T* __restrict__ w_table, int log_n1, int log_n2,
-                                                                        int inverse, T q_single,
-                                                                        const Modulus<T>* __restrict__ mods, unsigned seed,
-                                                                        unsigned* __restrict__ bad)
-        {
-            const T q = (mods != nullptr) ? mods[0].value : q_single;
-            if (q < 3 || (q >> (8 * sizeof(T) - 2)) != 0)
-                return; // outside the fast kernels' domain: the generic kernels read the caller's tables as they stand
-            const T rinv = recip_norm<T>(q);
-            const int n = log_n1 + log_n2;
-            const unsigned n1 = 1u << log_n1, n2 = 1u << log_n2;
-            const T w = inverse ? w_table[static_cast<unsigned long long>(n2) + (n2 >> 1)]
-                                : w_table[(static_cast<unsigned long long>(n2) << (log_n1 - 1)) + 1u];
-            const unsigned t = threadIdx.x;
-            // splitmix-style hash of (seed, t)
-            unsigned long long h = (static_cast<unsigned long long>(seed) << 32 | t) + 0x9E3779B97F4A7C15ull;
-            h = (h ^ (h >> 30)) * 0xBF58476D1CE4E5B9ull;
-            h = (h ^ (h >> 27)) * 0x94D049BB133111EBull;
-            h ^= h >> 31;
-            bool ok = true;
-            if (t == 0)
-                ok = (w < q) && powmod_r<T>(w, 1ull << (n - 1), q, rinv) == q - 1; // order exactly N
-            if (t < 128)
-            {
-                const unsigned r = static_cast<unsigned>(h) & (n1 - 1u), j = static_cast<unsigned>(h >> 32) & (n2 - 1u);
-                const unsigned long long e = inverse ? static_cast<unsigned long long>(r) * (__brev(j) >> (32 - log_n2))
-                                                     : static_cast<unsigned long long>(__brev(r) >> (32 - log_n1)) * j;
-                ok = ok && (w_table[static_cast<unsigned long long>(r) * n2 + j] == powmod_r<T>(w, e, q, rinv));
-            }
-            else if (t < 192)
-            {
-                const unsigned i = static_cast<unsigned>(h) & ((n2 >> 1) - 1u);
-                const unsigned long long e =
-                    (log_n2 > 1 ? static_cast<unsigned long long>(__brev(i) >> (33 - log_n2)) : 0ull) << log_n1;
-                ok = (n2_table[i] == powmod_r<T>(w, e, q, rinv));
-            }
-            else
-            {
-                const unsigned i = (t - 192u) & ((n1 >> 1) - 1u);
-                const unsigned long long e =
-                    (log_n1 > 1 ? static_cast<unsigned long long>(__brev(i) >> (33 - log_n1)) : 0ull) << log_n2;
-                ok = (n1_table[i] == powmod_r<T>(w, e, q, rinv));
-            }
-            if (!ok)
-                atomicAdd(bad, 1u);
-        }
-
     } // namespace kern
 
     namespace host
     {
         namespace
         {
+            // One scratch chain per (device, stream) for eager calls and one per (device, stream, capture) for calls made
+            // while the stream is being captured into a hipGraph.  A buffer that has ever been handed out is NEVER freed,
+            // and never handed to another chain, before GPU_NTT_ReleaseWorkspaces(): kernels already enqueued -- or baked
+            // into a captured graph that may be replayed at any later time, on any stream -- keep reading it.  Growth
+            // allocates a new buffer and RETIRES the old one (steps of at least 1.5 x, so the retired buffers of a chain add
+            // up to less than twice the live one).  A captured call never shares its buffer with eager calls: replaying
+            // the graph on another stream while eager calls run on the capture stream touches two different buffers.
             struct Slot
             {
-                void* ptr = nullptr;
-                size_t bytes = 0;
-                std::recursive_mutex mu; // held by a host thread for the duration of one API call
+                void* ptr = nullptr; // start of the buffer = its header (WS_HEADER bytes); the user area lies behind it
+                size_t bytes = 0;    // size of the user area
+                unsigned long long seq = 0; // calls that took a veto epoch from this chain (lazy_workspace_veto)
+                std::vector<void*> retired; // outgrown buffers, freed by release_workspaces() only
+                std::recursive_mutex mu;    // held by a host thread for the duration of one API call
             };
+            constexpr size_t WS_HEADER = 256;
+            using SlotKey = std::tuple<int, hipStream_t, unsigned long long>;
             std::mutex g_ws_mutex; // guards the map itself
-            std::map<std::pair<int, hipStream_t>, Slot> g_ws;
+            std::map<SlotKey, Slot> g_ws;
             thread_local int t_scope_depth = 0;
             thread_local std::vector<std::recursive_mutex*> t_held;
+
+            // 0: the stream is not being captured; else a key unique to the capture.  (The legacy default stream cannot be
+            // captured, and asking about it while another stream captures in global mode is itself an error.)
+            unsigned long long capture_key(hipStream_t stream)
+            {
+                if (stream == nullptr)
+                    return 0ull;
+                hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+                unsigned long long id = 0;
+                if (hipStreamGetCaptureInfo(stream, &st, &id) != hipSuccess)
+                {
+                    (void) hipGetLastError();
+                    return 0ull;
+                }
+                return st == hipStreamCaptureStatusActive ? (id | (1ull << 63)) : 0ull;
+            }
+
+            Slot& slot_of(hipStream_t stream, bool* capturing = nullptr)
+            {
+                int dev = 0;
+                GPUNTT_HIP_CHECK(hipGetDevice(&dev));
+                const unsigned long long cap = capture_key(stream);
+                if (capturing != nullptr)
+                    *capturing = cap != 0ull;
+                std::lock_guard<std::mutex> lock(g_ws_mutex);
+                return g_ws[std::make_tuple(dev, stream, cap)]; // map nodes never move and are never erased
+            }
+
+            // takes the chain's lock: for the rest of the call inside a WorkspaceScope, else until the guard dies
+            struct SlotLock
+            {
+                std::recursive_mutex* m;
+                explicit SlotLock(Slot& s) : m(&s.mu)
+                {
+                    m->lock();
+                    if (t_scope_depth > 0)
+                    {
+                        t_held.push_back(m); // released by the outermost WorkspaceScope of this thread
+                        m = nullptr;
+                    }
+                }
+                ~SlotLock()
+                {
+                    if (m != nullptr)
+                        m->unlock();
+                }
+            };
         } // namespace
 
         WorkspaceScope::WorkspaceScope() { ++t_scope_depth; }
@@ -405,6 +514,9 @@ namespace gpuntt
                     s.ptr = nullptr;
                     s.bytes = 0;
                 }
+                for (void* old : s.retired)
+                    (void) hipFree(old);
+                s.retired.clear();
             }
         }
 
@@ -540,7 +652,7 @@ namespace gpuntt
                 std::atomic<int> u32_tile{0};   // 12 | 14: 32-bit tile above 2^14
                 std::atomic<int> u32_ring13_batch{0x7fffffff}; // 32-bit ring 2^13: calls of at most this many polynomials take the 8192 tile
                 std::atomic<int> no_scratch{0}; // test hook: behave as if the twiddle scratch could not be allocated
-                std::atomic<int> validate_4step{0}; // GPU_4STEP_NTT: spot-check the caller's n2 / W tables against the derived powers
+                std::atomic<int> check_4step{1}; // 4-step entry points: verify the caller's three tables on the device (prep_merge_from_fourstep)
                 std::atomic<int> rns_predict{1}; // drop-in RNS calls: enqueue only the lazy family the stack needed last time
             } g_opt;
         } // namespace
@@ -596,7 +708,7 @@ namespace gpuntt
                     return false;
                 g_opt.u32_ring13_batch = iv;
             }
-            else if (k == "xcd_order" || k == "lim31" || k == "reverse" || k == "no_scratch" || k == "validate_4step_tables" ||
+            else if (k == "xcd_order" || k == "lim31" || k == "reverse" || k == "no_scratch" || k == "check_4step_tables" ||
                      k == "rns_predict")
             {
                 if (!one_of({0, 1}))
@@ -605,7 +717,7 @@ namespace gpuntt
                                         : k == "lim31"                 ? g_opt.lim31
                                         : k == "reverse"               ? g_opt.reverse
                                         : k == "no_scratch"            ? g_opt.no_scratch
-                                        : k == "validate_4step_tables" ? g_opt.validate_4step
+                                        : k == "check_4step_tables" ? g_opt.check_4step
                                                                        : g_opt.rns_predict;
                 dst = iv;
             }
@@ -642,58 +754,73 @@ namespace gpuntt
         {
             return static_cast<unsigned long long>(g_opt.u32_ring13_batch.load(std::memory_order_relaxed));
         }
-        bool validate_4step_tables() { return g_opt.validate_4step.load(std::memory_order_relaxed) != 0; }
+        bool check_4step_tables() { return g_opt.check_4step.load(std::memory_order_relaxed) != 0; }
 
         void* lazy_workspace(hipStream_t stream, size_t bytes, bool or_null)
         {
             if (or_null && g_opt.no_scratch.load(std::memory_order_relaxed) != 0)
                 return nullptr; // test hook: the out-of-memory fall-back of the drop-in entry points
-            int dev = 0;
-            GPUNTT_HIP_CHECK(hipGetDevice(&dev));
-            Slot* sp;
-            {
-                std::lock_guard<std::mutex> lock(g_ws_mutex);
-                sp = &g_ws[std::make_pair(dev, stream)]; // map nodes never move
-            }
-            Slot& s = *sp;
-            s.mu.lock();
-            struct Unlock
-            {
-                std::recursive_mutex* m;
-                ~Unlock()
-                {
-                    if (m != nullptr)
-                        m->unlock();
-                }
-            } unlock{&s.mu};
-            if (t_scope_depth > 0)
-            {
-                t_held.push_back(&s.mu); // released by the outermost WorkspaceScope of this thread
-                unlock.m = nullptr;
-            }
+            bool capturing = false;
+            Slot& s = slot_of(stream, &capturing);
+            SlotLock lock(s);
             if (s.bytes < bytes)
             {
-                if (s.ptr != nullptr)
-                {
-                    GPUNTT_HIP_CHECK(hipStreamSynchronize(stream)); // earlier calls may still read it
-                    GPUNTT_HIP_CHECK(hipFree(s.ptr));
-                    s.ptr = nullptr;
-                    s.bytes = 0;
-                }
+                // grow: a NEW buffer; the old one is retired, not freed -- earlier calls on this stream may still be
+                // reading it, and a graph captured from them may be replayed at any time (no synchronisation either)
                 size_t want = bytes < (size_t(1) << 20) ? (size_t(1) << 20) : bytes;
-                const hipError_t err = hipMalloc(&s.ptr, want);
+                if (want < s.bytes + s.bytes / 2)
+                    want = s.bytes + s.bytes / 2;
+                want = (want + 255u) & ~size_t(255);
+                // a capture in global mode refuses hipMalloc: allocate under the relaxed mode, as the capture rules allow
+                // for calls that do not touch the capturing stream
+                hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+                if (capturing)
+                    (void) hipThreadExchangeStreamCaptureMode(&mode);
+                void* fresh = nullptr;
+                hipError_t err = hipMalloc(&fresh, WS_HEADER + want);
+                if (capturing)
+                    (void) hipThreadExchangeStreamCaptureMode(&mode);
+                // header: the veto word of the 4-step table check (lazy_workspace_veto) starts at "no call yet" = all ones
+                if (err == hipSuccess)
+                {
+                    err = hipMemsetAsync(fresh, 0xff, WS_HEADER, stream);
+                    if (err != hipSuccess)
+                        (void) hipFree(fresh);
+                }
                 if (err != hipSuccess)
                 {
                     // out of device memory: the caller falls back to the kernels that need no scratch
                     (void) hipGetLastError();
-                    s.ptr = nullptr;
                     if (or_null)
                         return nullptr;
                     GPUNTT_HIP_CHECK(err);
                 }
+                if (s.ptr != nullptr)
+                    s.retired.push_back(s.ptr);
+                s.ptr = fresh;
                 s.bytes = want;
+                s.seq = 0;
             }
-            return s.ptr;
+            return static_cast<unsigned char*>(s.ptr) + WS_HEADER;
+        }
+
+        // The 64-bit veto word in the header of the chain's buffer (the one lazy_workspace() returned last) and a fresh
+        // epoch for it: kernels publish  ((~epoch) << 32) | state  with atomicMin, so the word always holds the state of
+        // the LATEST call on the chain -- smallest high half -- and, within that call, the smallest state any thread
+        // published (kern::GO_GENERIC = 0 = "the table check failed" beats every other).  No per-call reset: the word is
+        // set to all ones when the buffer is allocated and whenever the 32-bit epoch wraps.  Call after lazy_workspace().
+        void lazy_workspace_veto(hipStream_t stream, unsigned long long** word, unsigned* epoch)
+        {
+            Slot& s = slot_of(stream);
+            SlotLock lock(s);
+            if (s.ptr == nullptr)
+                throw std::logic_error("internal: veto word requested before the scratch buffer");
+            const unsigned e = static_cast<unsigned>(s.seq & 0xffffffffull);
+            if (s.seq != 0 && e == 0u)
+                GPUNTT_HIP_CHECK(hipMemsetAsync(s.ptr, 0xff, WS_HEADER, stream)); // epoch wrapped: start over
+            s.seq++;
+            *word = static_cast<unsigned long long*>(s.ptr);
+            *epoch = e;
         }
 
         template <typename T>
@@ -712,62 +839,29 @@ namespace gpuntt
             GPUNTT_HIP_CHECK(hipGetLastError());
         }
         template <typename T>
-        void validate_fourstep_tables_or_throw(const T* n1_table, const T* n2_table, const T* w_table, int log_n1, int log_n2,
-                                               bool inverse, T q, const Modulus<T>* mods, hipStream_t stream)
-        {
-            if (n1_table == nullptr || n2_table == nullptr || w_table == nullptr)
-                throw std::invalid_argument("4-step tables: null pointer argument");
-            unsigned* bad = nullptr;
-            GPUNTT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&bad), sizeof(unsigned)));
-            unsigned host_bad = 0;
-            hipError_t err = hipMemsetAsync(bad, 0, sizeof(unsigned), stream);
-            if (err == hipSuccess)
-            {
-                static std::atomic<unsigned> call_seed{0x5EED};
-                hipLaunchKernelGGL((kern::validate_fourstep_tables<T>), dim3(1), dim3(256), 0, stream, n1_table, n2_table,
-                                   w_table, log_n1, log_n2, inverse ? 1 : 0, q, mods, call_seed.fetch_add(0x9E37u), bad);
-                err = hipGetLastError();
-            }
-            if (err == hipSuccess)
-                err = hipMemcpyAsync(&host_bad, bad, sizeof(unsigned), hipMemcpyDeviceToHost, stream);
-            if (err == hipSuccess)
-                err = hipStreamSynchronize(stream);
-            (void) hipFree(bad);
-            GPUNTT_HIP_CHECK(err);
-            if (host_bad != 0)
-                throw std::invalid_argument(
-                    "4-step tables are not consistent with one root of order N (NTTParameters4Step layout): the fast path "
-                    "derives its twiddles from n1_table and one row of W and would not compute what the tables say "
-                    "(option validate_4step_tables; include/gpuntt/ntt_4step/ntt_4step.cuh, table contract)");
-        }
-        template void validate_fourstep_tables_or_throw<uint64_t>(const uint64_t*, const uint64_t*, const uint64_t*, int, int,
-                                                                  bool, uint64_t, const Modulus<uint64_t>*, hipStream_t);
-        template void validate_fourstep_tables_or_throw<uint32_t>(const uint32_t*, const uint32_t*, const uint32_t*, int, int,
-                                                                  bool, uint32_t, const Modulus<uint32_t>*, hipStream_t);
-
-        template <typename T>
         void launch_prep_merge_from_fourstep(const T* n1_table, const T* w_table, lazy::Tw<T>* ws, int log_n1, int log_n2,
                                              int perm_tile_log, bool inverse, bool fold, T q, T ninv,
                                              const Modulus<T>* mods, const T* ninv_dev, lazy::Tw<T>* ws_ninv,
                                              unsigned* go_flag, lazy::NormConst* norm_arr, hipStream_t stream,
-                                             unsigned* host_state)
+                                             unsigned* host_state, const FourStepVeto& veto, const T* n2_table)
         {
             const unsigned long long count = 1ull << (log_n1 + log_n2);
             const unsigned grid = static_cast<unsigned>((count + 255) / 256);
             hipLaunchKernelGGL((kern::prep_merge_from_fourstep<T>), dim3(grid), dim3(256), 0, stream, n1_table, w_table, ws,
                                log_n1, log_n2, perm_tile_log, inverse ? 1 : 0, fold ? 1 : 0, q,
-                               mods ? static_cast<T>(0) : recip_norm_host<T>(q), ninv, mods, ninv_dev, ws_ninv, go_flag,
-                               norm_arr, host_state);
+                               mods ? static_cast<T>(0) : recip_norm_host<T>(q), ninv, mods, ninv_dev, ws_ninv,
+                               veto.word != nullptr ? nullptr : go_flag, norm_arr, host_state,
+                               veto.check ? n2_table : nullptr, veto.word, veto.epoch);
             GPUNTT_HIP_CHECK(hipGetLastError());
         }
         template void launch_prep_merge_from_fourstep<uint64_t>(const uint64_t*, const uint64_t*, lazy::Tw64*, int, int, int,
                                                                 bool, bool, uint64_t, uint64_t, const Modulus<uint64_t>*,
                                                                 const uint64_t*, lazy::Tw64*, unsigned*, lazy::NormConst*,
-                                                                hipStream_t, unsigned*);
+                                                                hipStream_t, unsigned*, const FourStepVeto&, const uint64_t*);
         template void launch_prep_merge_from_fourstep<uint32_t>(const uint32_t*, const uint32_t*, lazy::Tw32*, int, int, int,
                                                                 bool, bool, uint32_t, uint32_t, const Modulus<uint32_t>*,
                                                                 const uint32_t*, lazy::Tw32*, unsigned*, lazy::NormConst*,
-                                                                hipStream_t, unsigned*);
+                                                                hipStream_t, unsigned*, const FourStepVeto&, const uint32_t*);
 
 
         template void launch_prep<uint64_t>(const uint64_t*, lazy::Tw64*, const Modulus<uint64_t>*, uint64_t, int,

@@ -16,26 +16,22 @@
 //   stream) every launch honours cfg.stream; GPU_Transpose runs on the default stream.
 //   Unsupported n_power: message on stdout, no throw (reference ntt_4step.cu:2529-2532).
 //
-// TABLE CONTRACT (narrower than the reference; this is the one place the drop-in reads LESS than it is given).
+// TABLES: whatever they say, like the reference -- mismatching tables only run slower.
 //   The reference multiplies element (i, j) by W[i*n2 + j] as it stands and runs the rows through the n2 table
-//   (src/lib/ntt_4step/ntt_4step.cu:1049-1058), so it computes "whatever the three tables say".  The fast path here runs
-//   the transform as the ring's Merge plan and derives EVERY twiddle from
-//       n1_table  (all n1/2 entries)   and   ONE row of W:  row n1/2 for FORWARD (W[(n1/2)*n2 + j] = w^j),
-//                                                           row 1    for INVERSE (W[n2 + c] = w^-brev(c)),
-//   via  w^k = Wrow(k mod n2) * n1_table[brev(k / n2)];  it never reads n2_table nor the other N - n2 entries of W.
-//   The two agree exactly when the tables are those of ONE root w of order N in the layout NTTParameters4Step
-//   generates (src/lib/common/nttparameters.cu:356-444):
-//       FORWARD  W[r*n2 + j] = w^(brev(r, log n1) * j)     INVERSE  W[r*n2 + c] = v^(r * brev(c, log n2)),  v = w^-1
-//       n1_table[i] = (root^n2)^brev(i, log n1 - 1)        n2_table[i] = (root^n1)^brev(i, log n2 - 1)
-//   True for NTTParameters4Step (host) and GPU_GeneratePowerTable / GPU_Generate4StepW (device).  NOT true for tables
-//   filled with unrelated values -- the reference's own timing program passes random tables with n1 / n2 swapped
-//   (benchmark/bench_4step_ntt.cu:80-90); such a call runs here at the same speed and computes a different
-//   (equally meaningless) result.  GPU_NTT_SetOption("validate_4step_tables", "1") makes every GPU_4STEP_NTT /
-//   GPU_4STEP_NTT_NaturalOrder call and every FourStepPlan constructor spot-check the tables on the device (the root's
-//   order, 128 random W entries, 64 n2_table and up to 64 n1_table entries; one small launch + one stream
-//   synchronisation) and throw std::invalid_argument on a mismatch.  The generic (Barrett) fall-back -- moduli outside
-//   the fast domain, RNS overload with mod_count > 1, option path = generic -- reads all three tables element by
-//   element like the reference does.
+//   (src/lib/ntt_4step/ntt_4step.cu:1049-1058, 776-779).  The fast path here runs the transform as the ring's Merge plan
+//   and derives every twiddle from n1_table and ONE row of W, which equals the reference's result exactly when the three
+//   tables are those of ONE root g with g^(N/2) = -1 in the layout NTTParameters4Step generates
+//   (src/lib/common/nttparameters.cu:356-444):
+//       FORWARD  W[r*n2 + j] = g^(brev(r, log n1) * j)     INVERSE  W[r*n2 + c] = g^(r * brev(c, log n2))
+//       n1_table[i] = (g^n2)^brev(i, log n1 - 1)           n2_table[i] = (g^n1)^brev(i, log n2 - 1)
+//   (true for NTTParameters4Step on the host and GPU_GeneratePowerTable / GPU_Generate4StepW on the device).  Every
+//   GPU_4STEP_NTT / GPU_4STEP_NTT_NaturalOrder call therefore VERIFIES all N + n1/2 + n2/2 table words inside its
+//   preparation launch -- one modular product per word against its neighbours, no extra launch, no host
+//   synchronisation -- and tables that are anything else (the reference's timing program passes random words with n1 / n2
+//   swapped, benchmark/bench_4step_ntt.cu:80-90) hand the call, on the device, to the element-by-element Barrett kernels
+//   enqueued behind the fast ones: bit for bit what the tables say.  A FourStepPlan checks once, in its constructor
+//   (fast_path() tells).  GPU_NTT_SetOption("check_4step_tables", "0") opts out for callers that guarantee the layout
+//   above (no check, no generic launches behind the call).
 #pragma once
 
 #include "gpuntt/ntt_4step/ntt_4step_cpu.cuh"

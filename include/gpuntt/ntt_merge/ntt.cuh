@@ -192,7 +192,9 @@ namespace gpuntt
         Impl* p_;
     };
 
-    // frees the per-(device, stream) scratch buffers of the drop-in entry points (synchronises the device)
+    // Frees the library-owned twiddle scratch of the drop-in entry points (synchronises the device).  The drop-in calls
+    // never free or reuse a scratch buffer on their own -- a hipGraph captured from them may be replayed at any time --
+    // so call this only when no such graph will be replayed again and no call is in flight.
     void GPU_NTT_ReleaseWorkspaces();
 
     // Process-wide tuning / test options (extension).  The library reads no environment variable; A/B scripts and
@@ -208,8 +210,9 @@ namespace gpuntt
     //                            (default 2147483647 = always; 0: never, the ring shares a 16384-coefficient tile)
     //   no_scratch     0 | 1     test hook: the drop-in calls behave as if their twiddle scratch could not be allocated
     //                            (they run on the generic kernels, which need none)
-    //   validate_4step_tables 0 | 1   GPU_4STEP_NTT / FourStepPlan: spot-check the caller's n2 / W tables against the powers
-    //                            the fast path derives (ntt_4step/ntt_4step.cuh, "table contract"); default 0
+    //   check_4step_tables 0 | 1   4-step entry points / FourStepPlan: verify all three caller tables on the device and run
+    //                            the element-by-element kernels when they are not the tables of one root
+    //                            (ntt_4step/ntt_4step.cuh, "TABLES"); default 1
     //   rns_predict    0 | 1     drop-in RNS calls enqueue only the lazy kernel family their stack of moduli (same device,
     //                            moduli pointer, mod_count) needed the last time, with the generic kernels behind it for
     //                            every other case (default 1); 0: every family behind the go-flag on every call

@@ -30,9 +30,10 @@
  *
  * All data/table/modulus-array pointers are DEVICE pointers unless the name ends in _host.
  * Calls are asynchronous on `stream` (a hipStream_t passed as void*; NULL = default
- * stream).  The transform entry points keep a library-owned twiddle scratch buffer per
- * (device, stream): its first use (or growth) allocates, growth synchronises that stream once;
- * gpuntt_release_workspaces() frees them.  gpuntt_plan_execute_* allocates nothing, never
+ * stream).  The transform entry points keep a library-owned twiddle scratch per (device, stream)
+ * -- and per capture while a stream is being captured: first use / growth allocates, nothing is
+ * freed, reused or synchronised on before gpuntt_release_workspaces(), so hipGraphs captured from
+ * these calls stay replayable ("Scratch lifetime and hipGraphs").  gpuntt_plan_execute_* allocates nothing, never
  * synchronises and launches no preparation kernel.
  *
  * Return value: GPUNTT_OK, or a negative code with the text available from
@@ -263,7 +264,8 @@ extern "C"
     int gpuntt_generate_4step_w_u64(uint64_t* out, uint64_t root, gpuntt_modulus64 modulus, int n_power, int ntt_type,
                                     void* stream);
 
-    /* frees the library-owned scratch buffers of the drop-in entry points (synchronises the device) */
+    /* frees the library-owned scratch buffers of the drop-in entry points (synchronises the device); only when no
+     * hipGraph captured from drop-in calls will be replayed again and no call is in flight */
     int gpuntt_release_workspaces(void);
 
     /* process-wide tuning / test option (GPU_NTT_SetOption, include/gpuntt/ntt_merge/ntt.cuh lists the names);

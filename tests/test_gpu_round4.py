@@ -1,4 +1,4 @@
-"""-m gpu tests added in round 4: the 4-step table contract and its validation option, the two plan / option
+"""-m gpu tests added in round 4 (the 4-step table contract of that round became a default-on check in round 5: tests/test_gpu_round5.py): the two plan / option
 interactions ADVICE r3 found, and the round's kernel variants (A/B switches must not change a single bit)."""
 import os
 
@@ -31,59 +31,6 @@ def _fourstep_forward(g, p4, tables, x, batch):
     g.GPU_Transpose(d_a, d_b, p4.n1, p4.n2, p4.logn, batch)
     torch.cuda.synchronize()
     return g.to_host(d_b)
-
-
-@pytest.mark.parametrize("bits,logn", [(64, 12), (64, 16), (32, 18)])
-def test_fourstep_table_contract(g, bits, logn):
-    """include/gpuntt/ntt_4step/ntt_4step.cuh, TABLE CONTRACT: the fast path derives its twiddles from n1_table and one
-    row of W (row n1/2 forward) and never reads n2_table or the rest of W -- where the reference multiplies by
-    W[address] element by element (src/lib/ntt_4step/ntt_4step.cu:1049-1058).
-      * option off (default): a W matrix whose OTHER rows are garbage and a garbage n2_table give the same result as the
-        consistent tables (the documented narrowing);
-      * option validate_4step_tables on: consistent tables pass; random tables (what benchmark/bench_4step_ntt.cu:80-90
-        passes) and the garbage-rows W are refused with std::invalid_argument -> ValueError;
-      * the generic kernels (path = generic) read every table like the reference: there the garbage W changes the result."""
-    P = O.Port(bits)
-    p4 = g.NTTParameters4Step(logn, bits)
-    oprm = P.fourstep_params(logn)
-    batch = 2
-    x = P.splitmix(31000 + logn, 0, batch * p4.n, p4.modulus.value)
-    want = P.fourstep_ntt(x, oprm)
-    t1, t2, w = p4.tables["fwd"]
-    rng = np.random.default_rng(logn)
-    w_bad = rng.integers(1, p4.modulus.value, size=w.size, dtype=np.uint64).astype(w.dtype)
-    row = (p4.n1 // 2) * p4.n2
-    w_bad[row:row + p4.n2] = w[row:row + p4.n2]  # the one row the fast path reads stays
-    t2_bad = rng.integers(1, p4.modulus.value, size=t2.size, dtype=np.uint64).astype(t2.dtype)
-    good = [g.to_device(t) for t in (t1, t2, w)]
-    narrowed = [g.to_device(t) for t in (t1, t2_bad, w_bad)]
-    random_w = [g.to_device(t) for t in (t1, t2, rng.integers(1, p4.modulus.value, size=w.size, dtype=np.uint64).astype(w.dtype))]
-    try:
-        g.set_option("validate_4step_tables", "0")
-        assert np.array_equal(_fourstep_forward(g, p4, good, x, batch), want)
-        assert np.array_equal(_fourstep_forward(g, p4, narrowed, x, batch), want), "fast path read more than the contract says"
-        g.set_option("validate_4step_tables", "1")
-        assert np.array_equal(_fourstep_forward(g, p4, good, x, batch), want)
-        for name, tabs in (("garbage rows", narrowed), ("random W", random_w)):
-            with pytest.raises(ValueError, match="4-step tables"):
-                _fourstep_forward(g, p4, tabs, x, batch)
-        # plans check once, in their constructor
-        cf = g.ntt4step_configuration(n_power=logn, ntt_type=g.FORWARD)
-        with pytest.raises(ValueError, match="4-step tables"):
-            g.FourStepPlan(*random_w, p4.modulus, cf, batch_hint=batch)
-        g.FourStepPlan(*good, p4.modulus, cf, batch_hint=batch).close()
-        # inverse tables, consistent: accepted
-        ti = [g.to_device(t) for t in p4.tables["inv"]]
-        g.FourStepPlan(*ti, p4.modulus, g.ntt4step_configuration(n_power=logn, ntt_type=g.INVERSE, mod_inverse=p4.n_inv),
-                       batch_hint=batch).close()
-        g.set_option("validate_4step_tables", "0")
-        g.set_option("path", "generic")
-        assert np.array_equal(_fourstep_forward(g, p4, good, x, batch), want)
-        assert not np.array_equal(_fourstep_forward(g, p4, narrowed, x, batch), want), \
-            "the generic kernels are documented to read W element by element"
-    finally:
-        g.set_option("validate_4step_tables", "0")
-        g.set_option("path", os.environ.get("GPUNTT_PATH", "default"))
 
 
 def test_u32_tile_option_with_fourstep_rings_below_2_18(g):
