@@ -247,8 +247,16 @@ namespace gpuntt
         template <> struct Mod<uint64_t, 4, false> : Mod64<4>
         {
         };
-        // per-lane moduli: one family for the whole documented domain (<= 62 bit), the 4 q range
+        // per-lane moduli.  PerCoefficient layout (strided passes): one family for the whole documented domain (<= 62 bit),
+        // the 4 q range.  RNS stacks of rings below one tile (contiguous passes, several polynomials per wave): the same
+        // three ranges as the uniform kernels, chosen by the go-flag / the plan
         template <> struct Mod<uint64_t, 4, true> : Mod64<4, true>
+        {
+        };
+        template <> struct Mod<uint64_t, 0, true> : Mod64<16, true>
+        {
+        };
+        template <> struct Mod<uint64_t, 8, true> : Mod64<8, true>
         {
         };
 

@@ -125,7 +125,8 @@ namespace gpuntt
             bool all_families;
             unsigned* state_out; // device pointer of the host-mapped word for the preparation kernel, or nullptr
         };
-        RnsGuess rns_guess(const void* moduli_device, int mod_count, int word_bytes, bool inverse);
+        // order: the mod_order array of a *_Modulus_Ordered call (a different subset of the stack may classify differently), else nullptr
+        RnsGuess rns_guess(const void* moduli_device, int mod_count, int word_bytes, bool inverse, const void* order = nullptr);
         extern template void launch_prep<uint64_t>(const uint64_t*, lazy::Tw64*, const Modulus<uint64_t>*,
                                                    uint64_t, int, int, bool, int, const uint64_t*,
                                                    lazy::Tw64*, unsigned*, lazy::NormConst*, hipStream_t, const int*,
@@ -342,13 +343,10 @@ namespace gpuntt
             return tl;
         }
 
-        // grid of a lazy kernel of the 8 q / 4 q family (64-bit words) launched behind a go-flag, i.e. in its shadow role behind a
-        // drop-in RNS call: capped, the blocks walk the tiles (kern::for_each_block) -- 8 blocks per CU keep the part full
-        // when the family owns the call, and a skipped launch costs < 1 us instead of 0.4 ns per tile
-        template <typename T, int LIMSEL> inline unsigned lazy_grid_cap(unsigned long long tiles, const unsigned* go_flag)
+        // grid of a lazy kernel: one block per tile (the capped, tile-walking grids of the 8 q / 4 q families went with
+        // kern::WalksTiles in round 5)
+        template <typename T, int LIMSEL> inline unsigned lazy_grid_cap(unsigned long long tiles, const unsigned*)
         {
-            if (sizeof(T) == 8 && (LIMSEL == 4 || LIMSEL == 8) && go_flag != nullptr && tiles > 2048)
-                return 2048u;
             return static_cast<unsigned>(tiles);
         }
 
@@ -372,6 +370,17 @@ namespace gpuntt
         extern template void launch_pass_lazy_vq<uint64_t, true>(const Pass&, bool, bool, const kern::LazyArgsT<uint64_t>&, hipStream_t);
         extern template void launch_pass_lazy_vq<uint32_t, false>(const Pass&, bool, bool, const kern::LazyArgsT<uint32_t>&, hipStream_t);
         extern template void launch_pass_lazy_vq<uint32_t, true>(const Pass&, bool, bool, const kern::LazyArgsT<uint32_t>&, hipStream_t);
+
+        // RNS stacks of rings of 2^4 .. 2^9 coefficients: the single contiguous pass with per-lane moduli
+        // (kern::merge_pass_lazy_vqc, lazy_vqc_*.hip); a.lim = 0 / 31 / 8 / 4 picks the lazy range like run_transform_lazy does
+        template <typename T, bool INV> void launch_small_rns_lazy(int n, const kern::LazyArgsT<T>& a, hipStream_t stream);
+        template <> void launch_small_rns_lazy<uint64_t, false>(int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
+        template <> void launch_small_rns_lazy<uint64_t, true>(int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
+        extern template void launch_small_rns_lazy<uint32_t, false>(int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
+        extern template void launch_small_rns_lazy<uint32_t, true>(int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
+        // smallest ring an RNS stack (mod_count > 1) runs on the fast kernels: below it the 16 coefficients of a thread
+        // would span polynomials of different moduli
+        constexpr int LAZY_MIN_RNS_N_POWER = kern::R;
 
         template <bool INV, int LIMSEL>
         void launch_pass_lazy_lim(const Pass& p, bool in_first, bool last, const kern::LazyArgsT<uint64_t>& a,
@@ -442,6 +451,18 @@ namespace gpuntt
                                : (forced_tl ? forced_tl : lazy_tile_log<T>(base.n, INV, base.total >> base.n));
             const int pn = (!INV && low_stages > 0) ? low_stages : base.n;
             const bool partial = pn != base.n;
+            // RNS stack of rings below one tile: the tile holds polynomials of different moduli.  From 1024 coefficients a
+            // wave lies in one polynomial and the ordinary kernels pick the modulus per wave (merge_pass_lazy); rings of
+            // 16 .. 512 coefficients take the per-lane-modulus form of the same pass
+            if (base.mods != nullptr && base.mod_count > 1 && base.n < tl && base.n - kern::R < 6)
+            {
+                if (base.n < LAZY_MIN_RNS_N_POWER || partial)
+                    throw std::invalid_argument("internal: RNS ring too small for the fast path");
+                kern::LazyArgsT<T> a = base;
+                a.p_lo = 0;
+                a.flags |= first_in_flags | last_out_flags;
+                return launch_small_rns_lazy<T, INV>(base.n, a, stream);
+            }
             const Plan pl = make_plan_tl(pn, tl, tl == 12 ? lazy_contig_k(pn) : tl);
             const void* src = base.in;
             int fwd_bound = partial ? 16 : 1; // range bound of the values in flight (forward, 31 q range: see fwd_bound_after)

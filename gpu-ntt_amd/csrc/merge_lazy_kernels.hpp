@@ -36,6 +36,7 @@ namespace gpuntt
             const int* poly_order;           // *_Poly_Ordered: polynomial p lives in slot poly_order[p]
             const T* mul_in;                 // GPU_PolyMul: canonical operand multiplied into the final forward store, or nullptr
             int lim;                         // 64-bit words: 0, or 8 / 4 = a 61- / 62-bit modulus in the call -> the LIMIT = 8 / 4 kernels (host-side switch)
+            int host_allow_31q;              // host side only: the preparation kernel of this drop-in RNS call may name the 31 q family
             int n2_log;                      // 4-step transposing passes: log2 of the row stride of the transposed side
             int row_log;                     // natural-order 4-step row passes (Fst::nat_rows): log2 of the row stride of the row-major side (n2); a.n stays the ring (twiddle indices)
             int batch;                       // > 1: polynomials of the call, blocks are ordered poly-minor (big-ring contiguous passes)
@@ -415,7 +416,9 @@ namespace gpuntt
             using M = lazy::Mod<T, LIM, VQ>;
             using SCH = PassSched<TLOG, INV, CONTIG, K, IN_BOUND, M::LIMIT, M::TB, SKIP>;
             using TW = lazy::Tw<T>;
-            static_assert(!VQ || (!CONTIG && FST == Fst::none && XP == Xp::none && !EXACT && SKIP == 0), "per-lane moduli: plain strided passes");
+            static_assert(!VQ || (FST == Fst::none && XP == Xp::none && !EXACT && SKIP == 0), "per-lane moduli: plain passes");
+            static_assert(!(VQ && CONTIG) || (K >= R && K < TLOG && IN_BOUND == 1 && LAST),
+                          "per-lane moduli, contiguous: single-pass transforms of rings of 16 .. tile/2 coefficients");
             constexpr bool HAS_FST = (FST != Fst::none);
             constexpr int TL = TLOG;
             constexpr int NT = LTile<TLOG>::NT;
@@ -451,10 +454,19 @@ namespace gpuntt
                 map.remap_poly(a.poly_order, a.n); // twiddle indices use flat & (N-1): unaffected
             if constexpr (VQ)
             {
-                // the thread's column (the same in every round, see above) picks its modulus
-                const unsigned col = static_cast<unsigned>(map.flat(elem_of<SCH::wl_of(0)>(t, 0))) & ((1u << a.col_log) - 1u);
-                mi = static_cast<int>(col % static_cast<unsigned>(a.mod_count));
-                const Modulus<T> md = a.mods[mi];
+                unsigned owner;
+                if constexpr (CONTIG)
+                    // RNS stack of rings below one tile: the tile holds 2^(TL - K) polynomials.  Every register window is
+                    // aligned to the top stage of its round and K >= 4, so no window reaches tile bit K: thread bit b >= WL
+                    // is tile bit b + 4 in every round, and the thread's 16 coefficients lie in polynomial t >> (K - 4) of
+                    // the tile in EVERY round (reference ForwardCoreLowRing / InverseCoreLowRing RNS forms,
+                    // src/lib/ntt_merge/ntt.cu:116-219, 326-433: mod_index = polynomial % mod_count)
+                    owner = static_cast<unsigned>(map.base >> K) + (static_cast<unsigned>(t) >> (K - R));
+                else
+                    // the thread's column (the same in every round, see above) picks its modulus
+                    owner = static_cast<unsigned>(map.flat(elem_of<SCH::wl_of(0)>(t, 0))) & ((1u << a.col_log) - 1u);
+                mi = static_cast<int>(owner % static_cast<unsigned>(a.mod_count));
+                const Modulus<T> md = a.mods[a.mod_order != nullptr ? a.mod_order[mi] : mi];
                 q_value = md.value;
                 q_bit = md.bit;
                 q_mu = md.mu;
@@ -466,7 +478,7 @@ namespace gpuntt
             M m;
             m.set(q_value, (a.norm_arr != nullptr) ? a.norm_arr[mi] : a.norm);
             const dev::ModCtx<T> em{q_value, q_bit, q_mu};
-            const unsigned long long root_base = static_cast<unsigned long long>(mi) << (VQ ? a.mod_shift : a.n);
+            const unsigned long long root_base = static_cast<unsigned long long>(mi) << ((VQ && !CONTIG) ? a.mod_shift : a.n);
             // (word by word: selecting between the two 8-byte structs as a whole left a dead 16-byte stack slot --
             // and with it a scratch allocation -- in every 32-bit inverse kernel)
             T ninv_w = a.ninv.w, ninv_wp = a.ninv.wp;
@@ -1165,28 +1177,18 @@ namespace gpuntt
             return (flags & F_VETO_ONLY) ? (st == GO_GENERIC) : (st != mine);
         }
 
-        // The 8 q and 4 q families of 64-bit words are enqueued behind EVERY drop-in RNS call as shadows of the default family
-        // (one of them owns the call only when the stack holds a 61- / 62-bit prime).  A skipped launch costs about 0.4 ns per block (7 us for
-        // the 16384 blocks of a C2-sized pass, > 100 us for a C3-sized one), so those families run on a CAPPED grid whose blocks
-        // walk the tiles (host: lazy_grid_cap) -- like the generic kernels' shadow launches (merge_kernels.hpp).  f(block
-        // index, number of blocks of the uncapped grid).
+        // One tile per block.  (Rounds 3-4 ran the 8 q / 4 q families of 64-bit words on a capped grid whose blocks walked
+        // the tiles, because they were enqueued behind EVERY drop-in RNS call as shadows and a skipped launch costs ~0.4 ns
+        // per block.  Since the family prediction -- host::RnsGuess -- a family is enqueued when it is expected to OWN the
+        // call, and the tile loop cost those kernels 150 .. 340 bytes of scratch per lane: removed in round 5.)
         template <typename T, int LIM> struct WalksTiles
         {
-            static constexpr bool value = (sizeof(T) == 8 && (LIM == 4 || LIM == 8));
+            static constexpr bool value = false;
         };
-        template <bool WALK, typename F> __device__ __forceinline__ void for_each_block(unsigned nblocks, F&& f)
+        template <bool WALK, typename F> __device__ __forceinline__ void for_each_block(unsigned, F&& f)
         {
-            if constexpr (WALK)
-            {
-                for (unsigned vb = blockIdx.x; vb < nblocks; vb += gridDim.x)
-                {
-                    if (vb != blockIdx.x)
-                        __syncthreads(); // every wave is done with the LDS of the previous tile
-                    f(vb, nblocks);
-                }
-            }
-            else
-                f(blockIdx.x, gridDim.x);
+            static_assert(!WALK, "tile-walking grids are gone");
+            f(blockIdx.x, gridDim.x);
         }
 
         // Poly-minor block order (the polynomials of a batch that share a slice of the twiddle / W table run back
@@ -1251,7 +1253,12 @@ namespace gpuntt
             if (a.mods != nullptr)
             {
                 const LTileMap<TLOG, CONTIG, K> map(a.n, a.p_lo, static_cast<unsigned long long>(blk));
-                const unsigned long long poly = map.flat(0) >> a.poly_shift;
+                unsigned long long poly = map.flat(0) >> a.poly_shift;
+                // RNS stack of rings below one tile, from 1024 coefficients: a wave's 16 x 64 coefficients lie in ONE
+                // polynomial (thread bits >= K - 4 >= 6 select it), so the modulus is wave-uniform and stays in scalar
+                // registers; smaller rings take the per-lane-modulus kernels (merge_pass_lazy_vqc)
+                if constexpr (CONTIG && K < TLOG && K - R >= 6 && IN_BOUND == 1 && LAST)
+                    poly += threadIdx.x >> (K - R);
                 mi = static_cast<int>(uniform32(static_cast<unsigned>(poly % static_cast<unsigned>(a.mod_count))));
                 const Modulus<T> md = a.mods[a.mod_order != nullptr ? a.mod_order[mi] : mi];
                 qv = md.value;
@@ -1282,6 +1289,29 @@ namespace gpuntt
                 return;
             pass_body<T, 12, false, INV, false, K, IN_BOUND, LAST, Fst::none, LIM, Xp::none, 0, true>(a, lds, 0, 0, 0, 0, 0, 0,
                                                                                        static_cast<long long>(blockIdx.x));
+        }
+
+        // RNS stacks of rings of 16 .. 512 coefficients (reference ForwardCoreLowRing / InverseCoreLowRing, RNS forms,
+        // src/lib/ntt_merge/ntt.cu:116-219, 326-433): one contiguous pass over a 4096-coefficient tile that holds 2^(12 - K)
+        // polynomials of DIFFERENT moduli, several of them per wave -- pass_body with per-lane moduli (VQ).  LIM: the lazy
+        // range the stack needs (0 the default range, 8 / 4: 64-bit words with a 61- / 62-bit prime); a.lim = 31 on a
+        // LIM = 0 launch: the launch stands in for the 31 q family (it accepts the go-flag state GO_LAZY_31Q instead of GO_LAZY)
+        template <typename T, bool INV, int K, int LIM>
+        __global__ __launch_bounds__(LTile<12>::NT, (LOcc<12, T>::WAVES)) void merge_pass_lazy_vqc(LazyArgsT<T> a)
+        {
+            __shared__ T lds[LTile<12>::LDS_ELEMS];
+            if (a.go_flag != nullptr)
+            {
+                const unsigned mine = sizeof(T) != 8 ? GO_LAZY
+                                      : (LIM == 4 ? GO_LAZY_4Q : (LIM == 8 ? GO_LAZY_8Q : (a.lim == 31 ? GO_LAZY_31Q : GO_LAZY)));
+                if (*a.go_flag != mine)
+                    return;
+            }
+            for_each_block<WalksTiles<T, LIM>::value>(
+                static_cast<unsigned>((a.total + LTile<12>::TILE - 1) >> 12), [&](unsigned bidx, unsigned) {
+                    pass_body<T, 12, false, INV, true, K, 1, true, Fst::none, LIM, Xp::none, 0, true>(
+                        a, lds, 0, 0, 0, 0, 0, 0, static_cast<long long>(bidx));
+                });
         }
 
         // block -> (polynomial, tile of the polynomial) for the transposing row passes of the natural-order 4-step: tile =

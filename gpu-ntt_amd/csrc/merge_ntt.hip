@@ -64,16 +64,18 @@ namespace gpuntt
         //   RNS: the moduli live in device memory, so the twiddle-prep kernel classifies them and
         //        publishes a four-state go-flag (generic / default lazy range / 8 q / 4 q range); every family is
         //        enqueued, each returning at once when the flag names another one (run_transform_lazy_rns).
-        // Tiny single-modulus rings (below 2^5 / 2^11), small RNS jobs, rings above 2^24 and RNS
-        // stacks of rings below one tile use the generic kernels only.
+        // Tiny single-modulus rings (below 2^5 / 2^11), small RNS jobs and RNS stacks of rings of 2 .. 8
+        // coefficients use the generic kernels only.
         // option path = generic | fast overrides the size heuristic (testing / A-B timing; host::set_option);
         // moduli without the headroom always take the generic kernels.
         using host::forced_path;
 
         template <typename TU> inline bool lazy_eligible(int n_power, int batch_size, int mod_count)
         {
+            // (RNS stacks of rings below one tile: the tile mixes moduli -- per wave from 1024 coefficients, per lane down
+            // to 16, kern::merge_pass_lazy_vqc; rings of 2 .. 8 coefficients with mod_count > 1 keep the generic kernels)
             const bool can = n_power <= host::LAZY_MAX_N_POWER &&
-                             !(mod_count > 1 && n_power < host::lazy_tile_log<TU>(n_power)) && // a tile would mix moduli
+                             !(mod_count > 1 && n_power < host::LAZY_MIN_RNS_N_POWER) &&
                              (static_cast<unsigned long long>(mod_count) << n_power) <= (1ull << 28); // 4 GiB table
             const int fp = forced_path();
             if (fp == 3 && !can)
@@ -156,11 +158,12 @@ namespace gpuntt
             unsigned char* tail_p = reinterpret_cast<unsigned char*>(ws + entries);
             unsigned* go_flag = mods ? reinterpret_cast<unsigned*>(tail_p) : nullptr;
             auto* norm_arr = mods ? reinterpret_cast<lazy::NormConst*>(tail_p + 16) : nullptr;
+            // option lim31 is read ONCE per call: the preparation kernel may name the 31 q family only if
+            // run_transform_lazy_rns enqueues it (two reads could disagree when another thread flips the option)
+            const bool allow_31q = mods != nullptr && host::lazy_lim31_enabled();
             host::launch_prep<TU>(roots, ws, mods, m.value, mod_count, n_power, neg, perm_tile_log, ninv_dev,
                                   ninv_dev ? ws_ninv : nullptr, go_flag, norm_arr, stream, mod_order, ninv_single,
-                                  ninv_dev != nullptr, mods ? host_state : nullptr,
-                                  /* allow_31q: the Merge RNS entry points enqueue that family (run_transform_lazy_rns) */
-                                  mods != nullptr && host::lazy_lim31_enabled());
+                                  ninv_dev != nullptr, mods ? host_state : nullptr, allow_31q);
             kern::LazyArgsT<TU> a{};
             a.in = in;
             a.out = out;
@@ -173,6 +176,7 @@ namespace gpuntt
             a.ninv = TW{0, 0};
             a.go_flag = go_flag;
             a.lim = lim;
+            a.host_allow_31q = allow_31q ? 1 : 0;
             a.mod_order = mod_order;
             a.poly_order = nullptr;
             a.norm = lazy::make_norm_const(static_cast<uint64_t>(m.value), static_cast<uint64_t>(m.bit));
@@ -202,7 +206,7 @@ namespace gpuntt
             {
                 kern::LazyArgsT<TU> wide = la;
                 if constexpr (!INV)
-                    if (host::lazy_lim31_enabled() && (guess.all_families || guess.state == kern::GO_LAZY_31Q))
+                    if (la.host_allow_31q != 0 && (guess.all_families || guess.state == kern::GO_LAZY_31Q))
                     {
                         wide.lim = 31; // every modulus has 31 q < 2^64 (the reference's pool primes): forward transforms
                         host::run_transform_lazy<TU, INV>(wide, in_flags, out_flags, stream);
@@ -364,6 +368,12 @@ namespace gpuntt
                 pl.pass[pl.count++] = host::Pass{false, k, log_w + top};
                 if (12 - k > log_w + top)
                     return false; // a tile row would be wider than the matrix row: small-matrix kernel (generic)
+                // A pass of k < 4 stages (n_power 1 .. 3) keeps its register window on tile bits 8 .. 11 while the stage
+                // bits start at 12 - k: register bits 0 .. 3 - k are COLUMN bits, a thread holds columns c, c + 256, ...
+                // and the kernel picks ONE modulus per thread (pass_body VQ) -- right only when every such column has the
+                // modulus of column c, i.e. when mod_count divides 256.  Anything else takes the generic kernels
+                if (k < 4 && mod_count > 1 && (256 % mod_count) != 0)
+                    return false;
             }
             const size_t entries = (static_cast<size_t>(mod_count) << n_power) + mod_count;
             const size_t norm_bytes = (sizeof(lazy::NormConst) * static_cast<size_t>(mod_count) + 15u) & ~size_t(15);
@@ -1188,7 +1198,7 @@ namespace gpuntt
             if (cfg.n_power >= host::lazy_tile_log<T>(cfg.n_power) &&
                 lazy_eligible<T>(cfg.n_power, batch_size, mod_count, cfg.stream) && (!inv || cfg.mod_inverse != nullptr))
             {
-                guess = host::rns_guess(modulus, mod_count, static_cast<int>(sizeof(T)), inv);
+                guess = host::rns_guess(modulus, mod_count, static_cast<int>(sizeof(T)), inv, mod_order);
                 kern::LazyArgsT<T> la =
                     lazy_args<T>(device_in, device_out, table, Modulus<T>(), modulus, mod_count,
                                  inv ? cfg.mod_inverse : nullptr, cfg.n_power, cfg.reduction_poly,

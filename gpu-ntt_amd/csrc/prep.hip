@@ -529,6 +529,7 @@ namespace gpuntt
                 unsigned predicted = kern::GO_LAZY;
                 bool have_prediction = false;
                 int mispredicts = 0;
+                int streak = 0; // correct predictions in a row (64 of them forgive the misses)
                 unsigned long long last_use = 0;
             };
             // one pinned, device-mapped allocation per device: GUESS_MAX_KEYS words, one cache line apart.  Never freed
@@ -544,14 +545,15 @@ namespace gpuntt
             constexpr unsigned STATE_UNKNOWN = 0xffffffffu;
             std::mutex g_guess_mutex;
             std::map<int, GuessPool> g_guess_pool;
-            // (device, moduli, mod_count, word size | entry point | direction): forward and inverse calls of one stack may
-            // need different families (31 q serves forward transforms only)
-            std::map<std::tuple<int, const void*, int, int>, GuessSlot> g_guess;
+            // (device, moduli, mod_order, mod_count, word size | 4-step entry | direction): forward and inverse calls of one
+            // stack may need different families (31 q serves forward transforms only), a *_Modulus_Ordered call uses the
+            // subset its order array names; the Merge entry points otherwise share one slot per stack
+            std::map<std::tuple<int, const void*, const void*, int, int>, GuessSlot> g_guess;
             unsigned long long g_guess_clock = 0;
         } // namespace
 
         static bool rns_predict_enabled(); // option rns_predict (defined with the options below)
-        RnsGuess rns_guess(const void* moduli_device, int mod_count, int word_bytes, bool inverse)
+        RnsGuess rns_guess(const void* moduli_device, int mod_count, int word_bytes, bool inverse, const void* order)
         {
             RnsGuess gss{kern::GO_LAZY, true, nullptr};
             if (!rns_predict_enabled() || forced_path() == 3)
@@ -578,7 +580,7 @@ namespace gpuntt
                 for (size_t i = 0; i < GUESS_MAX_KEYS; i++)
                     reinterpret_cast<volatile unsigned*>(pool.host)[i * GUESS_STRIDE] = STATE_UNKNOWN;
             }
-            const auto key = std::make_tuple(dev, moduli_device, mod_count, word_bytes | (inverse ? 0x100 : 0));
+            const auto key = std::make_tuple(dev, moduli_device, order, mod_count, word_bytes | (inverse ? 0x100 : 0));
             auto it = g_guess.find(key);
             if (it == g_guess.end())
             {
@@ -611,7 +613,12 @@ namespace gpuntt
                 // predicted for it: the caller rewrites this buffer with stacks of different widths -- after the second miss
                 // the stack keeps the all-families form (always the right lazy kernels, a few empty launches more)
                 if (s.have_prediction && seen != s.predicted)
+                {
                     s.mispredicts++;
+                    s.streak = 0;
+                }
+                else if (s.mispredicts > 0 && ++s.streak >= 64)
+                    s.mispredicts = s.streak = 0; // the stack has settled: back to the predicted family alone
                 s.predicted = seen;
                 s.have_prediction = true;
             }
