@@ -114,31 +114,46 @@ def cpu_baseline(cfg, case, y_gpu_sample):
         return {"value": 1.0 / dt, "unit": "NTT/s", "cores": 1, "kind": kind, "gpu_output_bit_exact": True,
                 "sample": "one forward NTT_4STEP_CPU::ntt of N=2^%d on one host core, %.1f s" % (logn, dt)}
     poly = O.X_N_minus if cfg["poly"] == "minus" else O.X_N_plus
+    inverse = cfg.get("direction", "fwd") == "inv"
     if cfg["kind"] == "rns":
         prms = [B.merge_params(logn, poly, f) for f in case["factors"]]
         mc = len(prms)
 
         def run_one(lo, hi):
-            return [B.merge_ntt(x[p * n:(p + 1) * n], prms[p % mc]) for p in range(lo, hi)]
+            return [B.merge_ntt(x[p * n:(p + 1) * n], prms[p % mc], inverse) for p in range(lo, hi)]
     else:
         prm = B.merge_params(logn, poly)
 
         def run_one(lo, hi):
-            return [B.merge_ntt(x[lo * n:hi * n], prm)]
+            return [B.merge_ntt(x[lo * n:hi * n], prm, inverse)]
     y = np.concatenate(run_one(0, polys))
     if not np.array_equal(y, y_gpu_sample):
         raise SystemExit("bench: GPU result differs from the CPU reference path")
     v1 = _timed_cpu(run_one, polys, 1, CPU_SECONDS)
-    vt = _timed_cpu(run_one, polys, threads, CPU_SECONDS) if threads > 1 else v1
+    how = "batch-parallel ctypes calls from a thread pool"
+    if threads > 1 and cfg["kind"] != "rns" and hasattr(B, "merge_ntt_mt"):
+        # all host threads: ONE call into the reference build, OpenMP loop over the polynomials around NTTCPU::ntt
+        # (oracle/ref_driver.cpp) -- what the host can really do, without a Python task per polynomial
+        reps = max(1, (4 * threads + polys - 1) // polys)
+        xs = np.tile(x, reps)
+        assert np.array_equal(B.merge_ntt_mt(xs, prm, inverse, threads)[:y.size], y)
+        done, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < CPU_SECONDS:
+            B.merge_ntt_mt(xs, prm, inverse, threads)
+            done += polys * reps
+        vt = done / (time.perf_counter() - t0)
+        how = "one OpenMP loop over %d polynomials inside the reference build" % (polys * reps)
+    else:
+        vt = _timed_cpu(run_one, polys, threads, CPU_SECONDS) if threads > 1 else v1
     return {"value": vt, "unit": "NTT/s", "cores": threads, "kind": kind, "value_1_core": v1,
             "gpu_output_bit_exact": True,
             "sample": "%d polynomials of one batch (u%d, N=2^%d) repeated for %.0f s on 1 host thread and "
-                      "%.0f s on %d host threads (batch-parallel), NTTCPU::ntt"
-                      % (polys, bits, logn, CPU_SECONDS, CPU_SECONDS, threads)}
+                      "%.0f s on %d host threads (%s), NTTCPU::%s"
+                      % (polys, bits, logn, CPU_SECONDS, CPU_SECONDS, threads, how, "intt" if inverse else "ntt")}
 
 
 # --------------------------------------------------------------------------- HBM traffic (PMC)
-def measure_traffic(config, api, out_of_place=False):
+def measure_traffic(config, api, out_of_place=False, direction="fwd"):
     """HBM bytes per call from the PMC counters, measured in THIS run: two short rocprofv3 --pmc child
     passes of this script (FETCH_SIZE, WRITE_SIZE -- separate passes, MI355X_MICROARCH.md), gfx950 x2
     correction on the fetch side.  Returns (bytes_per_call, detail) or (None, reason)."""
@@ -157,7 +172,7 @@ def measure_traffic(config, api, out_of_place=False):
             out = os.path.join(tmp, counter)
             cmd = [rocprof, "--pmc", counter, "-d", out, "-o", "pmc", "--", sys.executable,
                    os.path.join(ROOT, "bench.py"), "--config", config, "--api", api, "--steps", str(steps),
-                   "--warmup", "0", "--child"] + (["--out-of-place"] if out_of_place else [])
+                   "--warmup", "0", "--child", "--direction", direction] + (["--out-of-place"] if out_of_place else [])
             r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=180)
             dbs = glob.glob(out + "/**/*.db", recursive=True)
             if r.returncode != 0 or not dbs:
@@ -324,63 +339,74 @@ def build_case(g, cfg, rank, world, dev, api, inplace=True):
         x = splitmix64_mod(seed, batch * n, prm.modulus.value).astype(g.np_dtype(bits))
         d_in = g.to_device(x, dev)
         d_out = torch.empty_like(d_in)
-        table = g.to_device(prm.forward_table_device_order, dev)
-        c = g.ntt_configuration(n_power=logn, ntt_type=g.FORWARD, reduction_poly=poly)
+        inv = cfg.get("direction", "fwd") == "inv"
+        table = g.to_device(prm.inverse_table_device_order if inv else prm.forward_table_device_order, dev)
+        c = g.ntt_configuration(n_power=logn, ntt_type=g.INVERSE if inv else g.FORWARD, reduction_poly=poly,
+                                mod_inverse=prm.n_inv if inv else 0)
+        xf, xf_in = (g.GPU_INTT, g.GPU_INTT_Inplace) if inv else (g.GPU_NTT, g.GPU_NTT_Inplace)
         # the first call goes d_in -> d_out (the output the CPU leg checks); with `inplace` the timed calls are
         # GPU_NTT_Inplace on d_out (its contents stay residues below q), as the reference's benchmark times it
         src = d_out if inplace else d_in
+        mk_plan = lambda: g.NTTPlan(table, prm.modulus, logn, poly, g.INVERSE if inv else g.FORWARD,  # noqa: E731
+                                    mod_inverse=prm.n_inv if inv else None, batch_hint=batch)
         if api == "plan":
-            plan = g.NTTPlan(table, prm.modulus, logn, poly, g.FORWARD, batch_hint=batch)
+            plan = mk_plan()
             case["first"] = lambda: plan.execute(d_in, d_out, batch)
             case["step"] = lambda: plan.execute(src, d_out, batch)
             case["plan"] = plan
         else:
-            case["first"] = lambda: g.GPU_NTT(d_in, d_out, table, prm.modulus, c, batch)
-            case["step"] = (lambda: g.GPU_NTT_Inplace(d_out, table, prm.modulus, c, batch)) if inplace else \
-                           (lambda: g.GPU_NTT(d_in, d_out, table, prm.modulus, c, batch))
+            case["first"] = lambda: xf(d_in, d_out, table, prm.modulus, c, batch)
+            case["step"] = (lambda: xf_in(d_out, table, prm.modulus, c, batch)) if inplace else \
+                           (lambda: xf(d_in, d_out, table, prm.modulus, c, batch))
         def other_step():
             if api == "plan":
-                return (lambda: g.GPU_NTT_Inplace(d_out, table, prm.modulus, c, batch)) if inplace else \
-                       (lambda: g.GPU_NTT(d_in, d_out, table, prm.modulus, c, batch))
-            p2 = g.NTTPlan(table, prm.modulus, logn, poly, g.FORWARD, batch_hint=batch)
+                return (lambda: xf_in(d_out, table, prm.modulus, c, batch)) if inplace else \
+                       (lambda: xf(d_in, d_out, table, prm.modulus, c, batch))
+            p2 = mk_plan()
             case["plan"] = p2
             return lambda: p2.execute(src, d_out, batch)
         case.update(x=x, d_in=d_in, d_out=d_out, table=table, modulus=prm.modulus.value, other_step=other_step,
-                    run_shard=lambda a, b: g.GPU_NTT(a, b, table, prm.modulus, c, batch))
+                    run_shard=lambda a, b: xf(a, b, table, prm.modulus, c, batch))
     elif cfg["kind"] == "rns":
         rns = json.load(open(os.path.join(ROOT, "tests", "golden", "rns_c5.json")))
         mc = cfg["mod_count"]
         factors = [(e["q"], e["omega"], e["psi"]) for e in rns["primes"][:mc]]
         prms = [g.NTTParameters(logn, poly, bits, f) for f in factors]
+        inv = cfg.get("direction", "fwd") == "inv"
         tab = np.zeros(mc * n, dtype=np.uint64)
         for i, p in enumerate(prms):
-            tab[i * n:i * n + p.root_of_unity_size] = p.forward_table_device_order
+            tab[i * n:i * n + p.root_of_unity_size] = p.inverse_table_device_order if inv else p.forward_table_device_order
         x = np.concatenate([splitmix64_mod(seed, n, prms[p % mc].modulus.value, offset=p * n) for p in range(batch)])
         d_in = g.to_device(x, dev)
         d_out = torch.empty_like(d_in)
         table = g.to_device(tab, dev)
         mods = g.modulus_array_to_device([p.modulus for p in prms], bits, dev)
-        c = g.ntt_rns_configuration(n_power=logn, ntt_type=g.FORWARD, reduction_poly=poly)
+        ninv = g.to_device(np.array([p.n_inv for p in prms], dtype=np.uint64), dev)
+        c = g.ntt_rns_configuration(n_power=logn, ntt_type=g.INVERSE if inv else g.FORWARD, reduction_poly=poly,
+                                    mod_inverse=ninv if inv else None)
+        xf, xf_in = (g.GPU_INTT, g.GPU_INTT_Inplace) if inv else (g.GPU_NTT, g.GPU_NTT_Inplace)
         src = d_out if inplace else d_in
+        mk_plan = lambda: g.NTTPlan(table, [p.modulus for p in prms], logn, poly, g.INVERSE if inv else g.FORWARD,  # noqa: E731
+                                    mod_inverse=[p.n_inv for p in prms] if inv else None, batch_hint=batch)
         if api == "plan":
-            plan = g.NTTPlan(table, [p.modulus for p in prms], logn, poly, g.FORWARD, batch_hint=batch)
+            plan = mk_plan()
             case["first"] = lambda: plan.execute(d_in, d_out, batch)
             case["step"] = lambda: plan.execute(src, d_out, batch)
             case["plan"] = plan
         else:
-            case["first"] = lambda: g.GPU_NTT(d_in, d_out, table, mods, c, batch, mc)
-            case["step"] = (lambda: g.GPU_NTT_Inplace(d_out, table, mods, c, batch, mc)) if inplace else \
-                           (lambda: g.GPU_NTT(d_in, d_out, table, mods, c, batch, mc))
+            case["first"] = lambda: xf(d_in, d_out, table, mods, c, batch, mc)
+            case["step"] = (lambda: xf_in(d_out, table, mods, c, batch, mc)) if inplace else \
+                           (lambda: xf(d_in, d_out, table, mods, c, batch, mc))
         def other_step():
             if api == "plan":
-                return (lambda: g.GPU_NTT_Inplace(d_out, table, mods, c, batch, mc)) if inplace else \
-                       (lambda: g.GPU_NTT(d_in, d_out, table, mods, c, batch, mc))
-            p2 = g.NTTPlan(table, [p.modulus for p in prms], logn, poly, g.FORWARD, batch_hint=batch)
+                return (lambda: xf_in(d_out, table, mods, c, batch, mc)) if inplace else \
+                       (lambda: xf(d_in, d_out, table, mods, c, batch, mc))
+            p2 = mk_plan()
             case["plan"] = p2
             return lambda: p2.execute(src, d_out, batch)
         case.update(x=x, d_in=d_in, d_out=d_out, table=table, factors=factors, modulus=factors[0][0],
-                    other_step=other_step,
-                    run_shard=lambda a, b: g.GPU_NTT(a, b, table, mods, c, batch, mc))
+                    other_step=other_step, ninv=ninv,
+                    run_shard=lambda a, b: xf(a, b, table, mods, c, batch, mc))
     else:  # 4-step, forward + inverse pair on the transposed-order form the library entry point defines
         p4 = g.NTTParameters4Step(logn, bits)
         distinct = 4  # 4 distinct polynomials repeated: 8 GiB of splitmix on the host would take minutes
@@ -549,9 +575,9 @@ def sweep_points(args):
     return pts
 
 
-def sweep_case(g, kind, bits, logn, batch, dev, rank):
-    """(first, step, x0, y0-getter) of one sweep point: forward transform of `batch` polynomials of 2^logn, in place
-    for Merge (reference benchmark/bench_merge_ntt.cu:62), in -> out for 4-step (the entry point is out of place)."""
+def sweep_case(g, kind, bits, logn, batch, dev, rank, inverse=False):
+    """(first, step, x0, y0-getter) of one sweep point: forward (or inverse) transform of `batch` polynomials of 2^logn,
+    in place for Merge (reference benchmark/bench_merge_ntt.cu:62), in -> out for 4-step (the entry point is out of place)."""
     import torch
     n = 1 << logn
     seed = 0x5EED1000 + logn + 64 * rank
@@ -560,42 +586,55 @@ def sweep_case(g, kind, bits, logn, batch, dev, rank):
         x = splitmix64_mod(seed, batch * n, prm.modulus.value).astype(g.np_dtype(bits))
         d_in = g.to_device(x, dev)
         d_out = torch.empty_like(d_in)
-        table = g.to_device(prm.forward_table_device_order, dev)
-        c = g.ntt_configuration(n_power=logn, ntt_type=g.FORWARD, reduction_poly=g.X_N_minus)
-        first = lambda: g.GPU_NTT(d_in, d_out, table, prm.modulus, c, batch)  # noqa: E731
-        step = lambda: g.GPU_NTT_Inplace(d_out, table, prm.modulus, c, batch)  # noqa: E731
+        if inverse:
+            table = g.to_device(prm.inverse_table_device_order, dev)
+            c = g.ntt_configuration(n_power=logn, ntt_type=g.INVERSE, reduction_poly=g.X_N_minus, mod_inverse=prm.n_inv)
+            first = lambda: g.GPU_INTT(d_in, d_out, table, prm.modulus, c, batch)  # noqa: E731
+            step = lambda: g.GPU_INTT_Inplace(d_out, table, prm.modulus, c, batch)  # noqa: E731
+        else:
+            table = g.to_device(prm.forward_table_device_order, dev)
+            c = g.ntt_configuration(n_power=logn, ntt_type=g.FORWARD, reduction_poly=g.X_N_minus)
+            first = lambda: g.GPU_NTT(d_in, d_out, table, prm.modulus, c, batch)  # noqa: E731
+            step = lambda: g.GPU_NTT_Inplace(d_out, table, prm.modulus, c, batch)  # noqa: E731
         return first, step, x[:n], (lambda: g.to_host(d_out)[:n].copy()), [d_in, d_out, table]
     p4 = g.NTTParameters4Step(logn, bits)
     distinct = min(batch, 4)
     base = np.concatenate([splitmix64_mod(seed + 7 * i, n, p4.modulus.value) for i in range(distinct)]).astype(g.np_dtype(bits))
     d_in = g.to_device(base, dev).repeat(batch // distinct)
     d_out = torch.empty_like(d_in)
-    tf = [g.to_device(t, dev) for t in p4.tables["fwd"]]
-    cf = g.ntt4step_configuration(n_power=logn, ntt_type=g.FORWARD)
-    step = lambda: g.GPU_4STEP_NTT(d_in, d_out, *tf, p4.modulus, cf, batch)  # noqa: E731
-
-    # the call reads its input as the n2 x n1 transpose of the natural-order polynomial and writes the spectrum n1 x n2:
-    # NTT_4STEP_CPU::ntt(x_nat) is polynomial 0 of THE OUTPUT BUFFER transposed (what the reference example's closing
-    # GPU_Transpose does, test_4step_ntt.cu:170-178)
-    x_nat = np.ascontiguousarray(base[:n].reshape(p4.n2, p4.n1).T).reshape(-1)
+    tabs = [g.to_device(t, dev) for t in p4.tables["inv" if inverse else "fwd"]]
+    cf = g.ntt4step_configuration(n_power=logn, ntt_type=g.INVERSE if inverse else g.FORWARD,
+                                  mod_inverse=p4.n_inv if inverse else 0)
+    step = lambda: g.GPU_4STEP_NTT(d_in, d_out, *tabs, p4.modulus, cf, batch)  # noqa: E731
 
     def out0():
         torch.cuda.synchronize()
         return g.to_host(d_out[:n].view(p4.n1, p4.n2).t().contiguous().view(-1))
-    return step, step, x_nat, out0, [d_in, d_out] + tf
+    if inverse:
+        # the inverse call reads what NTT_4STEP_CPU::intt_first_transpose makes of the spectrum y and one closing
+        # GPU_Transpose gives NTT_4STEP_CPU::intt(y) (test_4step_intt.cu:81-179): the CPU leg gets y itself, found by
+        # undoing the first transpose of polynomial 0 of the input buffer: flat[i * n2 + j] = y[i + j * n1]
+        y_nat = np.ascontiguousarray(base[:n].reshape(p4.n1, p4.n2).T).reshape(-1)
+        return step, step, y_nat, out0, [d_in, d_out] + tabs
+    # the call reads its input as the n2 x n1 transpose of the natural-order polynomial and writes the spectrum n1 x n2:
+    # NTT_4STEP_CPU::ntt(x_nat) is polynomial 0 of THE OUTPUT BUFFER transposed (what the reference example's closing
+    # GPU_Transpose does, test_4step_ntt.cu:170-178)
+    x_nat = np.ascontiguousarray(base[:n].reshape(p4.n2, p4.n1).T).reshape(-1)
+    return step, step, x_nat, out0, [d_in, d_out] + tabs
 
 
-def sweep_cpu(kind, bits, logn, x0, y0):
+def sweep_cpu(kind, bits, logn, x0, y0, inverse=False):
     """reference CPU transform of ONE polynomial of this ring on one host core (>= 1 transform, ~0.5 s); also the
     bit-exact check of the GPU's polynomial 0"""
     from oracle import oracle as O
     B = O.Ref(bits) if O.have_ref() else O.Port(bits)
     if kind == "merge":
         prm = B.merge_params(logn, O.X_N_minus)
-        run = lambda: B.merge_ntt(x0, prm)  # noqa: E731
+        run = lambda: B.merge_ntt(x0, prm, inverse)  # noqa: E731
     else:
         prm = B.fourstep_params(logn)
-        run = (lambda: B.fourstep_run(x0, prm, 0)) if O.have_ref() else (lambda: B.fourstep_ntt(x0, prm))
+        run = (lambda: B.fourstep_run(x0, prm, 1 if inverse else 0)) if O.have_ref() else \
+              (lambda: B.fourstep_ntt(x0, prm, inverse))
     t0 = time.perf_counter()
     y = run()
     k = 1
@@ -626,7 +665,7 @@ def sweep_traffic(args, points):
             cmd = [rocprof, "--pmc", counter, "-d", out, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
                    "--sweep", "--child", "--steps", str(calls), "--sweep-kinds", args.sweep_kinds, "--sweep-bits",
                    args.sweep_bits, "--sweep-min", str(args.sweep_min), "--sweep-max", str(args.sweep_max),
-                   "--sweep-log-coeffs", str(args.sweep_log_coeffs)]
+                   "--sweep-log-coeffs", str(args.sweep_log_coeffs), "--direction", args.direction]
             r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True,
                                timeout=1500)
             dbs = glob.glob(out + "/**/*.db", recursive=True)
@@ -665,7 +704,7 @@ def run_sweep(g, args, dist_mod, dist, rank, world, dev):
     if args.child:
         mark = torch.empty(1, dtype=torch.float64, device=dev)  # (torch.zeros would itself launch the mark kernel)
         for k, (kind, bits, logn, batch) in enumerate(points):
-            first, step, _, _, keep = sweep_case(g, kind, bits, logn, batch, dev, rank)
+            first, step, _, _, keep = sweep_case(g, kind, bits, logn, batch, dev, rank, args.direction == "inv")
             torch.cuda.synchronize()
             mark.fill_(float(k))
             for _ in range(args.steps):
@@ -677,7 +716,7 @@ def run_sweep(g, args, dist_mod, dist, rank, world, dev):
     if world == 1 and not args.no_traffic:
         traffic, tinfo = sweep_traffic(args, points)
     for k, (kind, bits, logn, batch) in enumerate(points):
-        first, step, x0, y0_get, keep = sweep_case(g, kind, bits, logn, batch, dev, rank)
+        first, step, x0, y0_get, keep = sweep_case(g, kind, bits, logn, batch, dev, rank, args.direction == "inv")
         first()
         torch.cuda.synchronize()
         y0 = y0_get() if rank == 0 else None
@@ -716,7 +755,8 @@ def run_sweep(g, args, dist_mod, dist, rank, world, dev):
             call_ms = dev_ms / steps
             achieved = alg / (call_ms * 1e-3) / 1e9
             line = {"sweep": True, "algo": kind, "dtype": "u%d" % bits, "log2N": logn, "batch_per_gpu": batch,
-                    "n_gpus": world, "metric": "forward-NTTs/sec + achieved HBM GB/s", "unit": "NTT/s",
+                    "n_gpus": world, "direction": args.direction,
+                    "metric": "%s-NTTs/sec + achieved HBM GB/s" % ("inverse" if args.direction == "inv" else "forward"), "unit": "NTT/s",
                     "value": world * batch * steps / wall, "steps": steps, "ms_per_step": wall * 1e3 / steps,
                     "in_place": kind == "merge", "scaling": "weak", "data": "synthetic",
                     "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -727,7 +767,7 @@ def run_sweep(g, args, dist_mod, dist, rank, world, dev):
             if k == 0:
                 line["roofline"]["traffic_info"] = tinfo
             if not args.no_cpu_baseline and world == 1:
-                line["cpu_baseline"] = sweep_cpu(kind, bits, logn, x0, y0)
+                line["cpu_baseline"] = sweep_cpu(kind, bits, logn, x0, y0, args.direction == "inv")
                 if not line["cpu_baseline"]["gpu_output_bit_exact"]:
                     raise SystemExit("bench --sweep: GPU result differs from the CPU reference path at %s 2^%d" % (kind, logn))
             print(json.dumps(line), flush=True)
@@ -749,6 +789,9 @@ def main():
     ap.add_argument("--no-power", action="store_true")
     ap.add_argument("--out-of-place", action="store_true",
                     help="time GPU_NTT(in, out) instead of the in-place call the reference's own benchmark times")
+    ap.add_argument("--direction", choices=("fwd", "inv"), default="fwd",
+                    help="Merge configs (c2, c4, c5) and --sweep: time GPU_INTT instead of GPU_NTT "
+                         "(reference benchmark/bench_merge_ntt.cu:137-141 times both); c3 is a forward + inverse pair")
     ap.add_argument("--cpu-polys", type=int, default=64)
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)  # PMC child pass: calls only
     ap.add_argument("--sweep", action="store_true",
@@ -759,7 +802,11 @@ def main():
     ap.add_argument("--sweep-max", type=int, default=24)
     ap.add_argument("--sweep-log-coeffs", type=int, default=26, help="log2 of the coefficients per GPU and call")
     args = ap.parse_args()
-    cfg = dict(CONFIGS[args.config], name=args.config)
+    cfg = dict(CONFIGS[args.config], name=args.config, direction=args.direction)
+    if args.direction == "inv" and cfg["kind"] != "4step":
+        cfg["metric"] = cfg["metric"].replace("forward-NTTs/sec", "inverse-NTTs/sec")
+        cfg["workload"] = cfg["workload"].replace(" forward", " inverse") if " forward" in cfg["workload"] \
+            else cfg["workload"] + " [inverse]"
     if args.config == "c3" and args.steps == 200:
         args.steps, args.warmup = 10, 2  # a step is ~25 ms and 16 GiB of traffic
 
@@ -873,7 +920,7 @@ def main():
             achieved = alg_bytes / (call_ms * 1e-3) / 1e9
             traffic, traffic_info = None, None
             if world == 1 and not args.no_traffic:
-                traffic, traffic_info = measure_traffic(args.config, args.api, args.out_of_place)
+                traffic, traffic_info = measure_traffic(args.config, args.api, args.out_of_place, args.direction)
             quoted = False
             if traffic is None:
                 reason = traffic_info

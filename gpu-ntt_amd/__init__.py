@@ -95,7 +95,7 @@ EXPORTED_SYMBOLS = ["gpuntt_last_error", "gpuntt_version"] + [
               "4step_params", "plan_workspace_bytes", "plan_create", "plan_execute", "plan_fast_path",
               "plan_destroy", "operator_gpu", "4step_plan_workspace_bytes", "4step_plan_create",
               "4step_plan_execute", "4step_plan_fast_path", "4step_plan_destroy",
-              "generate_power_table", "generate_4step_w")
+              "generate_power_table", "generate_4step_w", "butterfly_unit")
     for s in ("u32", "u64")] + ["gpuntt_release_workspaces", "gpuntt_set_option"]
 
 # GPUNTT_* environment variables of the A/B scripts and tests -> library options.  The C++ library reads no
@@ -571,6 +571,16 @@ def operator_gpu(op, a, b, modulus):
     fn = getattr(lib, "gpuntt_operator_gpu_u%d" % modulus.bits)
     _check(fn(int(op), _ptr(a), _ptr(b), _ptr(out), modulus.c(), ctypes.c_uint64(a.numel()), _stream(None)))
     return out
+
+
+def butterfly_unit(u, v, roots, modulus, gentleman_sande=False):
+    """diagnostic: the public device helpers CooleyTukeyUnit / GentlemanSandeUnit (reference ntt.cuh:69-92) applied to
+    the pairs (u[i], v[i]) with roots[i], in place on the device tensors"""
+    lib = load_library()
+    _require_gpu(u, v, roots)
+    fn = getattr(lib, "gpuntt_butterfly_unit_u%d" % modulus.bits)
+    _check(fn(int(bool(gentleman_sande)), _ptr(u), _ptr(v), _ptr(roots), modulus.c(), ctypes.c_uint64(u.numel()),
+              _stream(None)))
 
 
 # ------------------------------------------------------------------ multi-GPU batch shard

@@ -361,6 +361,38 @@ namespace
         });
     }
 
+    // the public device butterflies CooleyTukeyUnit / GentlemanSandeUnit (gpuntt/ntt_merge/ntt.cuh) applied pairwise
+    template <typename T>
+    __global__ __launch_bounds__(256) void butterfly_unit_apply(int gs, T* u, T* v, const T* roots, Modulus<T> m,
+                                                                unsigned long long count)
+    {
+        for (unsigned long long i = blockIdx.x * 256ull + threadIdx.x; i < count;
+             i += static_cast<unsigned long long>(gridDim.x) * 256ull)
+        {
+            T U = u[i], V = v[i];
+            if (gs)
+                GentlemanSandeUnit<T>(U, V, roots[i], m);
+            else
+                CooleyTukeyUnit<T>(U, V, roots[i], m);
+            u[i] = U;
+            v[i] = V;
+        }
+    }
+    template <typename T, typename CM>
+    int butterfly_unit(int gs, T* u, T* v, const T* roots, const CM& cm, uint64_t count, void* stream)
+    {
+        return guarded([&] {
+            if (count == 0)
+                return;
+            unsigned long long blocks = (count + 255) / 256;
+            if (blocks > 65536)
+                blocks = 65536;
+            hipLaunchKernelGGL((butterfly_unit_apply<T>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0,
+                               static_cast<hipStream_t>(stream), gs, u, v, roots, to_mod<T>(cm), count);
+            GPUNTT_HIP_CHECK(hipGetLastError());
+        });
+    }
+
     template <typename T, typename CM>
     int plan_create(gpuntt_plan** plan, const T* table, const CM* moduli, int mod_count, int n_power, int poly,
                     int ntt_type, const T* ninv, int batch_hint, void* ws, void* stream)
@@ -622,6 +654,13 @@ extern "C"
     {                                                                                             \
         GPUNTT_NEED(a, out)                                                                       \
         return operator_gpu<T>(op, a, b, out, modulus, count, stream);                            \
+    }                                                                                             \
+    int gpuntt_butterfly_unit_##S(int gentleman_sande, T* u, T* v, const T* roots, CM modulus,    \
+                                  uint64_t count, void* stream)                                   \
+    {                                                                                             \
+        GPUNTT_NEED(u, v)                                                                         \
+        GPUNTT_NEED(roots, roots)                                                                 \
+        return butterfly_unit<T>(gentleman_sande, u, v, roots, modulus, count, stream);           \
     }
 
     GPUNTT_C_API(u32, uint32_t, gpuntt_modulus32)

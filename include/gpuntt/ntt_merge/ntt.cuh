@@ -20,13 +20,14 @@
 //   * signed instantiations: GPU_NTT<Data64s> takes inputs in (-q, q); GPU_INTT<Data64s>
 //     returns centred residues
 //   * asynchronous on cfg.stream; in == out allowed.  The fast kernels read twiddles that every call
-//     re-derives from the caller's table into a library-owned scratch buffer kept per (device, stream):
-//     the first call on a stream (and a call that needs a larger buffer) allocates it with hipMalloc,
-//     a growing call also synchronises that stream once.  A host thread holds the buffer's lock from
-//     the preparation launch to its last kernel launch, so threads sharing a stream are serialised
-//     there and stream order keeps their launches apart.  GPU_NTT_ReleaseWorkspaces() frees the
-//     buffers.  Callers that want zero allocation / synchronisation / preparation per call use
-//     NTTPlan<T> below (caller-owned workspace, tables prepared once).
+//     re-derives from the caller's table into a library-owned scratch buffer: one chain per (device, stream),
+//     and one per capture while a stream is being captured into a hipGraph.  First use / a larger ring
+//     allocates with hipMalloc; NOTHING is freed, reused for another chain or synchronised on before
+//     GPU_NTT_ReleaseWorkspaces(), so a graph captured from these calls can be replayed at any time on any
+//     stream.  A host thread holds the chain's lock from the preparation launch to its last kernel launch,
+//     so threads sharing a stream are serialised there and stream order keeps their launches apart.
+//     Callers that want zero allocation / preparation per call use NTTPlan<T> below (caller-owned
+//     workspace, tables prepared once).
 //   * throws std::invalid_argument("Invalid n_power range!") / ("Invalid ntt_layout!"),
 //     HipException (alias CudaException) on a failed launch
 #pragma once
@@ -58,6 +59,27 @@ namespace gpuntt
         Ninverse<T>* mod_inverse;
         stream_t stream;
     };
+
+    // ---- public device butterflies (reference ntt.cuh:69-92): for caller kernels built on OPERATOR_GPU<T> ----
+    // Cooley-Tukey: U' = U + V * root, V' = U - V * root; Gentleman-Sande: U' = U + V, V' = (U - V) * root; all mod q,
+    // canonical in, canonical out.  (The library's own kernels use lazy-range butterflies with prepared twiddles.)
+    template <typename T>
+    __device__ __forceinline__ void CooleyTukeyUnit(T& U, T& V, const Root<T>& root, const Modulus<T>& modulus)
+    {
+        const T u_ = U;
+        const T v_ = OPERATOR_GPU<T>::mult(V, root, modulus);
+        U = OPERATOR_GPU<T>::add(u_, v_, modulus);
+        V = OPERATOR_GPU<T>::sub(u_, v_, modulus);
+    }
+
+    template <typename T>
+    __device__ __forceinline__ void GentlemanSandeUnit(T& U, T& V, const Root<T>& root, const Modulus<T>& modulus)
+    {
+        const T u_ = U;
+        const T v_ = V;
+        U = OPERATOR_GPU<T>::add(u_, v_, modulus);
+        V = OPERATOR_GPU<T>::mult(OPERATOR_GPU<T>::sub(u_, v_, modulus), root, modulus);
+    }
 
     // ---- single modulus (passed by value from the host) ---------------------------------
     template <typename T>

@@ -280,6 +280,13 @@ extern "C"
     int gpuntt_operator_gpu_u64(int op, const uint64_t* a, const uint64_t* b, uint64_t* out,
                                 gpuntt_modulus64 modulus, uint64_t count, void* stream);
 
+    /* diagnostic: the public device butterflies CooleyTukeyUnit (gentleman_sande = 0) / GentlemanSandeUnit (1)
+     * (reference src/include/gpuntt/ntt_merge/ntt.cuh:69-92) applied to the pairs (u[i], v[i]) with roots[i], in place */
+    int gpuntt_butterfly_unit_u32(int gentleman_sande, uint32_t* u, uint32_t* v, const uint32_t* roots,
+                                  gpuntt_modulus32 modulus, uint64_t count, void* stream);
+    int gpuntt_butterfly_unit_u64(int gentleman_sande, uint64_t* u, uint64_t* v, const uint64_t* roots,
+                                  gpuntt_modulus64 modulus, uint64_t count, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -277,6 +277,13 @@ class Ref:
                             x.size // prm["n"])
         return out
 
+    def merge_ntt_mt(self, x, prm, inverse=False, nthreads=1):
+        """the same transforms, the batch loop on `nthreads` OpenMP threads inside the reference build"""
+        x = np.ascontiguousarray(x, dtype=self.T)
+        out = np.empty_like(x)
+        self.f("merge_run_mt")(prm["handle"], int(inverse), _ptr(x), _ptr(out), x.size // prm["n"], int(nthreads))
+        return out
+
     def pointwise(self, a, b, prm):
         out = np.empty_like(a)
         self.f("pointwise")(prm["handle"], _ptr(a), _ptr(b), _ptr(out))

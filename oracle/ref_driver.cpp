@@ -109,6 +109,22 @@ namespace
         }
     }
 
+    // all-core leg of bench.py's cpu_baseline: the same NTTCPU<T>::ntt / ::intt per polynomial (it only READS its
+    // parameters), the batch loop shared out over `nthreads` OpenMP threads
+    template <typename T>
+    void merge_run_mt(void* h_, int inverse, const T* in, T* out, int batch, int nthreads)
+    {
+        auto* h = static_cast<MergeHandle<T>*>(h_);
+        size_t n = h->params.n;
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 1)
+        for (int b = 0; b < batch; b++)
+        {
+            std::vector<T> v(in + b * n, in + (b + 1) * n);
+            std::vector<T> r = inverse ? h->cpu.intt(v) : h->cpu.ntt(v);
+            std::memcpy(out + b * n, r.data(), n * sizeof(T));
+        }
+    }
+
     template <typename T> void* fourstep_create(int logn)
     {
         NTTParameters4Step<T> p(logn, ReductionPolynomial::X_N_minus);
@@ -209,6 +225,11 @@ namespace
     void ref##S##_merge_run(void* h, int inverse, const T* in, T* out, int batch)    \
     {                                                                                \
         merge_run<T>(h, inverse, in, out, batch);                                    \
+    }                                                                                \
+    void ref##S##_merge_run_mt(void* h, int inverse, const T* in, T* out, int batch, \
+                               int nthreads)                                         \
+    {                                                                                \
+        merge_run_mt<T>(h, inverse, in, out, batch, nthreads);                       \
     }                                                                                \
     void ref##S##_pointwise(void* h, T* a, T* b, T* out)                             \
     {                                                                                \

@@ -67,6 +67,19 @@ class MergeCase:
         return g.to_host(d_out)
 
 
+def oracle_batch(cases, x, inverse=False):
+    """NTTCPU::ntt / ::intt of EVERY polynomial of a batch -- polynomial p under cases[p % len(cases)] -- through the
+    oracle's OpenMP batch entry (oracle/ntt_oracle_impl.h: merge_batch) on all host threads; returns a new array."""
+    import os
+    c0 = cases[0]
+    n = c0.n
+    size = c0.oprm["root_size"]
+    tables = np.concatenate([np.ascontiguousarray(c.oprm["inv" if inverse else "fwd"], dtype=c0.P.T) for c in cases])
+    y = np.array(x, dtype=c0.P.T, copy=True, order="C")
+    c0.P.merge_batch(y, c0.logn, c0.poly, inverse, tables, size, [c.q for c in cases], os.cpu_count() or 1)
+    return y
+
+
 def _is_probable_prime(n):
     if n < 2:
         return False
@@ -93,12 +106,15 @@ def _is_probable_prime(n):
     return True
 
 
-def find_ntt_factors(bits, logn, skip=0):
+def find_ntt_factors(bits, logn, skip=0, clear_of_top=False):
     """(q, omega, psi) for an NTT prime with exactly `bits` bits and 2^(logn+1) | q-1
     (psi of order 2N, omega = psi^2), found by search -- used to exercise moduli the
-    reference's pools do not contain (61/62-bit: no lazy headroom)."""
+    reference's pools do not contain (61/62-bit: no lazy headroom).  clear_of_top: start 2^(bits-40) below
+    2^bits -- closer than ~2^(bits-46) the double log2() behind Modulus<T>::bit rounds up to `bits` exactly
+    and the modulus gets bit = bits + 1; for tiny rings the first primes found lie that close."""
     step = 1 << (logn + 1)
-    q = ((1 << bits) - 1) // step * step + 1
+    top = (1 << bits) - 1 - ((1 << (bits - 40)) if (clear_of_top and bits > 40) else 0)
+    q = top // step * step + 1
     found = 0
     while True:
         if q.bit_length() < bits:

@@ -25,7 +25,7 @@ def g(pkg):
 def _distinct_factors(widths, logn):
     seen, out = {}, []
     for b in widths:
-        out.append(find_ntt_factors(b, logn, skip=seen.get(b, 0)))
+        out.append(find_ntt_factors(b, logn, skip=seen.get(b, 0), clear_of_top=True))
         seen[b] = seen.get(b, 0) + 1
     return out
 
@@ -456,7 +456,7 @@ def test_rns_rings_below_one_tile_on_the_lazy_kernels(g, bits):
             iplan.close()
         # rings of 2 .. 8 coefficients with mod_count > 1 stay on the generic kernels (a thread's 16 coefficients would span
         # polynomials of different moduli): refused under fast-strict, exact on the default path
-        cases, d_fwd, d_inv = _rns_stack(g, bits, 3, [60, 61, 60] if bits == 64 else [30, 29, 30], O.X_N_plus)
+        cases, d_fwd, d_inv = _rns_stack(g, bits, 3, [60, 59, 60] if bits == 64 else [30, 29, 30], O.X_N_plus)
         mods = g.modulus_array_to_device([c.prm.modulus for c in cases], bits)
         x = np.concatenate([cases[p % 3].P.splitmix(98900 + p, 0, 8, cases[p % 3].q) for p in range(700)])
         want = np.concatenate([cases[p % 3].P.merge_ntt(x[p * 8:(p + 1) * 8], cases[p % 3].oprm) for p in range(700)])
@@ -470,3 +470,32 @@ def test_rns_rings_below_one_tile_on_the_lazy_kernels(g, bits):
         assert np.array_equal(g.to_host(d), want)
     finally:
         g.set_option("path", os.environ.get("GPUNTT_PATH", "default"))
+
+
+# ---------------------------------------------------------------- public device butterflies
+@pytest.mark.parametrize("bits", [64, 32])
+def test_public_device_butterfly_units(g, bits):
+    """CooleyTukeyUnit / GentlemanSandeUnit (reference src/include/gpuntt/ntt_merge/ntt.cuh:69-92) are part of the public
+    header: a caller kernel built on them compiles and computes U' = U + V*w, V' = U - V*w / U' = U + V, V' = (U - V)*w
+    (mod q) -- checked on the device against Python integers, pool prime and a 62- / 30-bit prime."""
+    import torch
+    rng = np.random.default_rng(bits)
+    for q in ((576460756061519873, find_ntt_factors(62, 10)[0]) if bits == 64 else (469762049, find_ntt_factors(30, 10)[0])):
+        m = g.Modulus(q, bits=bits)
+        cnt = 5000
+        U, V, W = (rng.integers(0, q, size=cnt, dtype=np.uint64) for _ in range(3))
+        U[:3], V[:3], W[:3] = (0, q - 1, q - 1), (q - 1, q - 1, 0), (q - 1, 1, q - 1)
+        dt = g.np_dtype(bits)
+        for gs in (False, True):
+            du, dv, dw = (g.to_device(a.astype(dt)) for a in (U, V, W))
+            g.butterfly_unit(du, dv, dw, m, gentleman_sande=gs)
+            torch.cuda.synchronize()
+            u, v, w = ([int(t) for t in a] for a in (U, V, W))
+            if gs:
+                wu = [(a + b) % q for a, b in zip(u, v)]
+                wv = [((a - b) % q) * c % q for a, b, c in zip(u, v, w)]
+            else:
+                wu = [(a + b * c) % q for a, b, c in zip(u, v, w)]
+                wv = [(a - b * c) % q for a, b, c in zip(u, v, w)]
+            assert [int(t) for t in g.to_host(du)] == wu, (bits, q, gs)
+            assert [int(t) for t in g.to_host(dv)] == wv, (bits, q, gs)
