@@ -757,7 +757,7 @@ namespace gpuntt
                 // also checks the caller's tables and hands the call to the generic kernels when they are not the tables of
                 // one root (prep.hip)
                 const host::FourStepVeto veto = fourstep_veto<T>(l1, l2, stream);
-                guess = host::rns_guess(mods, 1, static_cast<int>(sizeof(T)) | 0x40, ntt_type == INVERSE); // (0x40: the 4-step entry keeps its own slot)
+                guess = host::rns_guess(mods, 1, static_cast<int>(sizeof(T)) | 0x40, ntt_type == INVERSE, nullptr, true); // (0x40: the 4-step entry keeps its own slot)
                 auto enqueue = [&](int family, const unsigned** flag_out) {
                     if (ntt_type == FORWARD)
                         return fourstep_run_lazy<T, false>(in, out, n1_table, n2_table, w_table, Modulus<T>(), T(0), n_power, l1, l2,

@@ -106,19 +106,20 @@ namespace gpuntt
                          bool negacyclic, int perm_tile_log, const T* ninv_arr, lazy::Tw<T>* ws_ninv,
                          unsigned* go_flag, lazy::NormConst* norm_arr, hipStream_t stream,
                          const int* mod_order = nullptr, const T* fold_ninv_single = nullptr,
-                         bool fold_ninv_rns = false, unsigned* host_state = nullptr, bool allow_31q = false);
+                         bool fold_ninv_rns = false, unsigned* host_state = nullptr, bool allow_31q = false,
+                         unsigned family = 0u, const kern::SlowArgs<T>* slow = nullptr);
 
-        // Drop-in RNS calls keep their moduli in device memory; the preparation kernel classifies them (four-state go-flag,
-        // merge_lazy_kernels.hpp).  Enqueueing EVERY kernel family behind that flag costs a kernel boundary (~1.5 us) per
-        // family and pass although one family runs, so the host PREDICTS the family from what the same stack -- same
-        // device, moduli pointer and mod_count -- needed the last time: the preparation kernel also writes the state to a
-        // host-mapped word (`state_out`), read here WITHOUT any synchronisation (an older value is as good).  Only the
-        // predicted lazy family is enqueued, and behind it the generic kernels with "return if the flag names the predicted
-        // state": a wrong or stale prediction (first call, moduli rewritten in place, a captured graph replayed after the
-        // moduli changed) is served by the Barrett kernels -- slower, never wrong -- and corrected on the next call.  A
-        // stack that misses twice keeps the all-families form.  all_families: enqueue every lazy family + the generic
-        // kernels behind "return if the flag is not GO_GENERIC" (also: option rns_predict = 0, path = fast-strict, a full
-        // prediction table).
+        // Drop-in RNS calls keep their moduli in device memory; the preparation kernel classifies them (go-flag states,
+        // merge_lazy_kernels.hpp).  The host PREDICTS the lazy family from what the same stack -- same device, moduli
+        // pointer, mod_order, mod_count, direction -- needed before: the preparation kernel writes the state to a host-mapped
+        // word (`state_out`), read here WITHOUT any synchronisation (an older value is as good).  ONLY the predicted family is
+        // enqueued; it also serves every narrower stack (kern::family_rank), so the prediction widens at once and narrows
+        // only after 16 calls in a row that needed less.  A stack the enqueued family cannot serve (first call of a stack
+        // with a 61- / 62-bit prime, moduli rewritten in place with wider ones, a captured graph replayed after the moduli
+        // changed, moduli outside the documented domain) is transformed by the preparation kernel ITSELF (kern::SlowArgs:
+        // slow, never wrong) -- no generic launch behind any Merge call.  all_families: every lazy family behind the exact
+        // state (option rns_predict = 0, path = fast-strict, a full prediction table); the 4-step and PerCoefficient entry
+        // points keep the generic kernels behind their calls.
         struct RnsGuess
         {
             unsigned state;      // predicted go-flag state (kern::GO_*); meaningful when !all_families
@@ -126,15 +127,20 @@ namespace gpuntt
             unsigned* state_out; // device pointer of the host-mapped word for the preparation kernel, or nullptr
         };
         // order: the mod_order array of a *_Modulus_Ordered call (a different subset of the stack may classify differently), else nullptr
-        RnsGuess rns_guess(const void* moduli_device, int mod_count, int word_bytes, bool inverse, const void* order = nullptr);
+        // exact (the 4-step entry point, whose kernels match the go-flag state exactly and keep the generic kernels behind
+        // them): predict the state seen last, as it stands
+        RnsGuess rns_guess(const void* moduli_device, int mod_count, int word_bytes, bool inverse, const void* order = nullptr,
+                           bool exact = false);
         extern template void launch_prep<uint64_t>(const uint64_t*, lazy::Tw64*, const Modulus<uint64_t>*,
                                                    uint64_t, int, int, bool, int, const uint64_t*,
                                                    lazy::Tw64*, unsigned*, lazy::NormConst*, hipStream_t, const int*,
-                                                   const uint64_t*, bool, unsigned*, bool);
+                                                   const uint64_t*, bool, unsigned*, bool, unsigned,
+                                                   const kern::SlowArgs<uint64_t>*);
         extern template void launch_prep<uint32_t>(const uint32_t*, lazy::Tw32*, const Modulus<uint32_t>*,
                                                    uint32_t, int, int, bool, int, const uint32_t*,
                                                    lazy::Tw32*, unsigned*, lazy::NormConst*, hipStream_t, const int*,
-                                                   const uint32_t*, bool, unsigned*, bool);
+                                                   const uint32_t*, bool, unsigned*, bool, unsigned,
+                                                   const kern::SlowArgs<uint32_t>*);
 
         // 4-step transform of a ring that fits one tile in one launch: 64-bit 2^12 (tile 12), 2^13 (tile 13), 2^14 forward
         // (tile 14); 32-bit 2^12 (tile 12), 2^13 (tile 13), 2^14 (tile 14).  a.tw = Merge table of the ring

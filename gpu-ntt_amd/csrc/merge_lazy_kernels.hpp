@@ -1165,6 +1165,32 @@ namespace gpuntt
         // GO_LAZY_31Q (forward Merge calls of 64-bit words only): every modulus of the stack has 31 q < 2^64 -- the 31 q
         // kernels (a range correction every fourth stage), what NTTPlan picks from host moduli for the same stack
         constexpr unsigned GO_GENERIC = 0u, GO_LAZY = 1u, GO_LAZY_8Q = 2u, GO_LAZY_4Q = 3u, GO_LAZY_31Q = 4u;
+        // generality of a lazy family: a family serves every stack a narrower one serves (31 q needs 31 q < 2^64, 16 q
+        // bit <= 60, 8 q bit <= 61, 4 q bit <= 62).  GO_GENERIC: -1
+        __host__ __device__ constexpr int family_rank(unsigned state)
+        {
+            return state == GO_LAZY_31Q ? 0 : (state == GO_LAZY ? 1 : (state == GO_LAZY_8Q ? 2 : (state == GO_LAZY_4Q ? 3 : -1)));
+        }
+        // Drop-in RNS Merge calls carry their own fall-back INSIDE the preparation kernel (prep.hip: prep_twiddles): when
+        // the stack the caller's buffer holds does not fit the one lazy family the host enqueued -- first call of a stack with
+        // a 61- / 62-bit prime, moduli rewritten in place with wider ones, moduli outside the documented domain -- the
+        // preparation kernel itself transforms the batch, one polynomial per block, stage by stage through global memory
+        // with the public Barrett arithmetic (OPERATOR_GPU<T>), and publishes GO_GENERIC so that every fast kernel behind
+        // it returns.  Slow (milliseconds), rare, never wrong -- and no generic shadow launch behind any call (rounds 3-4
+        // paid two skipped launches, ~6 us each, on EVERY drop-in RNS call).
+        template <typename T> struct SlowArgs
+        {
+            const void* in;
+            T* out;
+            const T* mul_in;       // GPU_PolyMul: multiplied into the forward result
+            const int* poly_order; // *_Poly_Ordered: polynomial p lives in slot poly_order[p]
+            unsigned long long polys;
+            unsigned flags;        // F_SIGNED_IN | F_SCALE | F_CENTERED
+            int inverse;
+            int enabled;           // 0: publish GO_GENERIC only (path = fast-strict: the tests want the lazy families to own the call)
+            int force;             // test hook (option rns_force_fallback): treat every stack as not fitting
+        };
+
         template <typename T, int LIM> __device__ __forceinline__ bool not_my_call(const unsigned* go_flag, unsigned flags = 0u)
         {
             constexpr unsigned mine = sizeof(T) != 8 ? GO_LAZY

@@ -132,7 +132,9 @@ namespace gpuntt
                                             const Modulus<TU>* mods, int mod_count, const TU* ninv_dev,
                                             int n_power, ReductionPolynomial poly, int batch_size,
                                             hipStream_t stream, const int* mod_order = nullptr,
-                                            const TU* ninv_single = nullptr, unsigned* host_state = nullptr)
+                                            const TU* ninv_single = nullptr, const host::RnsGuess* guess = nullptr,
+                                            unsigned io_flags = 0u, const int* poly_order = nullptr,
+                                            const TU* mul_in = nullptr)
         {
             using TW = lazy::Tw<TU>;
             const bool neg = (poly == ReductionPolynomial::X_N_plus);
@@ -161,9 +163,29 @@ namespace gpuntt
             // option lim31 is read ONCE per call: the preparation kernel may name the 31 q family only if
             // run_transform_lazy_rns enqueues it (two reads could disagree when another thread flips the option)
             const bool allow_31q = mods != nullptr && host::lazy_lim31_enabled();
-            host::launch_prep<TU>(roots, ws, mods, m.value, mod_count, n_power, neg, perm_tile_log, ninv_dev,
+            // drop-in RNS call: the family the host enqueues behind the preparation launch (0: every family) and the
+            // fall-back the preparation kernel runs itself when the stack does not fit it (kern::SlowArgs)
+            unsigned family = 0u;
+            kern::SlowArgs<TU> slow{};
+            int perm = perm_tile_log;
+            if (mods != nullptr && guess != nullptr)
+            {
+                family = guess->all_families ? 0u : guess->state;
+                if (sizeof(TU) == 8 && (family == kern::GO_LAZY_8Q || family == kern::GO_LAZY_4Q) && perm > 12)
+                    perm = 12; // those families run on 4096-coefficient tiles
+                slow.in = in;
+                slow.out = out;
+                slow.mul_in = mul_in;
+                slow.poly_order = poly_order;
+                slow.polys = static_cast<unsigned long long>(batch_size);
+                slow.flags = io_flags & (kern::F_SIGNED_IN | kern::F_SCALE | kern::F_CENTERED);
+                slow.inverse = inverse ? 1 : 0;
+                slow.enabled = forced_path() == 3 ? 0 : 1; // fast-strict: the lazy families must own the call
+            }
+            host::launch_prep<TU>(roots, ws, mods, m.value, mod_count, n_power, neg, perm, ninv_dev,
                                   ninv_dev ? ws_ninv : nullptr, go_flag, norm_arr, stream, mod_order, ninv_single,
-                                  ninv_dev != nullptr, mods ? host_state : nullptr, allow_31q);
+                                  ninv_dev != nullptr, (mods && guess) ? guess->state_out : nullptr, allow_31q, family,
+                                  (mods != nullptr && guess != nullptr) ? &slow : nullptr);
             kern::LazyArgsT<TU> a{};
             a.in = in;
             a.out = out;
@@ -178,7 +200,8 @@ namespace gpuntt
             a.lim = lim;
             a.host_allow_31q = allow_31q ? 1 : 0;
             a.mod_order = mod_order;
-            a.poly_order = nullptr;
+            a.poly_order = poly_order;
+            a.mul_in = mul_in;
             a.norm = lazy::make_norm_const(static_cast<uint64_t>(m.value), static_cast<uint64_t>(m.bit));
             a.norm_arr = norm_arr;
             a.total = static_cast<unsigned long long>(batch_size) << n_power;
@@ -190,16 +213,14 @@ namespace gpuntt
             return a;
         }
 
-        // Drop-in RNS calls (moduli in device memory): every lazy family is enqueued behind the four-state go-flag the
-        // preparation kernel publishes (kern::not_my_call) -- the default range of the word size and, for 64-bit words,
-        // the 8 q / 4 q families that serve a stack whose widest prime has 61 / 62 bits (4096-coefficient tiles, capped
-        // tile-walking grids; prep_twiddles lays the table out for the family that will run).  The families the flag does not name return at once; the generic
-        // kernels behind them (capped shadow grid) are left with moduli outside the documented domain.
+        // Drop-in RNS calls (moduli in device memory): the ONE lazy family the host predicts for the stack (host::RnsGuess),
+        // or -- all_families -- every family behind the exact go-flag state.  The preparation kernel in front of them
+        // publishes the flag and is itself the fall-back for a stack the enqueued family cannot serve (kern::SlowArgs):
+        // there is no generic launch behind these calls.
         template <typename TU, bool INV>
         inline void run_transform_lazy_rns(const kern::LazyArgsT<TU>& la, unsigned in_flags, unsigned out_flags,
                                            hipStream_t stream, const host::RnsGuess& guess)
         {
-            // the family the stack needed last time (host::RnsGuess), or every family
             if (guess.all_families || guess.state == kern::GO_LAZY)
                 host::run_transform_lazy<TU, INV>(la, in_flags, out_flags, stream);
             if constexpr (sizeof(TU) == 8)
@@ -213,8 +234,7 @@ namespace gpuntt
                     }
                 if (guess.all_families || guess.state == kern::GO_LAZY_8Q)
                 {
-                    wide.lim = 8; // widest modulus 61 bit (measured: a C5-shaped stack with one 61-bit prime 0.30 ms on the
-                                  // 4 q kernels against 0.22 ms on the 8 q ones)
+                    wide.lim = 8; // widest modulus 61 bit
                     host::run_transform_lazy<TU, INV>(wide, in_flags, out_flags, stream);
                 }
                 if (guess.all_families || guess.state == kern::GO_LAZY_4Q)
@@ -222,20 +242,6 @@ namespace gpuntt
                     wide.lim = 4; // widest modulus 62 bit
                     host::run_transform_lazy<TU, INV>(wide, in_flags, out_flags, stream);
                 }
-            }
-        }
-        // the generic kernels behind the lazy families of a drop-in RNS call: "return if a lazy family owns the call"
-        template <typename TU>
-        inline void generic_behind(kern::PassArgs<TU>& a, const unsigned* go_flag, const host::RnsGuess& guess)
-        {
-            a.skip_flag = go_flag;
-            a.skip_value = 0u; // every family was enqueued: any state but GO_GENERIC is theirs
-            if (go_flag != nullptr && !guess.all_families)
-            {
-                if (guess.state == kern::GO_GENERIC)
-                    a.skip_flag = nullptr; // nothing was enqueued in front: the whole call is this launch's
-                else
-                    a.skip_value = guess.state; // only that family was enqueued: every other state is this launch's
             }
         }
 
@@ -601,7 +607,6 @@ namespace gpuntt
             throw std::invalid_argument("Invalid mod_count!");
         const unsigned in_flags = std::is_signed<T>::value ? kern::F_SIGNED_IN : 0u;
         const unsigned* skip_flag = nullptr;
-        host::RnsGuess guess{kern::GO_LAZY, true, nullptr}; // all families unless a prediction is made below
         if (cfg.ntt_layout == PerCoefficient)
         {
             kern::PassArgs<TU> a = base_args<TU>(device_in, device_out, root_of_unity_table, cfg.n_power,
@@ -625,21 +630,20 @@ namespace gpuntt
             skip_flag = zeroed_flag(cfg.stream); // test hook: the generic kernels as they run behind a go-flag that names them
         else if (batch_size > 0 && lazy_eligible<TU>(cfg.n_power, batch_size, mod_count, cfg.stream))
         {
-            guess = host::rns_guess(modulus, mod_count, static_cast<int>(sizeof(TU)), false);
+            // preparation (classifies the stack; its own fall-back when the stack does not fit) + the predicted lazy family
+            const host::RnsGuess guess = host::rns_guess(modulus, mod_count, static_cast<int>(sizeof(TU)), false);
             kern::LazyArgsT<TU> la =
                 lazy_args<TU>(device_in, device_out, root_of_unity_table, Modulus<TU>(), modulus, mod_count,
                               nullptr, cfg.n_power, cfg.reduction_poly, batch_size, cfg.stream, nullptr, nullptr,
-                              guess.state_out);
+                              &guess, in_flags);
             run_transform_lazy_rns<TU, false>(la, in_flags, 0u, cfg.stream, guess);
-            skip_flag = la.go_flag;
-            if (forced_path() == 3)
-                return; // test hook (path = fast-strict): no generic shadow launches -- the lazy families must own the call
+            return;
         }
         kern::PassArgs<TU> a = base_args<TU>(device_in, device_out, root_of_unity_table, cfg.n_power,
                                              cfg.reduction_poly, batch_size);
         a.mods = modulus;
         a.mod_count = mod_count;
-        generic_behind(a, skip_flag, guess);
+        a.skip_flag = skip_flag;
         set_multi(a);
         host::run_transform<TU, false>(a, in_flags, 0u, cfg.stream);
     }
@@ -659,7 +663,6 @@ namespace gpuntt
         const unsigned out_flags =
             kern::F_SCALE | (std::is_signed<T>::value ? kern::F_CENTERED : 0u);
         const unsigned* skip_flag = nullptr;
-        host::RnsGuess guess{kern::GO_LAZY, true, nullptr}; // all families unless a prediction is made below
         if (cfg.ntt_layout == PerCoefficient)
         {
             kern::PassArgs<TU> a =
@@ -687,15 +690,13 @@ namespace gpuntt
         else if (batch_size > 0 && cfg.mod_inverse != nullptr &&
             lazy_eligible<TU>(cfg.n_power, batch_size, mod_count, cfg.stream))
         {
-            guess = host::rns_guess(modulus, mod_count, static_cast<int>(sizeof(TU)), true);
+            const host::RnsGuess guess = host::rns_guess(modulus, mod_count, static_cast<int>(sizeof(TU)), true);
             kern::LazyArgsT<TU> la =
                 lazy_args<TU>(device_in, reinterpret_cast<TU*>(device_out), root_of_unity_table,
                               Modulus<TU>(), modulus, mod_count, cfg.mod_inverse, cfg.n_power,
-                              cfg.reduction_poly, batch_size, cfg.stream, nullptr, nullptr, guess.state_out);
+                              cfg.reduction_poly, batch_size, cfg.stream, nullptr, nullptr, &guess, out_flags);
             run_transform_lazy_rns<TU, true>(la, 0u, out_flags, cfg.stream, guess);
-            skip_flag = la.go_flag;
-            if (forced_path() == 3)
-                return; // test hook (path = fast-strict): no generic shadow launches
+            return;
         }
         kern::PassArgs<TU> a =
             base_args<TU>(device_in, reinterpret_cast<TU*>(device_out), root_of_unity_table,
@@ -703,7 +704,7 @@ namespace gpuntt
         a.mods = modulus;
         a.mod_count = mod_count;
         a.ninv_arr = cfg.mod_inverse;
-        generic_behind(a, skip_flag, guess);
+        a.skip_flag = skip_flag;
         set_multi(a);
         host::run_transform<TU, true>(a, 0u, out_flags, cfg.stream);
     }
@@ -890,29 +891,26 @@ namespace gpuntt
         T* first = (device_out == device_a) ? device_b : device_a;
         T* second = (device_out == device_a) ? device_a : device_b;
         GPU_NTT<T>(first, first, forward_table, modulus, f, batch_size, mod_count);
-        // moduli live on the device: fast kernels (multiplying on their final store) and generic
-        // kernels + pointwise_mul are both enqueued, the go-flag decides which family runs
-        const unsigned* skip_flag = nullptr;
-        host::RnsGuess guess{kern::GO_LAZY, true, nullptr};
+        // moduli live on the device: the predicted lazy family multiplies on its final store; a stack it cannot serve is
+        // transformed AND multiplied by the preparation kernel's own fall-back (kern::SlowArgs::mul_in)
         if (lazy_eligible<T>(cfg.n_power, batch_size, mod_count, cfg.stream))
         {
-            guess = host::rns_guess(modulus, mod_count, static_cast<int>(sizeof(T)), false);
+            const host::RnsGuess guess = host::rns_guess(modulus, mod_count, static_cast<int>(sizeof(T)), false);
             kern::LazyArgsT<T> la = lazy_args<T>(second, device_out, forward_table, Modulus<T>(), modulus, mod_count,
                                                  nullptr, cfg.n_power, cfg.reduction_poly, batch_size, cfg.stream, nullptr,
-                                                 nullptr, guess.state_out);
-            la.mul_in = first;
+                                                 nullptr, &guess, 0u, nullptr, first);
             run_transform_lazy_rns<T, false>(la, 0u, 0u, cfg.stream, guess);
-            skip_flag = la.go_flag;
         }
-        kern::PassArgs<T> a = base_args<T>(second, device_out, forward_table, cfg.n_power, cfg.reduction_poly, batch_size);
-        a.mods = modulus;
-        a.mod_count = mod_count;
-        generic_behind(a, skip_flag, guess);
-        set_multi(a);
-        host::run_transform<T, false>(a, 0u, 0u, cfg.stream);
-        // the pointwise product runs exactly when the generic transform did (the lazy kernels multiply on their final store)
-        pointwise_launch<T>(first, device_out, device_out, modulus, Modulus<T>(), mod_count, cfg.n_power, batch_size,
-                            cfg.stream, a.skip_flag, a.skip_value);
+        else
+        {
+            kern::PassArgs<T> a = base_args<T>(second, device_out, forward_table, cfg.n_power, cfg.reduction_poly, batch_size);
+            a.mods = modulus;
+            a.mod_count = mod_count;
+            set_multi(a);
+            host::run_transform<T, false>(a, 0u, 0u, cfg.stream);
+            pointwise_launch<T>(first, device_out, device_out, modulus, Modulus<T>(), mod_count, cfg.n_power, batch_size,
+                                cfg.stream);
+        }
         f.ntt_type = INVERSE;
         GPU_INTT<T>(device_out, device_out, inverse_table, modulus, f, batch_size, mod_count);
     }
@@ -1192,30 +1190,27 @@ namespace gpuntt
             if (batch_size <= 0)
                 return;
             const bool inv = (cfg.ntt_type == INVERSE);
-            const unsigned* skip_flag = nullptr;
-            host::RnsGuess guess{kern::GO_LAZY, true, nullptr};
             // fast path: whole tiles inside one polynomial
             if (cfg.n_power >= host::lazy_tile_log<T>(cfg.n_power) &&
                 lazy_eligible<T>(cfg.n_power, batch_size, mod_count, cfg.stream) && (!inv || cfg.mod_inverse != nullptr))
             {
-                guess = host::rns_guess(modulus, mod_count, static_cast<int>(sizeof(T)), inv, mod_order);
+                const host::RnsGuess guess = host::rns_guess(modulus, mod_count, static_cast<int>(sizeof(T)), inv, mod_order);
+                const unsigned io_flags = inv ? static_cast<unsigned>(kern::F_SCALE) : 0u;
                 kern::LazyArgsT<T> la =
                     lazy_args<T>(device_in, device_out, table, Modulus<T>(), modulus, mod_count,
                                  inv ? cfg.mod_inverse : nullptr, cfg.n_power, cfg.reduction_poly,
-                                 batch_size, cfg.stream, mod_order, nullptr, guess.state_out);
-                la.poly_order = poly_order;
+                                 batch_size, cfg.stream, mod_order, nullptr, &guess, io_flags, poly_order);
                 if (inv)
                     run_transform_lazy_rns<T, true>(la, 0u, kern::F_SCALE, cfg.stream, guess);
                 else
                     run_transform_lazy_rns<T, false>(la, 0u, 0u, cfg.stream, guess);
-                skip_flag = la.go_flag;
+                return;
             }
             kern::PassArgs<T> a = base_args<T>(device_in, device_out, table, cfg.n_power,
                                                cfg.reduction_poly, batch_size);
             a.mods = modulus;
             a.mod_count = mod_count;
             a.ninv_arr = cfg.mod_inverse;
-            generic_behind(a, skip_flag, guess);
             a.mod_order = mod_order;
             a.poly_order = poly_order;
             set_multi(a);

@@ -84,6 +84,78 @@ namespace gpuntt
             return (r >= q) ? (r - q) : r;
         }
 
+        // The fall-back of a drop-in RNS Merge call (kern::SlowArgs): polynomial p of the batch -- modulus p % mod_count,
+        // prime index through mod_order, memory slot through poly_order -- transformed by ONE block, a stage at a time
+        // through global memory, with the caller's plain table and the public Barrett arithmetic (what the reference's
+        // kernels compute, src/lib/ntt_merge/ntt.cu:596-761, 1086-1318; same stage / twiddle indexing as
+        // merge_kernels.hpp: column_ntt_small).  Correctness path: runs when the host's family prediction was wrong.
+        template <typename T>
+        __device__ void slow_rns_transform(const SlowArgs<T>& sa, const T* __restrict__ roots, const Modulus<T>* __restrict__ mods,
+                                           const T* __restrict__ ninv_arr, const int* __restrict__ mod_order, int mod_count,
+                                           int n, int negacyclic)
+        {
+            using S = typename std::make_signed<T>::type;
+            const unsigned long long N = 1ull << n;
+            for (unsigned long long p = blockIdx.x; p < sa.polys; p += gridDim.x)
+            {
+                const int mi = static_cast<int>(p % static_cast<unsigned>(mod_count));
+                const int prime = (mod_order != nullptr) ? mod_order[mi] : mi;
+                const Modulus<T> md = mods[prime];
+                const dev::ModCtx<T> m{md.value, md.bit, md.mu};
+                const unsigned long long slot = (sa.poly_order != nullptr) ? static_cast<unsigned>(sa.poly_order[p]) : p;
+                const T* src = static_cast<const T*>(sa.in) + (slot << n);
+                T* dst = sa.out + (slot << n);
+                const T* tab = roots + (static_cast<unsigned long long>(prime) << n);
+                for (unsigned long long e = threadIdx.x; e < N; e += 256)
+                {
+                    T x = src[e];
+                    if ((sa.flags & F_SIGNED_IN) && static_cast<S>(x) < 0)
+                        x = static_cast<T>(m.q + x);
+                    dst[e] = x;
+                }
+                __threadfence();
+                __syncthreads();
+                for (int st = 0; st < n; st++)
+                {
+                    const int P = sa.inverse ? st : (n - 1 - st); // butterfly distance 2^P
+                    for (unsigned long long b = threadIdx.x; b < (N >> 1); b += 256)
+                    {
+                        const unsigned long long lo = b & ((1ull << P) - 1ull), grp = b >> P;
+                        const unsigned long long i0 = (grp << (P + 1)) | lo, i1 = i0 + (1ull << P);
+                        const T w = tab[grp + (negacyclic ? (1ull << (n - 1 - P)) : 0ull)];
+                        T U = dst[i0], V = dst[i1];
+                        if (sa.inverse)
+                            dev::gs_butterfly(U, V, w, m);
+                        else
+                            dev::ct_butterfly(U, V, w, m);
+                        dst[i0] = U;
+                        dst[i1] = V;
+                    }
+                    __threadfence();
+                    __syncthreads();
+                }
+                const bool scale = (sa.flags & F_SCALE) != 0u && ninv_arr != nullptr;
+                if (scale || sa.mul_in != nullptr)
+                {
+                    const T ninv = scale ? ninv_arr[prime] : static_cast<T>(0);
+                    for (unsigned long long e = threadIdx.x; e < N; e += 256)
+                    {
+                        T x = dst[e];
+                        if (sa.mul_in != nullptr)
+                            x = m.mul(x, sa.mul_in[(slot << n) + e]);
+                        if (scale)
+                        {
+                            x = m.mul(x, ninv);
+                            if (sa.flags & F_CENTERED)
+                                x = (x > (m.q >> 1)) ? static_cast<T>(x - m.q) : x;
+                        }
+                        dst[e] = x;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+
         // fold_ninv (inverse transforms): the single twiddle of the final Gentleman-Sande stage
         // (slot 1) is stored pre-multiplied by n^-1, so that stage scales both outputs itself --
         // U' = (U + V) * n^-1, V' = (U - V) * (w * n^-1) -- instead of a separate n^-1 product on
@@ -100,7 +172,8 @@ namespace gpuntt
                                                              lazy::NormConst* __restrict__ norm_arr,
                                                              const int* __restrict__ mod_order,
                                                              T ninv_single, int fold_ninv,
-                                                             unsigned* __restrict__ host_state, int allow_31q)
+                                                             unsigned* __restrict__ host_state, int allow_31q,
+                                                             unsigned family, SlowArgs<T> slow)
         {
             const unsigned long long gid = blockIdx.x * 256ull + threadIdx.x;
             // RNS stacks (moduli in device memory): classify the stack -- kern::GO_GENERIC (a modulus outside the fast
@@ -108,8 +181,11 @@ namespace gpuntt
             // 30), GO_LAZY_8Q / GO_LAZY_4Q (64-bit words, widest modulus 61 / 62 bits: the 8 q / 4 q kernels, 4096-coefficient
             // tiles only).  Block 0 publishes the state; every block needs it when the default family would run on a bigger
             // tile, because the per-tile permutation of the last three stages must match the family that will really run.
+            // family != 0: the ONE lazy family the host enqueued behind this launch (its prediction for the stack); the
+            // flag then names that family when the stack fits it, else GO_GENERIC -- and this kernel transforms the batch
+            // itself (slow_rns_transform).  family == 0: every family is enqueued, the flag names the exact state.
             unsigned state = GO_LAZY;
-            if (mods != nullptr && (perm_tile_log > 12 || blockIdx.x == 0))
+            if (mods != nullptr)
             {
                 bool bad = false, w61 = false, w62 = false, over31 = false;
                 for (int i = static_cast<int>(threadIdx.x); i < mod_count; i += 256)
@@ -136,15 +212,28 @@ namespace gpuntt
                 state = any_bad ? GO_GENERIC
                                 : (any62 ? GO_LAZY_4Q : (any61 ? GO_LAZY_8Q : (wide_range ? GO_LAZY_31Q : GO_LAZY)));
             }
+            // host-mapped word (or nullptr): what the host predicts the NEXT call of this stack from (RnsGuess)
+            if (gid == 0 && host_state != nullptr)
+                *host_state = state;
+            if (mods != nullptr && go_flag != nullptr)
+            {
+                const bool fits = (family == 0u) ? (state != GO_GENERIC)
+                                                 : (state != GO_GENERIC && family_rank(state) <= family_rank(family));
+                if (!fits || slow.force != 0)
+                {
+                    if (gid == 0)
+                        *go_flag = GO_GENERIC; // every fast kernel behind this launch returns
+                    if (slow.enabled != 0)
+                        slow_rns_transform<T>(slow, roots, mods, ninv_arr, mod_order, mod_count, n, negacyclic);
+                    return; // (no table: nobody reads it)
+                }
+                if (family != 0u)
+                    state = family; // the stack runs on the (equal or wider) family that was enqueued
+            }
             if ((state == GO_LAZY_8Q || state == GO_LAZY_4Q) && perm_tile_log > 12)
                 perm_tile_log = 12;
             if (gid == 0 && go_flag != nullptr)
-            {
                 *go_flag = state;
-                // host-mapped word (or nullptr): what the host predicts the NEXT call of this stack from (RnsGuess)
-                if (host_state != nullptr)
-                    *host_state = state;
-            }
             const unsigned long long per_mod = 1ull << n;
             // RNS stacks: the reciprocal of the block's modulus is derived once per block (a block
             // never straddles two moduli when n >= 8; below that every thread derives its own)
@@ -155,7 +244,8 @@ namespace gpuntt
                 if (threadIdx.x == 0)
                 {
                     const int bm = static_cast<int>((blockIdx.x * 256ull) >> n);
-                    s_rinv = recip_norm<T>(mods[mod_order != nullptr ? mod_order[bm] : bm].value);
+                    // (blocks beyond the table exist when the grid was enlarged for the fall-back: nothing to prepare)
+                    s_rinv = (bm < mod_count) ? recip_norm<T>(mods[mod_order != nullptr ? mod_order[bm] : bm].value) : static_cast<T>(0);
                 }
                 __syncthreads();
             }
@@ -528,8 +618,8 @@ namespace gpuntt
                 int word = -1; // index of the slot's word in its device's pool of host-mapped words
                 unsigned predicted = kern::GO_LAZY;
                 bool have_prediction = false;
-                int mispredicts = 0;
-                int streak = 0; // correct predictions in a row (64 of them forgive the misses)
+                int streak = 0;                          // calls in a row that needed a narrower family than the predicted one
+                unsigned streak_state = kern::GO_LAZY;   // the widest of them
                 unsigned long long last_use = 0;
             };
             // one pinned, device-mapped allocation per device: GUESS_MAX_KEYS words, one cache line apart.  Never freed
@@ -553,7 +643,9 @@ namespace gpuntt
         } // namespace
 
         static bool rns_predict_enabled(); // option rns_predict (defined with the options below)
-        RnsGuess rns_guess(const void* moduli_device, int mod_count, int word_bytes, bool inverse, const void* order)
+        static bool rns_force_fallback();  // option rns_force_fallback (test hook)
+        RnsGuess rns_guess(const void* moduli_device, int mod_count, int word_bytes, bool inverse, const void* order,
+                           bool exact)
         {
             RnsGuess gss{kern::GO_LAZY, true, nullptr};
             if (!rns_predict_enabled() || forced_path() == 3)
@@ -607,24 +699,31 @@ namespace gpuntt
             GuessSlot& s = it->second;
             s.last_use = ++g_guess_clock;
             const unsigned seen = reinterpret_cast<volatile unsigned*>(pool.host)[s.word * GUESS_STRIDE];
-            if (seen != STATE_UNKNOWN && seen <= kern::GO_LAZY_31Q)
+            if (seen != STATE_UNKNOWN && seen <= kern::GO_LAZY_31Q && (exact || seen != kern::GO_GENERIC))
             {
-                // the state some earlier call of this stack found (the last one that has finished).  It differs from what was
-                // predicted for it: the caller rewrites this buffer with stacks of different widths -- after the second miss
-                // the stack keeps the all-families form (always the right lazy kernels, a few empty launches more)
-                if (s.have_prediction && seen != s.predicted)
+                // the state some earlier call of this stack found (the last one that has finished).  The enqueued family
+                // serves every narrower stack too, so: widen at once, narrow after 16 calls in a row that needed less
+                const int r_seen = kern::family_rank(seen), r_now = kern::family_rank(s.predicted);
+                if (!s.have_prediction || r_seen > r_now || exact)
                 {
-                    s.mispredicts++;
+                    s.predicted = seen;
                     s.streak = 0;
                 }
-                else if (s.mispredicts > 0 && ++s.streak >= 64)
-                    s.mispredicts = s.streak = 0; // the stack has settled: back to the predicted family alone
-                s.predicted = seen;
+                else if (r_seen == r_now)
+                    s.streak = 0;
+                else
+                {
+                    if (s.streak == 0 || r_seen > kern::family_rank(s.streak_state))
+                        s.streak_state = seen;
+                    if (++s.streak >= 16)
+                    {
+                        s.predicted = s.streak_state;
+                        s.streak = 0;
+                    }
+                }
                 s.have_prediction = true;
             }
             gss.state_out = pool.dev + s.word * GUESS_STRIDE;
-            if (s.mispredicts >= 2)
-                return gss;
             gss.all_families = false;
             gss.state = s.predicted;
             return gss;
@@ -661,6 +760,7 @@ namespace gpuntt
                 std::atomic<int> no_scratch{0}; // test hook: behave as if the twiddle scratch could not be allocated
                 std::atomic<int> check_4step{1}; // 4-step entry points: verify the caller's three tables on the device (prep_merge_from_fourstep)
                 std::atomic<int> rns_predict{1}; // drop-in RNS calls: enqueue only the lazy family the stack needed last time
+                std::atomic<int> rns_force_fallback{0}; // test hook: the preparation kernel's own fall-back serves every drop-in RNS Merge call
             } g_opt;
         } // namespace
 
@@ -716,7 +816,7 @@ namespace gpuntt
                 g_opt.u32_ring13_batch = iv;
             }
             else if (k == "xcd_order" || k == "lim31" || k == "reverse" || k == "no_scratch" || k == "check_4step_tables" ||
-                     k == "rns_predict")
+                     k == "rns_predict" || k == "rns_force_fallback")
             {
                 if (!one_of({0, 1}))
                     return false;
@@ -725,7 +825,8 @@ namespace gpuntt
                                         : k == "reverse"               ? g_opt.reverse
                                         : k == "no_scratch"            ? g_opt.no_scratch
                                         : k == "check_4step_tables" ? g_opt.check_4step
-                                                                       : g_opt.rns_predict;
+                                        : k == "rns_force_fallback" ? g_opt.rns_force_fallback
+                                                                    : g_opt.rns_predict;
                 dst = iv;
             }
             else
@@ -735,6 +836,7 @@ namespace gpuntt
 
         int forced_path() { return g_opt.path.load(std::memory_order_relaxed); }
         static bool rns_predict_enabled() { return g_opt.rns_predict.load(std::memory_order_relaxed) != 0; }
+        static bool rns_force_fallback() { return g_opt.rns_force_fallback.load(std::memory_order_relaxed) != 0; }
 
         int lazy_contig_k(int n)
         {
@@ -834,15 +936,26 @@ namespace gpuntt
         void launch_prep(const T* roots, lazy::Tw<T>* ws, const Modulus<T>* mods, T q, int mod_count, int n,
                          bool negacyclic, int perm_tile_log, const T* ninv_arr, lazy::Tw<T>* ws_ninv,
                          unsigned* go_flag, lazy::NormConst* norm_arr, hipStream_t stream, const int* mod_order,
-                         const T* fold_ninv_single, bool fold_ninv_rns, unsigned* host_state, bool allow_31q)
+                         const T* fold_ninv_single, bool fold_ninv_rns, unsigned* host_state, bool allow_31q,
+                         unsigned family, const kern::SlowArgs<T>* slow)
         {
             const unsigned long long entries = static_cast<unsigned long long>(mod_count) << n;
-            const unsigned grid = static_cast<unsigned>((entries + 255) / 256);
+            unsigned grid = static_cast<unsigned>((entries + 255) / 256);
+            kern::SlowArgs<T> sa{};
+            if (slow != nullptr)
+            {
+                sa = *slow;
+                sa.force = (rns_force_fallback() && sa.enabled) ? 1 : 0;
+                // the fall-back transforms one polynomial per block: a tiny table must not leave it a one-block grid
+                const unsigned long long want = sa.polys < 1024ull ? sa.polys : 1024ull;
+                if (sa.enabled && grid < want)
+                    grid = static_cast<unsigned>(want);
+            }
             hipLaunchKernelGGL((kern::prep_twiddles<T>), dim3(grid), dim3(256), 0, stream, roots, ws, mods, q,
                                (mods == nullptr) ? recip_norm_host<T>(q) : static_cast<T>(0), mod_count, n, negacyclic ? 1 : 0, perm_tile_log, ninv_arr, ws_ninv, go_flag, norm_arr, mod_order,
                                fold_ninv_single ? *fold_ninv_single : static_cast<T>(0),
                                (fold_ninv_single != nullptr || (fold_ninv_rns && ninv_arr != nullptr)) ? 1 : 0, host_state,
-                               allow_31q ? 1 : 0);
+                               allow_31q ? 1 : 0, family, sa);
             GPUNTT_HIP_CHECK(hipGetLastError());
         }
         template <typename T>
@@ -873,9 +986,9 @@ namespace gpuntt
 
         template void launch_prep<uint64_t>(const uint64_t*, lazy::Tw64*, const Modulus<uint64_t>*, uint64_t, int,
                                             int, bool, int, const uint64_t*, lazy::Tw64*, unsigned*, lazy::NormConst*, hipStream_t, const int*,
-                                            const uint64_t*, bool, unsigned*, bool);
+                                            const uint64_t*, bool, unsigned*, bool, unsigned, const kern::SlowArgs<uint64_t>*);
         template void launch_prep<uint32_t>(const uint32_t*, lazy::Tw32*, const Modulus<uint32_t>*, uint32_t, int,
                                             int, bool, int, const uint32_t*, lazy::Tw32*, unsigned*, lazy::NormConst*, hipStream_t, const int*,
-                                            const uint32_t*, bool, unsigned*, bool);
+                                            const uint32_t*, bool, unsigned*, bool, unsigned, const kern::SlowArgs<uint32_t>*);
     } // namespace host
 } // namespace gpuntt

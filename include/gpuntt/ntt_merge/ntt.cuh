@@ -235,9 +235,10 @@ namespace gpuntt
     //   check_4step_tables 0 | 1   4-step entry points / FourStepPlan: verify all three caller tables on the device and run
     //                            the element-by-element kernels when they are not the tables of one root
     //                            (ntt_4step/ntt_4step.cuh, "TABLES"); default 1
-    //   rns_predict    0 | 1     drop-in RNS calls enqueue only the lazy kernel family their stack of moduli (same device,
-    //                            moduli pointer, mod_count) needed the last time, with the generic kernels behind it for
-    //                            every other case (default 1); 0: every family behind the go-flag on every call
+    //   rns_predict    0 | 1     drop-in RNS calls enqueue only the lazy kernel family predicted for their stack of moduli (same
+    //                            device, moduli pointer, mod_count, direction); a stack that family cannot serve is transformed
+    //                            by the preparation kernel itself (default 1); 0: every family behind the go-flag on every call
+    //   rns_force_fallback 0 | 1 test hook: that fall-back serves every drop-in RNS Merge call (default 0)
     // Returns false for an unknown name or a value outside the sets above (the whole string must parse: "abc", contig_k = 7,
     // u32_tile = 13 are refused, nothing is silently mapped to a default).  Plans keep the choice made when they were created.
     bool GPU_NTT_SetOption(const char* name, const char* value);

@@ -80,7 +80,8 @@ def test_graph_replay_rns_with_moduli_rewritten_between_capture_and_replay(g):
     """(b) the RNS form: the graph holds a drop-in RNS call whose kernel family was predicted from the stack the buffer
     held at capture time (60-bit primes).  The moduli buffer, the table and the input are then rewritten in place with a
     stack that needs another family (a 62-bit prime): the replay must still be exact (the preparation kernel inside the
-    graph re-classifies, the Barrett kernels behind the stale prediction serve the call), eager calls on the capture
+    graph re-classifies and, since the family baked into the graph cannot serve the stack, transforms the batch itself),
+    eager calls on the capture
     stream in between grow and overwrite that stream's own scratch, and the host-mapped prediction word the graph writes
     to stays alive."""
     import torch
@@ -499,3 +500,62 @@ def test_public_device_butterfly_units(g, bits):
                 wv = [(a - b * c) % q for a, b, c in zip(u, v, w)]
             assert [int(t) for t in g.to_host(du)] == wu, (bits, q, gs)
             assert [int(t) for t in g.to_host(dv)] == wv, (bits, q, gs)
+
+
+# ---------------------------------------------------------------- the preparation kernel's own fall-back
+@pytest.mark.parametrize("bits", [64, 32])
+def test_rns_fallback_inside_the_preparation_kernel(g, bits, golden_dir):
+    """Drop-in RNS Merge calls have NO generic launch behind them any more (two skipped shadow launches
+    cost every call ~13 us): when the stack does not fit the one lazy family the host enqueued, the preparation kernel
+    transforms the batch itself (prep.hip: slow_rns_transform).  Option rns_force_fallback makes that path serve EVERY
+    drop-in RNS Merge call: the existing RNS, signed / centred, *_Ordered, GPU_PolyMul and small-ring tests are re-run
+    through it, and a direct sweep of shapes -- rings 2^4 .. 2^17, both polynomials, ragged batches, out of place --
+    against NTTCPU per polynomial."""
+    import torch
+    import test_gpu_merge as M
+    g.set_option("rns_force_fallback", "1")
+    try:
+        M.test_rns_multi_modulus(g, bits)
+        M.test_modulus_ordered_and_poly_ordered(g, bits)
+        if bits == 64:
+            M.test_polymul_rns(g)
+            M.test_rns_c5_against_golden(g, golden_dir)
+        for idx, (logn, mc, batch) in enumerate(((4, 3, 1000), (9, 2, 37), (12, 5, 11), (13, 4, 9), (16, 3, 4), (17, 2, 3))):
+            widths = ([60, 61, 62, 60, 59] if bits == 64 else [30, 29, 30, 28, 27])[:mc]
+            poly = O.X_N_plus if idx % 2 == 0 else O.X_N_minus
+            cases, d_fwd, d_inv = _rns_stack(g, bits, logn, widths, poly)
+            n = 1 << logn
+            mods = g.modulus_array_to_device([c.prm.modulus for c in cases], bits)
+            ninv = g.to_device(np.array([c.prm.n_inv for c in cases], dtype=cases[0].P.T))
+            x = np.concatenate([cases[p % mc].P.splitmix(99000 + 17 * idx + p, 0, n, cases[p % mc].q) for p in range(batch)])
+            want = np.concatenate([cases[p % mc].P.merge_ntt(x[p * n:(p + 1) * n], cases[p % mc].oprm) for p in range(batch)])
+            cfg = g.ntt_rns_configuration(n_power=logn, reduction_poly=poly)
+            icfg = g.ntt_rns_configuration(n_power=logn, ntt_type=g.INVERSE, reduction_poly=poly, mod_inverse=ninv)
+            d = g.to_device(x)
+            o = torch.zeros_like(d)
+            g.GPU_NTT(d, o, d_fwd, mods, cfg, batch, mc)
+            torch.cuda.synchronize()
+            assert np.array_equal(g.to_host(d), x) and np.array_equal(g.to_host(o), want), ("fwd", bits, logn, mc)
+            # signed input: x - q on every second coefficient is the same residue
+            xs = x.astype(np.int64 if bits == 64 else np.int32)
+            qs = np.concatenate([np.full(n, cases[p % mc].q, dtype=np.uint64) for p in range(batch)]).astype(xs.dtype)
+            xs[1::2] -= qs[1::2]
+            ds = g.to_device(xs)
+            g.GPU_NTT(ds, o, d_fwd, mods, cfg, batch, mc, dtype="s%d" % bits)
+            torch.cuda.synchronize()
+            assert np.array_equal(g.to_host(o), want), ("signed fwd", bits, logn, mc)
+            g.GPU_INTT_Inplace(o, d_inv, mods, icfg, batch, mc)
+            torch.cuda.synchronize()
+            assert np.array_equal(g.to_host(o), x), ("inv", bits, logn, mc)
+            # centred signed output of the inverse
+            o.copy_(g.to_device(want))
+            c_out = torch.zeros_like(o)
+            g.GPU_INTT(o, c_out, d_inv, mods, icfg, batch, mc, dtype="s%d" % bits)
+            torch.cuda.synchronize()
+            got = g.to_host(c_out, signed=True).astype(object)
+            for p in (0, batch - 1):
+                q = cases[p % mc].q
+                ref = [int(v) - q if int(v) > q // 2 else int(v) for v in x[p * n:(p + 1) * n]]
+                assert [int(v) for v in got[p * n:(p + 1) * n]] == ref, ("centred", bits, logn, p)
+    finally:
+        g.set_option("rns_force_fallback", "0")

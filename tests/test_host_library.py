@@ -155,7 +155,7 @@ def test_options_replace_environment_switches(g):
                         ("reverse", "0"), ("reverse", "1"), ("u64_big_tiles", "13"), ("u64_big_tiles", "14"),
                         ("u32_tile", "12"), ("u32_tile", "0"), ("no_scratch", "1"), ("no_scratch", "0")):
         g.set_option(name, value)
-    for name, value in (("check_4step_tables", "0"), ("check_4step_tables", "1"), ("rns_predict", "0"),
+    for name, value in (("check_4step_tables", "0"), ("check_4step_tables", "1"), ("rns_force_fallback", "1"), ("rns_force_fallback", "0"), ("rns_predict", "0"),
                         ("rns_predict", "1"), ("u32_ring13_batch", "0"), ("u32_ring13_batch", "2147483647")):
         g.set_option(name, value)
     # unknown names, and values outside the documented sets, are refused -- never silently mapped to a default
