@@ -184,33 +184,63 @@ namespace gpuntt
             // family != 0: the ONE lazy family the host enqueued behind this launch (its prediction for the stack); the
             // flag then names that family when the stack fits it, else GO_GENERIC -- and this kernel transforms the batch
             // itself (slow_rns_transform).  family == 0: every family is enqueued, the flag names the exact state.
+            // EVERY block classifies (its fall-back role needs the verdict; so does the per-tile permutation): wave 0 reads the
+            // moduli and votes, thread 0 derives the reciprocal of the block's modulus meanwhile (RNS: a block never straddles
+            // two moduli when n >= 8; below that every thread derives its own), ONE barrier publishes both
+            __shared__ unsigned s_state;
+            __shared__ T s_rinv;
+            const unsigned long long per_mod = 1ull << n;
+            const bool block_recip = (mods != nullptr) && n >= 8;
+            // the thread's table word is requested FIRST: its latency then runs beside the classification and the
+            // reciprocal instead of behind the barrier (the kernel is a chain of latencies, not of work)
+            const bool in_table = gid < per_mod * mod_count;
+            const int mi = static_cast<int>(gid >> n);
+            // prepared tables are indexed by the compact slot mi; the caller's moduli, tables and
+            // n^-1 values by the prime index (identical unless *_Modulus_Ordered remaps it)
+            const int prime = (in_table && mod_order != nullptr) ? mod_order[mi] : mi;
+            const unsigned slot = static_cast<unsigned>(gid & (per_mod - 1));
+            const int S = slot ? (31 - __clz(slot)) : 0; // stage: m = 2^S groups
+            const unsigned i = slot - (1u << S);         // group index = position in the caller's table
+            T w = 0;
+            if (in_table && slot != 0u)
+                w = roots[(static_cast<unsigned long long>(prime) << n) + (negacyclic ? ((1u << S) + i) : i)];
             unsigned state = GO_LAZY;
             if (mods != nullptr)
             {
-                bool bad = false, w61 = false, w62 = false, over31 = false;
-                for (int i = static_cast<int>(threadIdx.x); i < mod_count; i += 256)
+                if (threadIdx.x < 64)
                 {
-                    const Modulus<T> md = mods[mod_order != nullptr ? mod_order[i] : i];
-                    if (md.value < 3 || md.bit > static_cast<T>(sizeof(T) == 8 ? 62 : lazy::Mod<T>::MAX_BIT))
-                        bad = true;
-                    else if (sizeof(T) == 8 && md.bit == static_cast<T>(62))
-                        w62 = true;
-                    else if (sizeof(T) == 8 && md.bit == static_cast<T>(61))
-                        w61 = true;
-                    if (sizeof(T) == 8 && static_cast<unsigned long long>(md.value) > 0xffffffffffffffffull / 31)
-                        over31 = true;
-                    // normalisation constants of modulus i (one 64-bit division each): one LANE per modulus instead of a
-                    // serial loop in thread 0 (it matters for long stacks only: an 8-prime preparation stays at 9.8 us, which
-                    // is launch + modulus load -> reciprocal -> barrier -> table load -> store, a chain of latencies)
-                    if (blockIdx.x == 0 && norm_arr != nullptr && go_flag != nullptr)
-                        norm_arr[i] = lazy::make_norm_const(md.value, md.bit);
+                    bool bad = false, w61 = false, w62 = false, over31 = false;
+                    for (int i = static_cast<int>(threadIdx.x); i < mod_count; i += 64)
+                    {
+                        const Modulus<T> md = mods[mod_order != nullptr ? mod_order[i] : i];
+                        if (md.value < 3 || md.bit > static_cast<T>(sizeof(T) == 8 ? 62 : lazy::Mod<T>::MAX_BIT))
+                            bad = true;
+                        else if (sizeof(T) == 8 && md.bit == static_cast<T>(62))
+                            w62 = true;
+                        else if (sizeof(T) == 8 && md.bit == static_cast<T>(61))
+                            w61 = true;
+                        if (sizeof(T) == 8 && static_cast<unsigned long long>(md.value) > 0xffffffffffffffffull / 31)
+                            over31 = true;
+                        // normalisation constants of modulus i (one 64-bit division each): one LANE per modulus
+                        if (blockIdx.x == 0 && norm_arr != nullptr && go_flag != nullptr)
+                            norm_arr[i] = lazy::make_norm_const(md.value, md.bit);
+                    }
+                    const bool any_bad = __ballot(bad) != 0ull, any62 = __ballot(w62) != 0ull, any61 = __ballot(w61) != 0ull,
+                               any_over31 = __ballot(over31) != 0ull;
+                    // forward calls (no n^-1 folded) of 64-bit words whose every modulus has 31 q < 2^64: the 31 q kernels
+                    const bool wide_range = sizeof(T) == 8 && allow_31q != 0 && fold_ninv == 0 && !any_over31;
+                    if (threadIdx.x == 0)
+                        s_state = any_bad ? GO_GENERIC
+                                          : (any62 ? GO_LAZY_4Q : (any61 ? GO_LAZY_8Q : (wide_range ? GO_LAZY_31Q : GO_LAZY)));
                 }
-                const int any_bad = __syncthreads_or(bad ? 1 : 0), any62 = __syncthreads_or(w62 ? 1 : 0),
-                          any61 = __syncthreads_or(w61 ? 1 : 0), any_over31 = __syncthreads_or(over31 ? 1 : 0);
-                // forward calls (no n^-1 folded) of 64-bit words whose every modulus has 31 q < 2^64: the 31 q kernels
-                const bool wide_range = sizeof(T) == 8 && allow_31q != 0 && fold_ninv == 0 && !any_over31;
-                state = any_bad ? GO_GENERIC
-                                : (any62 ? GO_LAZY_4Q : (any61 ? GO_LAZY_8Q : (wide_range ? GO_LAZY_31Q : GO_LAZY)));
+                if (block_recip && threadIdx.x == 64)
+                {
+                    const int bm = static_cast<int>((blockIdx.x * 256ull) >> n);
+                    // (blocks beyond the table exist when the grid was enlarged for the fall-back: nothing to prepare)
+                    s_rinv = (bm < mod_count) ? recip_norm<T>(mods[mod_order != nullptr ? mod_order[bm] : bm].value) : static_cast<T>(0);
+                }
+                __syncthreads();
+                state = s_state;
             }
             // host-mapped word (or nullptr): what the host predicts the NEXT call of this stack from (RnsGuess)
             if (gid == 0 && host_state != nullptr)
@@ -234,28 +264,8 @@ namespace gpuntt
                 perm_tile_log = 12;
             if (gid == 0 && go_flag != nullptr)
                 *go_flag = state;
-            const unsigned long long per_mod = 1ull << n;
-            // RNS stacks: the reciprocal of the block's modulus is derived once per block (a block
-            // never straddles two moduli when n >= 8; below that every thread derives its own)
-            __shared__ T s_rinv;
-            const bool block_recip = (mods != nullptr) && n >= 8;
-            if (block_recip)
-            {
-                if (threadIdx.x == 0)
-                {
-                    const int bm = static_cast<int>((blockIdx.x * 256ull) >> n);
-                    // (blocks beyond the table exist when the grid was enlarged for the fall-back: nothing to prepare)
-                    s_rinv = (bm < mod_count) ? recip_norm<T>(mods[mod_order != nullptr ? mod_order[bm] : bm].value) : static_cast<T>(0);
-                }
-                __syncthreads();
-            }
-            if (gid >= per_mod * mod_count)
+            if (!in_table)
                 return;
-            const int mi = static_cast<int>(gid >> n);
-            // prepared tables are indexed by the compact slot mi; the caller's moduli, tables and
-            // n^-1 values by the prime index (identical unless *_Modulus_Ordered remaps it)
-            const int prime = (mod_order != nullptr) ? mod_order[mi] : mi;
-            const unsigned slot = static_cast<unsigned>(gid & (per_mod - 1));
             const T q = (mods != nullptr) ? mods[prime].value : q_single;
             const T rinv = (mods == nullptr) ? rinv_single : (block_recip ? s_rinv : recip_norm<T>(q));
             if (slot == 0)
@@ -268,8 +278,6 @@ namespace gpuntt
                 ws[gid] = lazy::Tw<T>{0, 0};
                 return;
             }
-            const int S = 31 - __clz(slot);       // stage: m = 2^S groups
-            const unsigned i = slot - (1u << S);  // group index = position in the caller's table
             const int P = n - 1 - S;              // butterfly distance 2^P
             unsigned long long dst = gid;
             if (perm_tile_log > 0 && P <= 2)
@@ -286,8 +294,6 @@ namespace gpuntt
                 const unsigned kk = rem & ((1u << rp_log) - 1u), t = rem >> rp_log;
                 dst = (gid - i) + (tile << (rp_log + nt_log)) + (kk << nt_log) + t;
             }
-            const unsigned src = negacyclic ? ((1u << S) + i) : i;
-            T w = roots[(static_cast<unsigned long long>(prime) << n) + src];
             if (fold_ninv && slot == 1)
                 w = mulmod_r<T>(w, (ninv_arr != nullptr) ? ninv_arr[prime] : ninv_single, q, rinv);
             ws[dst] = lazy::Tw<T>{w, shoup_quotient_r<T>(w, q, rinv)};

@@ -48,6 +48,16 @@ def test_gpu_4step_example(logn, batch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("logn,batch,devices,mc", [(13, 64, 0, 2), (16, 24, 8, 3), (10, 400, 2, 4)])
+def test_multi_device_example(logn, batch, devices, mc):
+    """tests/cpp/example_multi_device.cpp: the batch shard from C++ -- one host thread per device (hipSetDevice), drop-in
+    call and NTTPlan on a stream per device, every polynomial against NTTCPU.  Asking for more devices than the box has
+    degrades to what exists (this box: one), the same code path with one worker."""
+    out = _run("example_multi_device", logn, batch, devices, mc)
+    assert "All Correct on" in out and "WRONG" not in out
+
+
+@pytest.mark.gpu
 def test_native_benchmark_program_runs():
     """tests/cpp/bench_ntt.cpp (the reference benchmark's axes timed from C++: drop-in call, plan, plan replayed
     from a hipGraph) -- a short run of each algorithm; one JSON object per ring size"""
