@@ -100,11 +100,7 @@ EXPORTED_SYMBOLS = ["gpuntt_last_error", "gpuntt_version"] + [
 
 # GPUNTT_* environment variables of the A/B scripts and tests -> library options.  The C++ library reads no
 # environment variable; this harness forwards them once, when it loads the library.
-ENV_OPTIONS = {"GPUNTT_PATH": ("path", None), "GPUNTT_CONTIG_K": ("contig_k", None),
-               "GPUNTT_XCD_ORDER": ("xcd_order", None), "GPUNTT_LIM31": ("lim31", None),
-               "GPUNTT_NO_REVERSE": ("reverse", lambda v: "0" if v not in ("", "0") else "1"),
-               "GPUNTT_U64_BIG_TILES": ("u64_big_tiles", None), "GPUNTT_U32_TILE": ("u32_tile", None),
-               }
+ENV_OPTIONS = {"GPUNTT_PATH": ("path", None)}
 
 
 def set_option(name, value):

@@ -175,16 +175,7 @@ namespace gpuntt
                 asm("v_mad_u64_u32 %0, %1, %2, 1, %3" : "=v"(qh), "=s"(carry) : "v"(h2), "v"(qh));
                 uint64_t c = mad32z<UNI>(x0, hi32(t.w));
                 c = mad32<UNI>(x1, lo32(t.w), c);
-#ifdef GPUNTT_EXP_Q59
-                // EXPERIMENT (VERDICT r3 #4a, profiles/r04_c2_last_levers.txt): every prime of the reference's pools is
-                // 2^59 + c with c < 2^32, so hi32(-q) = 2^32 - 2^27 - 1 and  lo32(qh) * hi32(-q)  =  -(lo32(qh) << 27) - lo32(qh)
-                // (mod 2^32): one v_mad_u64_u32 of the chain becomes a v_lshl_add_u32 + a v_sub_u32 (applied below)
-                constexpr bool Q59 = (LIM == 31);
-#else
-                constexpr bool Q59 = false;
-#endif
-                if constexpr (!Q59)
-                    c = mad32<!VQ>(lo32(qh), hi32(qneg), c);
+                c = mad32<!VQ>(lo32(qh), hi32(qneg), c);
                 c = mad32<!VQ>(hi32(qh), lo32(qneg), c);
                 uint64_t a = ZERO ? mad32z<UNI>(x0, lo32(t.w)) : mad32<UNI>(x0, lo32(t.w), acc);
                 // the cross sum goes into the accumulator's high word BEFORE the last multiply-add, so the result
@@ -192,12 +183,6 @@ namespace gpuntt
                 // butterfly's 64-bit subtraction on the halves: a third instruction in a third of the butterflies)
                 uint32_t ah;
                 asm("v_add_u32 %0, %1, %2" : "=v"(ah) : "v"(hi32(a)), "v"(lo32(c)));
-                if constexpr (Q59)
-                {
-                    uint32_t t27;
-                    asm("v_lshl_add_u32 %0, %1, 27, %1" : "=v"(t27) : "v"(lo32(qh)));
-                    asm("v_sub_u32 %0, %1, %2" : "=v"(ah) : "v"(ah), "v"(t27));
-                }
                 a = (static_cast<uint64_t>(ah) << 32) | lo32(a);
                 return mad32<!VQ>(lo32(qh), lo32(qneg), a);
             }

@@ -19,17 +19,17 @@ namespace gpuntt
 
         // tile size (log2) used by the fast kernels for element type T and ring size 2^n:
         // 64-bit: 4096 coefficients (32 KiB of LDS).  32-bit: 16384 coefficients (64 KiB) for rings
-        // of 2^13 and 2^14, which makes them a single HBM sweep.  Larger 32-bit rings take the tile
+        // of 2^14, 8192 for 2^13, which makes them a single HBM sweep.  Larger 32-bit rings take the tile
         // that needs fewer sweeps (2^20..2^22: 16384) and, at equal sweep count, the 4096 tile, whose
         // kernels are 10-20 % faster per stage (4 blocks per CU, strided pass carrying up to 8
-        // stages): measured in profiles/u32_tile_ab_r01.txt.  GPUNTT_U32_TILE=12|14 overrides the
-        // choice above 2^14 (A/B timing).
-        int lazy_u32_tile_override();
-        // largest ring (log2) that 64-bit calls may transform inside one big tile (default 14;
-        // GPUNTT_U64_BIG_TILES=13 drops the 16384-coefficient tile, =0 both)
-        int lazy_u64_big_tiles();
-        // 32-bit ring 2^13: largest call (polynomials) that takes the 8192-coefficient tile (option u32_ring13_batch)
-        unsigned long long lazy_u32_small_batch();
+        // stages): measured in profiles/u32_tile_ab_r01.txt, r04_u32_tile_big_rings_ab.txt, r04_u32_ring13_tile_ab.txt.
+        // (The A/B switches of rounds 1-4 -- u32_tile, u64_big_tiles, u32_ring13_batch, contig_k, xcd_order, reverse, lim31 --
+        // are retired: their questions are closed, the constants below are what they settled on.)
+        constexpr int lazy_u32_tile_override() { return 0; }
+        // largest ring (log2) that 64-bit calls may transform inside one big tile
+        constexpr int lazy_u64_big_tiles() { return 14; }
+        // 32-bit ring 2^13: every call takes the 8192-coefficient tile
+        constexpr unsigned long long lazy_u32_small_batch() { return 0x7fffffffull; }
         // `inverse` and `polys` (transforms in the call) must be the same wherever one call asks:
         // the twiddle preparation lays the table out for the tile the passes will use
         template <typename T> inline int lazy_tile_log(int n, bool inverse = false, unsigned long long polys = 0)
@@ -320,7 +320,8 @@ namespace gpuntt
         // stages handled by the contiguous pass of the fast path (option contig_k overrides, 8..12)
         int lazy_contig_k(int n);
 
-        bool lazy_reverse_passes();
+        // consecutive passes of one transform walk the batch in opposite directions (Infinity Cache reuse of the hand-off)
+        constexpr bool lazy_reverse_passes() { return true; }
         bool check_4step_tables();        // option check_4step_tables (default on)
         // forward 4-step in Merge form: stages of the first pass (the one that reads the transposed input) -- the first
         // strided pass of the ring's Merge plan on tile `tl`, widened to log2 n1 where that is larger (5 .. 8)
@@ -417,10 +418,9 @@ namespace gpuntt
         // LIMIT = 31 forward kernels on any 64-bit tile size (4096 / 8192 / 16384 coefficients)
         void launch_pass_lazy31(const Pass& p, int tile_log, bool in_first, bool last, const kern::LazyArgsT<uint64_t>& a,
                                 hipStream_t stream);
-        // forward transforms of a modulus with 31 q < 2^64 take the LIMIT = 31 kernels
-        // (GPUNTT_LIM31=0 switches that off for A/B timing)
-        bool lazy_lim31_enabled();
-        unsigned lazy_order_flags(); // F_PLAIN_ORDER if GPUNTT_XCD_ORDER=0
+        // forward transforms of a modulus with 31 q < 2^64 take the LIMIT = 31 kernels (32-bit: q < 2^29 the LIMIT = 8 ones)
+        constexpr bool lazy_lim31_enabled() { return true; }
+        constexpr unsigned lazy_order_flags() { return 0u; } // XCD-aware poly-minor block order
         // 32-bit words, every modulus of the call below 2^29: the LIMIT = 8 kernels (both directions, both tiles);
         // switched together with the 31 q range (GPUNTT_LIM31=0)
         template <bool INV>

@@ -248,12 +248,9 @@ namespace gpuntt
         // 2^(R-1-jb) entries -> at most 1 + 2 + 4 + 8 = 15 per thread
         constexpr int TW_PER_ROUND = EPT - 1;
 
-        // EXACT = false: lazy residues (modulus with >= 4 bits of headroom, bit <= 60) -- the only
-        //                variant instantiated: fusing both behind a run-time branch cost the lazy
-        //                path its register allocation (spills), so moduli without headroom are
-        //                served by the generic kernels (merge_kernels.hpp) instead
-        // EXACT = true : canonical residues with the reference's Barrett contract on the same
-        //                data movement (kept for experiments)
+        // Lazy residues throughout; moduli outside the lazy families' domain are served by the generic kernels
+        // (merge_kernels.hpp) -- fusing both arithmetic policies behind a run-time branch cost the lazy path its register
+        // allocation (round 1).
         // FST: the transposing passes of the 4-step entry points (reference FourStepForwardCoreT1..4 /
         // FourStepInverseCoreT1..4 + FourStepPartial*Core, src/lib/ntt_4step/ntt_4step.cu:68-743, 1049-1058, 1177-1872).
         // Every 4-step transform is the ring's own Merge plan with a transposition on the natural-order side (DESIGN.md
@@ -405,7 +402,7 @@ namespace gpuntt
         // slot and n^-1).  Strided passes only; the 16 coefficients of a thread lie in ONE column in every round (register
         // windows of strided passes never dip below the contiguous-run bits), so a thread keeps one modulus for the pass
         // and only the operand classes change: q, -q, twiddles and n^-1 in vector registers (lazy::Mod<T, LIM, true>).
-        template <typename T, int TLOG, bool EXACT, bool INV, bool CONTIG, int K, int IN_BOUND, bool LAST,
+        template <typename T, int TLOG, bool INV, bool CONTIG, int K, int IN_BOUND, bool LAST,
                   Fst FST = Fst::none, int LIM = 0, Xp XP = Xp::none, int SKIP = 0, bool VQ = false, int ROWLEN = 0>
         __device__ __forceinline__ void pass_body(const LazyArgsT<T>& a, T* lds, T q_value, T q_bit, T q_mu,
                                                   int mi, unsigned long long fst_poly = 0,
@@ -416,7 +413,7 @@ namespace gpuntt
             using M = lazy::Mod<T, LIM, VQ>;
             using SCH = PassSched<TLOG, INV, CONTIG, K, IN_BOUND, M::LIMIT, M::TB, SKIP>;
             using TW = lazy::Tw<T>;
-            static_assert(!VQ || (FST == Fst::none && XP == Xp::none && !EXACT && SKIP == 0), "per-lane moduli: plain passes");
+            static_assert(!VQ || (FST == Fst::none && XP == Xp::none && SKIP == 0), "per-lane moduli: plain passes");
             static_assert(!(VQ && CONTIG) || (K >= R && K < TLOG && IN_BOUND == 1 && LAST),
                           "per-lane moduli, contiguous: single-pass transforms of rings of 16 .. tile/2 coefficients");
             constexpr bool HAS_FST = (FST != Fst::none);
@@ -434,7 +431,7 @@ namespace gpuntt
             // <= 10 stages, the last exchange of every longer one (u64 K = 11, 12; u32 big tiles).  Full-tile
             // contiguous passes also enter / leave through the 64-contiguous window (512-byte runs per wave
             // instruction, WIO) with a wave-local transposition instead of the block-wide coalescing pass.
-            constexpr bool WIO_OK = CONTIG && (!HAS_FST || FST == Fst::inv_first) && !MULTI_POLY && !EXACT && (TL >= 10);
+            constexpr bool WIO_OK = CONTIG && (!HAS_FST || FST == Fst::inv_first) && !MULTI_POLY && (TL >= 10);
             constexpr int WIO = 6;
             const int t = threadIdx.x;
             constexpr bool SEG = (FST == Fst::nat_rows);
@@ -845,14 +842,7 @@ namespace gpuntt
                         constexpr int kk = j0 >> (jb + 1);
                         const TW tw = tw_cur[off + kk];
                         constexpr bool UNI_TW = UNIFORM_R && !VQ; // twiddle in scalar registers
-                        if constexpr (EXACT)
-                        {
-                            if constexpr (!INV)
-                                dev::ct_butterfly(v[j0], v[j1], tw.w, em);
-                            else
-                                dev::gs_butterfly(v[j0], v[j1], tw.w, em);
-                        }
-                        else if constexpr (!INV)
+                        if constexpr (!INV)
                         {
                             constexpr int ku = SCH::d.ku[r][s][h];
                             T U = v[j0];
@@ -914,10 +904,10 @@ namespace gpuntt
                 // ---- scatter ----------------------------------------------------------
                 if constexpr (r == NR_ - 1)
                 {
-                    constexpr bool PMUL_OK = LAST && !INV && !HAS_FST && !EXACT;
+                    constexpr bool PMUL_OK = LAST && !INV && !HAS_FST;
                     const T* mul_in = PMUL_OK ? a.mul_in : nullptr;
                     (void) mul_in;
-                    if constexpr (LAST && !INV && !EXACT && sizeof(T) == 8)
+                    if constexpr (LAST && !INV && sizeof(T) == 8)
                     {
                         // moduli of >= 48 bits: quotient estimate from the high word (one shift less per coefficient);
                         // the test is wave-uniform, both forms are straight-line code
@@ -938,16 +928,12 @@ namespace gpuntt
                             constexpr int j = decltype(j_)::value;
                             if constexpr (INV)
                             {
-                                T x;
-                                if constexpr (EXACT)
-                                    x = em.mul(v[j], ninv.w);
-                                else
-                                    x = lazy::normalize<M::TB>(m, v[j]); // n^-1 went in with the last stage
+                                T x = lazy::normalize<M::TB>(m, v[j]); // n^-1 went in with the last stage
                                 if (a.flags & F_CENTERED)
                                     x = (x > (m.q >> 1)) ? (x - m.q) : x;
                                 v[j] = x;
                             }
-                            else if constexpr (!EXACT)
+                            else
                             {
                                 v[j] = lazy::normalize<SCH::d.bout[r][j]>(m, v[j]);
                             }
@@ -1150,7 +1136,7 @@ namespace gpuntt
 #pragma unroll
                     for (int j = 0; j < EPT; j++)
                         lw[lds_joff<WL>(j)] = v[j];
-                    if constexpr (!EXACT && WL <= 6 && SCH::wl_of(r + 1 < NR_ ? r + 1 : r) <= 6)
+                    if constexpr (WL <= 6 && SCH::wl_of(r + 1 < NR_ ? r + 1 : r) <= 6)
                         wave_sync(); // both windows inside the wave's sub-block
                     else
                         __syncthreads();
@@ -1291,7 +1277,7 @@ namespace gpuntt
                 qb = md.bit;
                 qm = md.mu;
             }
-            pass_body<T, TLOG, false, INV, CONTIG, K, IN_BOUND, LAST, Fst::none, LIM, Xp::none, SKIP>(a, lds, qv, qb, qm, mi, 0, 0, blk);
+            pass_body<T, TLOG, INV, CONTIG, K, IN_BOUND, LAST, Fst::none, LIM, Xp::none, SKIP>(a, lds, qv, qb, qm, mi, 0, 0, blk);
                 });
         }
 
@@ -1313,7 +1299,7 @@ namespace gpuntt
             __shared__ T lds[NEEDS_LDS ? LTile<12>::LDS_ELEMS : 1];
             if (a.go_flag != nullptr && *a.go_flag == GO_GENERIC)
                 return;
-            pass_body<T, 12, false, INV, false, K, IN_BOUND, LAST, Fst::none, LIM, Xp::none, 0, true>(a, lds, 0, 0, 0, 0, 0, 0,
+            pass_body<T, 12, INV, false, K, IN_BOUND, LAST, Fst::none, LIM, Xp::none, 0, true>(a, lds, 0, 0, 0, 0, 0, 0,
                                                                                        static_cast<long long>(blockIdx.x));
         }
 
@@ -1335,7 +1321,7 @@ namespace gpuntt
             }
             for_each_block<WalksTiles<T, LIM>::value>(
                 static_cast<unsigned>((a.total + LTile<12>::TILE - 1) >> 12), [&](unsigned bidx, unsigned) {
-                    pass_body<T, 12, false, INV, true, K, 1, true, Fst::none, LIM, Xp::none, 0, true>(
+                    pass_body<T, 12, INV, true, K, 1, true, Fst::none, LIM, Xp::none, 0, true>(
                         a, lds, 0, 0, 0, 0, 0, 0, static_cast<long long>(bidx));
                 });
         }
@@ -1375,7 +1361,7 @@ namespace gpuntt
             unsigned poly, tile;
             nat_block(a, TLOG, poly, tile);
             const unsigned rb = tile & ((1u << rb_log) - 1u), seg = tile >> rb_log;
-            pass_body<T, TLOG, false, false, true, K, IN_BOUND, true, Fst::nat_rows, LIM>(a, lds, a.q, a.q_bit, a.q_mu, 0, poly, rb, -1, seg);
+            pass_body<T, TLOG, false, true, K, IN_BOUND, true, Fst::nat_rows, LIM>(a, lds, a.q, a.q_bit, a.q_mu, 0, poly, rb, -1, seg);
         }
 
         // natural-order 4-step, inverse direction (the forward passes run backwards):
@@ -1392,7 +1378,7 @@ namespace gpuntt
             unsigned poly, tile;
             nat_block(a, TLOG, poly, tile);
             const unsigned rb = tile & ((1u << rb_log) - 1u), seg = tile >> rb_log;
-            pass_body<T, TLOG, false, true, true, K, 1, false, Fst::nat_rows, LIM>(a, lds, a.q, a.q_bit, a.q_mu, 0, poly, rb, -1, seg);
+            pass_body<T, TLOG, true, true, K, 1, false, Fst::nat_rows, LIM>(a, lds, a.q, a.q_bit, a.q_mu, 0, poly, rb, -1, seg);
         }
 
         // forward 4-step, first pass in Merge form with the transposed gather (Xp::first_gather): the first strided pass of the ring's
@@ -1414,7 +1400,7 @@ namespace gpuntt
             }
             for_each_block<WalksTiles<T, LIM>::value>(static_cast<unsigned>(a.total >> 12), [&](unsigned bidx, unsigned nblk) {
                 const unsigned bx = (a.flags & F_REVERSE) ? (nblk - 1u - bidx) : bidx;
-                pass_body<T, 12, false, false, false, K, 1, false, Fst::none, LIM, Xp::first_gather>(a, lds, qv, qb, qm, 0, 0, 0,
+                pass_body<T, 12, false, false, K, 1, false, Fst::none, LIM, Xp::first_gather>(a, lds, qv, qb, qm, 0, 0, 0,
                                                                               static_cast<long long>(bx));
             });
         }
@@ -1454,7 +1440,7 @@ namespace gpuntt
                     poly = bx >> tiles_log;
                     tile = bx & ((1u << tiles_log) - 1u);
                 }
-                pass_body<T, TLOG, false, true, true, TLOG, 1, false, Fst::inv_first, LIM, Xp::none, 0, false, L1>(a, lds, qv, qb, qm, 0, uniform32(poly),
+                pass_body<T, TLOG, true, true, TLOG, 1, false, Fst::inv_first, LIM, Xp::none, 0, false, L1>(a, lds, qv, qb, qm, 0, uniform32(poly),
                                                                                       uniform32(tile));
             });
         }
@@ -1480,7 +1466,7 @@ namespace gpuntt
             }
             for_each_block<WalksTiles<T, LIM>::value>(
                 static_cast<unsigned>((a.total + LTile<TLOG>::TILE - 1) >> TLOG), [&](unsigned bidx, unsigned) {
-                    pass_body<T, TLOG, false, INV, true, K, 1, true, Fst::none, LIM,
+                    pass_body<T, TLOG, INV, true, K, 1, true, Fst::none, LIM,
                               NAT ? (INV ? Xp::small_nat_inv : Xp::small_nat_fwd) : (INV ? Xp::small_inv : Xp::small_fwd)>(
                         a, lds, qv, qb, qm, 0, 0, 0, static_cast<long long>(bidx));
                 });

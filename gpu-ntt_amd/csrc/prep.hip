@@ -756,13 +756,6 @@ namespace gpuntt
             struct Options
             {
                 std::atomic<int> path{0};       // 0 size heuristic, 1 generic, 2 fast, 3 fast-strict, 4 generic-capped
-                std::atomic<int> contig_k{0};   // 8 .. 12: stage split of the 4096-coefficient-tile plans
-                std::atomic<int> xcd_order{1};  // XCD-aware poly-minor block order
-                std::atomic<int> lim31{1};      // wider lazy ranges where the modulus allows them
-                std::atomic<int> reverse{1};    // consecutive passes walk the batch in opposite directions
-                std::atomic<int> big_tiles{14}; // largest 64-bit ring done in one big tile
-                std::atomic<int> u32_tile{0};   // 12 | 14: 32-bit tile above 2^14
-                std::atomic<int> u32_ring13_batch{0x7fffffff}; // 32-bit ring 2^13: calls of at most this many polynomials take the 8192 tile
                 std::atomic<int> no_scratch{0}; // test hook: behave as if the twiddle scratch could not be allocated
                 std::atomic<int> check_4step{1}; // 4-step entry points: verify the caller's three tables on the device (prep_merge_from_fourstep)
                 std::atomic<int> rns_predict{1}; // drop-in RNS calls: enqueue only the lazy family the stack needed last time
@@ -797,39 +790,11 @@ namespace gpuntt
                     return false;
                 g_opt.path = m;
             }
-            else if (k == "contig_k")
-            {
-                if (!one_of({0, 8, 9, 10, 11, 12}))
-                    return false;
-                g_opt.contig_k = iv;
-            }
-            else if (k == "u64_big_tiles")
-            {
-                if (!one_of({0, 13, 14}))
-                    return false;
-                g_opt.big_tiles = iv;
-            }
-            else if (k == "u32_tile")
-            {
-                if (!one_of({0, 12, 14}))
-                    return false;
-                g_opt.u32_tile = iv;
-            }
-            else if (k == "u32_ring13_batch")
-            {
-                if (!is_num || lv < 0 || lv > 0x7fffffffl)
-                    return false;
-                g_opt.u32_ring13_batch = iv;
-            }
-            else if (k == "xcd_order" || k == "lim31" || k == "reverse" || k == "no_scratch" || k == "check_4step_tables" ||
-                     k == "rns_predict" || k == "rns_force_fallback")
+            else if (k == "no_scratch" || k == "check_4step_tables" || k == "rns_predict" || k == "rns_force_fallback")
             {
                 if (!one_of({0, 1}))
                     return false;
-                std::atomic<int>& dst = k == "xcd_order"               ? g_opt.xcd_order
-                                        : k == "lim31"                 ? g_opt.lim31
-                                        : k == "reverse"               ? g_opt.reverse
-                                        : k == "no_scratch"            ? g_opt.no_scratch
+                std::atomic<int>& dst = k == "no_scratch"           ? g_opt.no_scratch
                                         : k == "check_4step_tables" ? g_opt.check_4step
                                         : k == "rns_force_fallback" ? g_opt.rns_force_fallback
                                                                     : g_opt.rns_predict;
@@ -846,29 +811,15 @@ namespace gpuntt
 
         int lazy_contig_k(int n)
         {
-            const int forced = g_opt.contig_k.load(std::memory_order_relaxed);
-            if (forced >= 8 && forced <= 12)
-                return forced;
             // The strided pass is HBM-bound with idle VALU slots while the contiguous pass is
             // VALU-bound, so up to 6 stages (the most a strided tile keeps wave-uniform twiddles
-            // for) are moved in front: 2^16 = 6 + 10 measured 2-3 % faster than 4 + 12.
+            // for) are moved in front: 2^16 = 6 + 10 measured 2-3 % faster than 4 + 12 (stage splits 8 + 8 ... 4 + 12 lie
+            // within 3.5 %, profiles/r03_c2_stage_split.txt).
             if (n > 12 && n <= 18)
                 return (n - 6 > 10) ? (n - 6) : 10;
             return 12;
         }
 
-        unsigned lazy_order_flags()
-        {
-            return g_opt.xcd_order.load(std::memory_order_relaxed) ? 0u : static_cast<unsigned>(kern::F_PLAIN_ORDER);
-        }
-        bool lazy_lim31_enabled() { return g_opt.lim31.load(std::memory_order_relaxed) != 0; }
-        bool lazy_reverse_passes() { return g_opt.reverse.load(std::memory_order_relaxed) != 0; }
-        int lazy_u64_big_tiles() { return g_opt.big_tiles.load(std::memory_order_relaxed); }
-        int lazy_u32_tile_override() { return g_opt.u32_tile.load(std::memory_order_relaxed); }
-        unsigned long long lazy_u32_small_batch()
-        {
-            return static_cast<unsigned long long>(g_opt.u32_ring13_batch.load(std::memory_order_relaxed));
-        }
         bool check_4step_tables() { return g_opt.check_4step.load(std::memory_order_relaxed) != 0; }
 
         void* lazy_workspace(hipStream_t stream, size_t bytes, bool or_null)

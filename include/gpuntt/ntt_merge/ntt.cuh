@@ -219,17 +219,9 @@ namespace gpuntt
     // so call this only when no such graph will be replayed again and no call is in flight.
     void GPU_NTT_ReleaseWorkspaces();
 
-    // Process-wide tuning / test options (extension).  The library reads no environment variable; A/B scripts and
-    // tests set these instead.  name = value:
+    // Process-wide test / behaviour options (extension).  The library reads no environment variable.  name = value:
     //   path           default | generic | fast | fast-strict | generic-capped   kernel family forced for every call
-    //   contig_k       8..12     stage split of the 4096-coefficient-tile plans (0: built-in choice)
-    //   xcd_order      0 | 1     XCD-aware poly-minor block order (default 1)
-    //   lim31          0 | 1     wider lazy ranges where the modulus allows them (default 1)
-    //   reverse        0 | 1     consecutive passes walk the batch in opposite directions (default 1)
-    //   u64_big_tiles  0|13|14   largest 64-bit ring transformed inside one big tile (default 14)
-    //   u32_tile       0|12|14   32-bit tile size above 2^14 (default 0: built-in choice)
-    //   u32_ring13_batch  n      32-bit ring 2^13: calls of at most n polynomials run on a 8192-coefficient tile of their own
-    //                            (default 2147483647 = always; 0: never, the ring shares a 16384-coefficient tile)
+    //                            (fast-strict: a call the fast kernels cannot take throws; test hook)
     //   no_scratch     0 | 1     test hook: the drop-in calls behave as if their twiddle scratch could not be allocated
     //                            (they run on the generic kernels, which need none)
     //   check_4step_tables 0 | 1   4-step entry points / FourStepPlan: verify all three caller tables on the device and run
@@ -239,8 +231,10 @@ namespace gpuntt
     //                            device, moduli pointer, mod_count, direction); a stack that family cannot serve is transformed
     //                            by the preparation kernel itself (default 1); 0: every family behind the go-flag on every call
     //   rns_force_fallback 0 | 1 test hook: that fall-back serves every drop-in RNS Merge call (default 0)
-    // Returns false for an unknown name or a value outside the sets above (the whole string must parse: "abc", contig_k = 7,
-    // u32_tile = 13 are refused, nothing is silently mapped to a default).  Plans keep the choice made when they were created.
+    // (The A/B switches of rounds 1-4 -- contig_k, xcd_order, lim31, reverse, u64_big_tiles, u32_tile, u32_ring13_batch -- are
+    // retired: their measurements are in profiles/, the library keeps the settings that won.)
+    // Returns false for an unknown name or a value outside the sets above (the whole string must parse; nothing is silently
+    // mapped to a default).  Plans keep the choice made when they were created.
     bool GPU_NTT_SetOption(const char* name, const char* value);
 
 } // namespace gpuntt

@@ -680,7 +680,7 @@ def test_fourstep_2_24_from_device_generated_tables(g):
 
 def test_31q_range_switch(g):
     """Forward transforms of 64-bit moduli with 31 q < 2^64 (every pool prime) take the LIMIT = 31 kernels, 32-bit
-    moduli below 2^29 the LIMIT = 8 kernels (both directions); GPUNTT_LIM31=0 keeps both on the default ranges.
+    moduli below 2^29 the LIMIT = 8 kernels (both directions).
     All must equal the oracle, and a 60-bit prime above 2^64 / 31 / a 30-bit prime must stay on the default
     kernels (and equal the oracle too)."""
     from test_gpu_merge import _run_in_subprocess
@@ -719,7 +719,7 @@ x = c.random(3, 5)
 assert np.array_equal(c.gpu_forward(x), c.P.merge_ntt(x, c.oprm))
 print("31q switch OK")
 '''
-    for env in ({"GPUNTT_LIM31": "0"}, {"GPUNTT_LIM31": "1"}, {"GPUNTT_LIM31": "1", "GPUNTT_PATH": "fast-strict"}):
+    for env in ({}, {"GPUNTT_PATH": "fast-strict"}):
         assert "31q switch OK" in _run_in_subprocess(code, env)
 
 

@@ -33,75 +33,6 @@ def _fourstep_forward(g, p4, tables, x, batch):
     return g.to_host(d_b)
 
 
-def test_u32_tile_option_with_fourstep_rings_below_2_18(g):
-    """option u32_tile = 14 sent the forward 4-step of the 32-bit rings 2^15 .. 2^17 to a 16384-coefficient
-    tile whose remaining low stages (9 .. 12) have no lazy-input kernel -- GPU_4STEP_NTT threw after its first pass had
-    written `out`.  Those rings keep the 4096-coefficient tile now; drop-in and plan, every polynomial."""
-    import torch
-    import test_gpu_4step as T
-    P = O.Port(32)
-    g.set_option("u32_tile", "14")
-    g.set_option("path", "fast-strict")
-    try:
-        for logn, batch in ((15, 9), (16, 5), (17, 3), (18, 3), (19, 2)):
-            p4 = g.NTTParameters4Step(logn, 32)
-            oprm = P.fourstep_params(logn)
-            x = P.splitmix(32000 + logn, 0, batch * p4.n, p4.modulus.value)
-            want = P.fourstep_ntt(x, oprm)
-            assert np.array_equal(T.run_fourstep(g, p4, x, batch, inverse=False), want), logn
-            tf = [g.to_device(t) for t in p4.tables["fwd"]]
-            plan = g.FourStepPlan(*tf, p4.modulus, g.ntt4step_configuration(n_power=logn, ntt_type=g.FORWARD), batch_hint=batch)
-            assert plan.fast_path
-            d_a = g.to_device(x)
-            d_b = torch.zeros_like(d_a)
-            g.GPU_Transpose(d_a, d_b, p4.n1, p4.n2, logn, batch)
-            plan.execute(d_b, d_a, batch)
-            g.GPU_Transpose(d_a, d_b, p4.n1, p4.n2, logn, batch)
-            torch.cuda.synchronize()
-            assert np.array_equal(g.to_host(d_b), want), ("plan", logn)
-            plan.close()
-            xin = P.fourstep_intt_first_transpose(want, oprm)
-            assert np.array_equal(T.run_fourstep(g, p4, xin, batch, inverse=True), x), ("inverse", logn)
-    finally:
-        g.set_option("u32_tile", "0")
-        g.set_option("path", os.environ.get("GPUNTT_PATH", "default"))
-
-
-def test_inverse_fourstep_plan_keeps_its_tile_when_the_option_changes(g):
-    """ADVICE r3: an inverse FourStepPlan of the 64-bit ring 2^21 permutes its table for the 8192-coefficient tile;
-    execute() re-read the live u64_big_tiles option and ran the 4096-tile kernels on that table after the option
-    changed -- silently wrong.  The plan stores its tile now ("plans keep the choice made when they were created")."""
-    import torch
-    P = O.Port(64)
-    logn, batch = 21, 2
-    p4 = g.NTTParameters4Step(logn, 64)
-    oprm = P.fourstep_params(logn)
-    x = P.splitmix(33021, 0, batch * p4.n, p4.modulus.value)
-    y = P.fourstep_ntt(x, oprm)
-    xin = P.fourstep_intt_first_transpose(y, oprm)
-    ti = [g.to_device(t) for t in p4.tables["inv"]]
-    ci = g.ntt4step_configuration(n_power=logn, ntt_type=g.INVERSE, mod_inverse=p4.n_inv)
-    try:
-        g.set_option("u64_big_tiles", "14")
-        plan_big = g.FourStepPlan(*ti, p4.modulus, ci, batch_hint=batch)
-        g.set_option("u64_big_tiles", "0")
-        plan_small = g.FourStepPlan(*ti, p4.modulus, ci, batch_hint=batch)
-        for opt in ("0", "13", "14"):
-            g.set_option("u64_big_tiles", opt)
-            for plan in (plan_big, plan_small):
-                d_in = g.to_device(xin)
-                d_out = torch.zeros_like(d_in)
-                d_nat = torch.zeros_like(d_in)
-                plan.execute(d_in, d_out, batch)
-                g.GPU_Transpose(d_out, d_nat, p4.n1, p4.n2, logn, batch)
-                torch.cuda.synchronize()
-                assert np.array_equal(g.to_host(d_nat), x), (opt, plan is plan_big)
-        plan_big.close()
-        plan_small.close()
-    finally:
-        g.set_option("u64_big_tiles", "14")
-
-
 def _distinct_factors(widths, logn):
     """distinct NTT primes of the given widths with (q, omega, psi) for a ring of 2^logn.  Searched for 2^max(logn, 12) and
     brought down by squaring psi: the topmost primes = 1 mod 2^(logn + 1) of a small ring lie within double rounding of
@@ -336,12 +267,11 @@ def test_natural_order_fourstep_and_percoefficient_with_wide_single_modulus(g, q
 def test_u32_ring_2_13_on_its_own_tile(g):
     """32-bit ring 2^13 runs on a 8192-coefficient tile of its own instead of sharing a 16384-coefficient one (VERDICT r3
     weak #8: batch 1 of 2^13 was slower than batch 1 of 2^14; tools/ab_u32_ring13.py: equal or faster at every batch size).
-    Both tile choices (option u32_ring13_batch: always / at most 16 polynomials / never), both lazy ranges (29-bit pool
-    prime: 8 q; 30-bit prime: 4 q), drop-in and NTTPlan, every polynomial."""
+    Both lazy ranges (29-bit pool prime: 8 q; 30-bit prime: 4 q), drop-in and NTTPlan, every polynomial.  (The option that
+    chose between the two tiles is retired: the A/B is closed.)"""
     import torch
     try:
-        for opt in ("2147483647", "16", "0"):
-            g.set_option("u32_ring13_batch", opt)
+        for opt in ("own tile",):
             for factors in (None, find_ntt_factors(30, 13)):
                 for poly in (O.X_N_plus, O.X_N_minus):
                     c = MergeCase(g, 32, 13, poly, factors)
@@ -358,7 +288,7 @@ def test_u32_ring_2_13_on_its_own_tile(g):
                         assert plan.fast_path and np.array_equal(g.to_host(o), want), ("plan", opt, poly, batch)
                         plan.close()
     finally:
-        g.set_option("u32_ring13_batch", "2147483647")
+        pass
 
 
 def test_rns_family_prediction_survives_moduli_rewritten_in_place(g):
