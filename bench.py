@@ -23,6 +23,8 @@ table, scatter of a batch that starts on rank 0, transform, gather back -- each 
 
 Prints ONE JSON line on rank 0 (DESIGN.md "Measurement" has the roofline arithmetic).
 """
+import os
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")  # cpu_baseline's OpenMP leg: idle threads must not spin away a container quota
 import argparse
 import json
 import os
@@ -137,12 +139,20 @@ def cpu_baseline(cfg, case, y_gpu_sample):
         reps = max(1, (4 * threads + polys - 1) // polys)
         xs = np.tile(x, reps)
         assert np.array_equal(B.merge_ntt_mt(xs, prm, inverse, threads)[:y.size], y)
-        done, t0 = 0, time.perf_counter()
-        while time.perf_counter() - t0 < CPU_SECONDS:
-            B.merge_ntt_mt(xs, prm, inverse, threads)
-            done += polys * reps
-        vt = done / (time.perf_counter() - t0)
-        how = "one OpenMP loop over %d polynomials inside the reference build" % (polys * reps)
+        # the box may hand this process fewer cores than it lists (container quota): every thread count T, T/2, T/4, T/8
+        # gets its share of the time budget, the best one is reported with the threads it used
+        cands = sorted({max(1, threads >> k) for k in range(4)}, reverse=True)
+        vt, used = 0.0, threads
+        for tc in cands:
+            done, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < CPU_SECONDS / len(cands):
+                B.merge_ntt_mt(xs, prm, inverse, tc)
+                done += polys * reps
+            rate = done / (time.perf_counter() - t0)
+            if rate > vt:
+                vt, used = rate, tc
+        how = "one OpenMP loop over %d polynomials inside the reference build; best of %s threads: %d" % (polys * reps, cands, used)
+        threads = used
     else:
         vt = _timed_cpu(run_one, polys, threads, CPU_SECONDS) if threads > 1 else v1
     return {"value": vt, "unit": "NTT/s", "cores": threads, "kind": kind, "value_1_core": v1,

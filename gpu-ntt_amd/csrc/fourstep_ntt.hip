@@ -131,7 +131,7 @@ namespace gpuntt
             // behind the go-flag (one device-side modulus) this is a shadow launch: capped grid that
             // walks the tiles, like the Merge shadow launches (launch_impl.hpp)
             const unsigned long long tiles = a.total >> kern::TL;
-            const unsigned grid = (skip_flag != nullptr && tiles > 512) ? 512u : static_cast<unsigned>(tiles);
+            const unsigned grid = (skip_flag != nullptr && tiles > GPUNTT_SHADOW_GRID) ? static_cast<unsigned>(GPUNTT_SHADOW_GRID) : static_cast<unsigned>(tiles);
             switch (log_n1)
             {
                 case 5:

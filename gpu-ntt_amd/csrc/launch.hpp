@@ -13,6 +13,12 @@
 #include "gpuntt/common/common.cuh"
 #include "merge_kernels.hpp"
 
+// blocks of a generic kernel launched BEHIND fast kernels (it returns at once unless the go-flag hands it the call): the
+// blocks walk the tiles.  2 blocks per CU keep the part busy when the launch does own the call
+#ifndef GPUNTT_SHADOW_GRID
+#define GPUNTT_SHADOW_GRID 512
+#endif
+
 namespace gpuntt
 {
     namespace host

@@ -25,7 +25,7 @@ namespace gpuntt
             if (tiles > 0x7fffffffull)
                 throw std::invalid_argument("batch_size * N too large for one launch");
             // shadow launch of an RNS call (the fast kernels usually own it): capped grid, see merge_pass
-            const unsigned grid = (a.skip_flag != nullptr && tiles > 512) ? 512u : static_cast<unsigned>(tiles);
+            const unsigned grid = (a.skip_flag != nullptr && tiles > GPUNTT_SHADOW_GRID) ? static_cast<unsigned>(GPUNTT_SHADOW_GRID) : static_cast<unsigned>(tiles);
             if (p.contig)
             {
                 switch (p.k)
