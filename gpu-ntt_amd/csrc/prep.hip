@@ -357,6 +357,63 @@ namespace gpuntt
             const T y = t[(static_cast<unsigned long long>(2u) << k) * stride];
             return y < q && x == mulmod_r<T>(y, y, q, rinv);
         }
+        // Bulk of the check for rings from 2^17 (n2 >= 4096): a thread verifies FOUR_E entries that share their multiplier --
+        // forward: the entries e = chunk * 256 * FOUR_E + k * 256 + t of one row (ratio W[r*n2 + 1]); inverse: column c of
+        // FOUR_E consecutive rows (ratio W[n2 + c]) -- so the Shoup quotient of the multiplier is derived once per thread
+        // and an entry costs one multiply-subtract and a compare (~12 instructions instead of ~50).
+        constexpr int FOUR_E = 8;
+        template <typename T>
+        __device__ __forceinline__ bool fourstep_bulk_ok(const T* __restrict__ w, unsigned t8, int l1, int l2, int inverse, T q, T rinv)
+        {
+            const unsigned long long n2 = 1ull << l2;
+            bool ok = true;
+            if (!inverse)
+            {
+                const unsigned long long e0 = (static_cast<unsigned long long>(t8 >> 8) << 11) + (t8 & 255u);
+                const unsigned long long row = e0 >> l2;
+                const T v = w[(row << l2) + 1ull];
+                const T vp = shoup_quotient_r<T>(v < q ? v : static_cast<T>(0), q, rinv);
+#pragma unroll
+                for (int k = 0; k < FOUR_E; k++)
+                {
+                    const unsigned long long e = e0 + (static_cast<unsigned long long>(k) << 8);
+                    const unsigned long long j = e & (n2 - 1ull);
+                    const T x = w[e];
+                    ok = ok && x < q;
+                    if (j >= 2ull)
+                    {
+                        const T u = w[e - 1ull];
+                        T r = u * v - dev::mulhi(u, vp) * q; // [0, 2q) for any u
+                        r = (r >= q) ? (r - q) : r;
+                        ok = ok && x == r;
+                    }
+                }
+            }
+            else
+            {
+                const unsigned long long c = t8 & (n2 - 1ull);
+                const unsigned long long r0 = static_cast<unsigned long long>(t8 >> l2) * FOUR_E;
+                const T v = w[n2 + c];
+                const T vp = shoup_quotient_r<T>(v < q ? v : static_cast<T>(0), q, rinv);
+                T u = (r0 > 0ull) ? w[((r0 - 1ull) << l2) + c] : static_cast<T>(0);
+#pragma unroll
+                for (int k = 0; k < FOUR_E; k++)
+                {
+                    const unsigned long long r = r0 + static_cast<unsigned long long>(k);
+                    const T x = w[(r << l2) + c];
+                    ok = ok && x < q;
+                    if (r >= 2ull)
+                    {
+                        T m = u * v - dev::mulhi(u, vp) * q;
+                        m = (m >= q) ? (m - q) : m;
+                        ok = ok && x == m;
+                    }
+                    u = x;
+                }
+            }
+            (void) l1;
+            return ok;
+        }
         template <typename T>
         __device__ __forceinline__ bool fourstep_tables_ok(const T* __restrict__ n1_table, const T* __restrict__ n2_table,
                                                            const T* __restrict__ w, unsigned gid, int l1, int l2, int inverse,
@@ -364,30 +421,32 @@ namespace gpuntt
         {
             const unsigned long long n2 = 1ull << l2;
             const unsigned r = gid >> l2, c = gid & static_cast<unsigned>(n2 - 1ull);
-            const T x = w[gid];
-            bool ok = x < q;
+            const bool bulk = l2 >= 11; // the geometric relations of rows / columns are checked FOUR_E at a time
+            bool ok = true;
+            if (bulk && gid < (1u << (l1 + l2 - 3)))
+                ok = fourstep_bulk_ok<T>(w, gid, l1, l2, inverse, q, rinv);
             if (!inverse)
             {
                 if (c == 0u)
-                    ok = ok && x == static_cast<T>(1);
+                    ok = ok && w[gid] == static_cast<T>(1);
                 else if (c == 1u)
                     ok = ok && brev_powers_ok<T>(w + 1, n2, r, l1, nullptr, q, rinv);
-                else
+                else if (!bulk)
                 {
-                    const T u = w[gid - 1u], v = w[(static_cast<unsigned long long>(r) << l2) + 1u];
-                    ok = ok && u < q && v < q && x == mulmod_r<T>(u, v, q, rinv);
+                    const T x = w[gid], u = w[gid - 1u], v = w[(static_cast<unsigned long long>(r) << l2) + 1u];
+                    ok = ok && x < q && u < q && v < q && x == mulmod_r<T>(u, v, q, rinv);
                 }
             }
             else
             {
                 if (r == 0u)
-                    ok = ok && x == static_cast<T>(1);
+                    ok = ok && w[gid] == static_cast<T>(1);
                 else if (r == 1u)
                     ok = ok && brev_powers_ok<T>(w + n2, 1ull, c, l2, nullptr, q, rinv);
-                else
+                else if (!bulk)
                 {
-                    const T u = w[gid - n2], v = w[n2 + c];
-                    ok = ok && u < q && v < q && x == mulmod_r<T>(u, v, q, rinv);
+                    const T x = w[gid], u = w[gid - n2], v = w[n2 + c];
+                    ok = ok && x < q && u < q && v < q && x == mulmod_r<T>(u, v, q, rinv);
                 }
             }
             if (gid == 0u)

@@ -559,3 +559,70 @@ def test_rns_fallback_inside_the_preparation_kernel(g, bits, golden_dir):
                 assert [int(v) for v in got[p * n:(p + 1) * n]] == ref, ("centred", bits, logn, p)
     finally:
         g.set_option("rns_force_fallback", "0")
+
+
+# ---------------------------------------------------------------- scratch chains under host threads
+def test_threads_sharing_and_owning_streams_with_growing_scratch(g):
+    """Four host threads issue drop-in calls of GROWING ring sizes -- two of them on ONE shared stream, two on streams of
+    their own -- while a fifth replays a graph captured from drop-in calls.  Every chain retires buffers as it grows
+    (nothing is freed or synchronised on), a thread holds its chain's lock from the preparation launch to the last kernel
+    launch of a call, and calls made during the capture have a chain of their own: every result equals the oracle."""
+    import threading
+    import torch
+    shared = torch.cuda.Stream()
+    own = [torch.cuda.Stream(), torch.cuda.Stream()]
+    sizes = (10, 12, 13, 14, 15, 16, 17, 18)
+    cases = {(bits, n): MergeCase(g, bits, n, O.X_N_plus if n % 2 else O.X_N_minus) for bits in (64, 32) for n in sizes}
+    errors = []
+
+    def work(tid, stream, bits):
+        try:
+            for rep in range(3):
+                for n in sizes:
+                    c = cases[bits, n]
+                    batch = 1 + (tid + rep) % 3
+                    x = c.random(batch, 60000 + 100 * tid + n)
+                    want = c.P.merge_ntt(x, c.oprm)
+                    with torch.cuda.stream(stream):
+                        d = g.to_device(x)
+                        o = torch.zeros_like(d)
+                        g.GPU_NTT(d, o, c.fwd_dev, c.prm.modulus, c.cfg(stream=stream), batch)
+                        g.GPU_INTT(o, d, c.inv_dev, c.prm.modulus, c.cfg(True, stream=stream), batch)
+                        g.GPU_NTT(d, o, c.fwd_dev, c.prm.modulus, c.cfg(stream=stream), batch)
+                        stream.synchronize()
+                    if not np.array_equal(g.to_host(o), want):
+                        errors.append((tid, bits, n, rep))
+        except Exception as e:  # noqa: BLE001
+            errors.append((tid, repr(e)))
+
+    cg = cases[64, 13]
+    xg = cg.random(4, 61234)
+    dg = g.to_device(xg)
+    og = torch.zeros_like(dg)
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        g.GPU_NTT(dg, og, cg.fwd_dev, cg.prm.modulus, cg.cfg(stream=torch.cuda.current_stream()), 4)
+    want_g = cg.P.merge_ntt(xg, cg.oprm)
+
+    def replay():
+        try:
+            for _ in range(40):
+                og.zero_()
+                graph.replay()
+                torch.cuda.synchronize()
+                if not np.array_equal(g.to_host(og), want_g):
+                    errors.append(("graph",))
+        except Exception as e:  # noqa: BLE001
+            errors.append(("graph", repr(e)))
+
+    threads = [threading.Thread(target=work, args=(0, shared, 64)), threading.Thread(target=work, args=(1, shared, 32)),
+               threading.Thread(target=work, args=(2, own[0], 64)), threading.Thread(target=work, args=(3, own[1], 32)),
+               threading.Thread(target=replay)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errors, errors[:5]
