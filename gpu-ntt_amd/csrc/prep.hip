@@ -606,15 +606,38 @@ namespace gpuntt
                 return st == hipStreamCaptureStatusActive ? (id | (1ull << 63)) : 0ull;
             }
 
+            // the chain of (current device, stream, capture state).  Inside a WorkspaceScope -- one API call -- neither can
+            // change, so the answer of the first lookup is kept (a drop-in call asks three or four times: three HIP runtime
+            // calls and a map lookup each)
+            struct SlotCache
+            {
+                hipStream_t stream = nullptr;
+                Slot* slot = nullptr;
+                bool capturing = false;
+            };
+            thread_local SlotCache t_slot_cache;
+
             Slot& slot_of(hipStream_t stream, bool* capturing = nullptr)
             {
+                if (t_scope_depth > 0 && t_slot_cache.slot != nullptr && t_slot_cache.stream == stream)
+                {
+                    if (capturing != nullptr)
+                        *capturing = t_slot_cache.capturing;
+                    return *t_slot_cache.slot;
+                }
                 int dev = 0;
                 GPUNTT_HIP_CHECK(hipGetDevice(&dev));
                 const unsigned long long cap = capture_key(stream);
                 if (capturing != nullptr)
                     *capturing = cap != 0ull;
-                std::lock_guard<std::mutex> lock(g_ws_mutex);
-                return g_ws[std::make_tuple(dev, stream, cap)]; // map nodes never move and are never erased
+                Slot* sp;
+                {
+                    std::lock_guard<std::mutex> lock(g_ws_mutex);
+                    sp = &g_ws[std::make_tuple(dev, stream, cap)]; // map nodes never move and are never erased
+                }
+                if (t_scope_depth > 0)
+                    t_slot_cache = SlotCache{stream, sp, cap != 0ull};
+                return *sp;
             }
 
             // takes the chain's lock: for the rest of the call inside a WorkspaceScope, else until the guard dies
@@ -646,6 +669,7 @@ namespace gpuntt
                 for (auto it = t_held.rbegin(); it != t_held.rend(); ++it)
                     (*it)->unlock();
                 t_held.clear();
+                t_slot_cache = SlotCache{};
             }
         }
 

@@ -19,5 +19,9 @@ rm -rf "$O/kt_c2" "$O/kt_c3"
 # north_star's table: every ring 2^12 .. 2^24, both algorithms, both word sizes
 python bench.py --sweep --sweep-bits 64 > "$O/sweep_u64.jsonl" 2> "$O/sweep_u64.err"
 python bench.py --sweep --sweep-bits 32 > "$O/sweep_u32.jsonl" 2> "$O/sweep_u32.err"
+python bench.py --sweep --sweep-bits 64 --direction inv > "$O/sweep_u64_inv.jsonl" 2> "$O/sweep_u64_inv.err"
+python bench.py --sweep --sweep-bits 32 --direction inv > "$O/sweep_u32_inv.jsonl" 2> "$O/sweep_u32_inv.err"
+python tools/bench_small_dropin.py > "$O/small_dropin.txt" 2>/dev/null
+python tools/bench_4step_small.py > "$O/4step_small_calls.txt" 2>/dev/null
 python tools/bench_batch1.py > "$O/batch1.txt" 2>&1
 ls -la "$O"
