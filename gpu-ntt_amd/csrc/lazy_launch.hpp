@@ -118,8 +118,8 @@ namespace gpuntt
         // with a 61- / 62-bit prime, moduli rewritten in place with wider ones, a captured graph replayed after the moduli
         // changed, moduli outside the documented domain) is transformed by the preparation kernel ITSELF (kern::SlowArgs:
         // slow, never wrong) -- no generic launch behind any Merge call.  all_families: every lazy family behind the exact
-        // state (option rns_predict = 0, path = fast-strict, a full prediction table); the 4-step and PerCoefficient entry
-        // points keep the generic kernels behind their calls.
+        // state (option rns_predict = 0, path = fast-strict, a full prediction table); only the 4-step entry points keep the
+        // generic kernels behind their calls (table check).
         struct RnsGuess
         {
             unsigned state;      // predicted go-flag state (kern::GO_*); meaningful when !all_families

@@ -1171,6 +1171,8 @@ namespace gpuntt
             const T* mul_in;       // GPU_PolyMul: multiplied into the forward result
             const int* poly_order; // *_Poly_Ordered: polynomial p lives in slot poly_order[p]
             unsigned long long polys;
+            int col_log;           // >= 0: PerCoefficient layout -- polynomial p is COLUMN p of a 2^n x 2^col_log row-major
+                                   // matrix (coefficient i at i * 2^col_log + p); -1: polynomial p at p << n (PerPolynomial)
             unsigned flags;        // F_SIGNED_IN | F_SCALE | F_CENTERED
             int inverse;
             int enabled;           // 0: publish GO_GENERIC only (path = fast-strict: the tests want the lazy families to own the call)

@@ -178,6 +178,7 @@ namespace gpuntt
                 slow.mul_in = mul_in;
                 slow.poly_order = poly_order;
                 slow.polys = static_cast<unsigned long long>(batch_size);
+                slow.col_log = -1;
                 slow.flags = io_flags & (kern::F_SIGNED_IN | kern::F_SCALE | kern::F_CENTERED);
                 slow.inverse = inverse ? 1 : 0;
                 slow.enabled = forced_path() == 3 ? 0 : 1; // fast-strict: the lazy families must own the call
@@ -391,8 +392,19 @@ namespace gpuntt
             unsigned* go_flag = reinterpret_cast<unsigned*>(tail_p);
             auto* norm_arr = reinterpret_cast<lazy::NormConst*>(tail_p + 16);
             const bool neg = (poly == ReductionPolynomial::X_N_plus);
+            // the per-lane-modulus kernels serve every stack of the documented domain; one with a modulus outside it is
+            // transformed by the preparation kernel itself, column by column (kern::SlowArgs::col_log) -- nothing behind the call
+            kern::SlowArgs<TU> slow{};
+            slow.in = in;
+            slow.out = out;
+            slow.polys = static_cast<unsigned long long>(batch_size);
+            slow.col_log = log_w;
+            slow.flags = (in_flags | out_flags) & (kern::F_SIGNED_IN | kern::F_SCALE | kern::F_CENTERED);
+            slow.inverse = INV ? 1 : 0;
+            slow.enabled = forced_path() == 3 ? 0 : 1;
             host::launch_prep<TU>(roots, ws, mods_dev, TU(0), mod_count, n_power, neg, 0, INV ? ninv_dev : nullptr,
-                                  INV ? ws_ninv : nullptr, go_flag, norm_arr, stream, nullptr, nullptr, INV);
+                                  INV ? ws_ninv : nullptr, go_flag, norm_arr, stream, nullptr, nullptr, INV, nullptr, false, 0u,
+                                  &slow);
             kern::LazyArgsT<TU> a{};
             a.tw = ws;
             a.mods = mods_dev;
@@ -616,13 +628,10 @@ namespace gpuntt
             const bool lazy = run_percoefficient_lazy_rns<TU, false>(device_in, device_out, root_of_unity_table, modulus,
                                                                      mod_count, nullptr, cfg.n_power, cfg.reduction_poly,
                                                                      batch_size, in_flags, 0u, cfg.stream, &skip_flag);
+            if (lazy)
+                return; // (a stack outside the domain: the preparation kernel's own fall-back)
             if (forced_path() == 3)
-            {
-                if (!lazy)
-                    throw std::invalid_argument("fast path unavailable for this call (path = fast-strict)");
-                return; // test hook: no generic shadow launches
-            }
-            a.skip_flag = skip_flag;
+                throw std::invalid_argument("fast path unavailable for this call (path = fast-strict)");
             run_percoefficient<TU, false>(a, cfg.n_power, batch_size, in_flags, 0u, cfg.stream);
             return;
         }
@@ -675,13 +684,10 @@ namespace gpuntt
                                                                     root_of_unity_table, modulus, mod_count, cfg.mod_inverse,
                                                                     cfg.n_power, cfg.reduction_poly, batch_size, 0u, out_flags,
                                                                     cfg.stream, &skip_flag);
+            if (lazy)
+                return;
             if (forced_path() == 3)
-            {
-                if (!lazy)
-                    throw std::invalid_argument("fast path unavailable for this call (path = fast-strict)");
-                return; // test hook: no generic shadow launches
-            }
-            a.skip_flag = skip_flag;
+                throw std::invalid_argument("fast path unavailable for this call (path = fast-strict)");
             run_percoefficient<TU, true>(a, cfg.n_power, batch_size, 0u, out_flags, cfg.stream);
             return;
         }

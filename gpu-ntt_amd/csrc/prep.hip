@@ -103,15 +103,19 @@ namespace gpuntt
                 const Modulus<T> md = mods[prime];
                 const dev::ModCtx<T> m{md.value, md.bit, md.mu};
                 const unsigned long long slot = (sa.poly_order != nullptr) ? static_cast<unsigned>(sa.poly_order[p]) : p;
-                const T* src = static_cast<const T*>(sa.in) + (slot << n);
-                T* dst = sa.out + (slot << n);
+                // coefficient e of the polynomial lies at base + (e << es): rows of a PerPolynomial batch, or a column of the
+                // PerCoefficient matrix (reference ForwardCoreTranspose / InverseCoreTranspose, ntt.cu:1693-1835, 1957-2074)
+                const int es = sa.col_log >= 0 ? sa.col_log : 0;
+                const unsigned long long base = sa.col_log >= 0 ? slot : (slot << n);
+                const T* src = static_cast<const T*>(sa.in) + base;
+                T* dst = sa.out + base;
                 const T* tab = roots + (static_cast<unsigned long long>(prime) << n);
                 for (unsigned long long e = threadIdx.x; e < N; e += 256)
                 {
-                    T x = src[e];
+                    T x = src[e << es];
                     if ((sa.flags & F_SIGNED_IN) && static_cast<S>(x) < 0)
                         x = static_cast<T>(m.q + x);
-                    dst[e] = x;
+                    dst[e << es] = x;
                 }
                 __threadfence();
                 __syncthreads();
@@ -123,13 +127,13 @@ namespace gpuntt
                         const unsigned long long lo = b & ((1ull << P) - 1ull), grp = b >> P;
                         const unsigned long long i0 = (grp << (P + 1)) | lo, i1 = i0 + (1ull << P);
                         const T w = tab[grp + (negacyclic ? (1ull << (n - 1 - P)) : 0ull)];
-                        T U = dst[i0], V = dst[i1];
+                        T U = dst[i0 << es], V = dst[i1 << es];
                         if (sa.inverse)
                             dev::gs_butterfly(U, V, w, m);
                         else
                             dev::ct_butterfly(U, V, w, m);
-                        dst[i0] = U;
-                        dst[i1] = V;
+                        dst[i0 << es] = U;
+                        dst[i1 << es] = V;
                     }
                     __threadfence();
                     __syncthreads();
@@ -140,16 +144,16 @@ namespace gpuntt
                     const T ninv = scale ? ninv_arr[prime] : static_cast<T>(0);
                     for (unsigned long long e = threadIdx.x; e < N; e += 256)
                     {
-                        T x = dst[e];
+                        T x = dst[e << es];
                         if (sa.mul_in != nullptr)
-                            x = m.mul(x, sa.mul_in[(slot << n) + e]);
+                            x = m.mul(x, sa.mul_in[base + (e << es)]);
                         if (scale)
                         {
                             x = m.mul(x, ninv);
                             if (sa.flags & F_CENTERED)
                                 x = (x > (m.q >> 1)) ? static_cast<T>(x - m.q) : x;
                         }
-                        dst[e] = x;
+                        dst[e << es] = x;
                     }
                 }
                 __syncthreads();

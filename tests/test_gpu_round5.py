@@ -557,6 +557,27 @@ def test_rns_fallback_inside_the_preparation_kernel(g, bits, golden_dir):
                 q = cases[p % mc].q
                 ref = [int(v) - q if int(v) > q // 2 else int(v) for v in x[p * n:(p + 1) * n]]
                 assert [int(v) for v in got[p * n:(p + 1) * n]] == ref, ("centred", bits, logn, p)
+        # the PerCoefficient layout with a stack: the same fall-back walks COLUMNS (coefficient i of column c at i * w + c)
+        for logn, w, mc in ((9, 512, 3), (6, 256, 5), (3, 1024, 2)):
+            widths = ([60, 61, 62, 60, 59] if bits == 64 else [30, 29, 30, 28, 27])[:mc]
+            cases, d_fwd, d_inv = _rns_stack(g, bits, logn, widths, O.X_N_plus)
+            n = 1 << logn
+            mods = g.modulus_array_to_device([c.prm.modulus for c in cases], bits)
+            ninv = g.to_device(np.array([c.prm.n_inv for c in cases], dtype=cases[0].P.T))
+            cols = np.stack([cases[p % mc].P.splitmix(99500 + p, 0, n, cases[p % mc].q) for p in range(w)])
+            mat = np.ascontiguousarray(cols.T)
+            want_f = np.stack([cases[p % mc].P.merge_ntt(cols[p], cases[p % mc].oprm) for p in range(w)]).T
+            cfg = g.ntt_rns_configuration(n_power=logn, ntt_layout=g.PerCoefficient, reduction_poly=O.X_N_plus)
+            icfg = g.ntt_rns_configuration(n_power=logn, ntt_type=g.INVERSE, ntt_layout=g.PerCoefficient,
+                                           reduction_poly=O.X_N_plus, mod_inverse=ninv)
+            d = g.to_device(mat.reshape(-1))
+            o = torch.zeros_like(d)
+            g.GPU_NTT(d, o, d_fwd, mods, cfg, w, mc)
+            torch.cuda.synchronize()
+            assert np.array_equal(g.to_host(o).reshape(n, w), want_f), ("percoefficient fwd", bits, logn, w, mc)
+            g.GPU_INTT_Inplace(o, d_inv, mods, icfg, w, mc)
+            torch.cuda.synchronize()
+            assert np.array_equal(g.to_host(o).reshape(n, w), mat), ("percoefficient inv", bits, logn, w, mc)
     finally:
         g.set_option("rns_force_fallback", "0")
 
