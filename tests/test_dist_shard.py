@@ -116,13 +116,14 @@ def test_bench_starts_its_own_ranks_without_torchrun():
 
 def test_first_multigpu_lease_script_parses_and_names_existing_programs():
     """tools/first_multigpu_lease.sh --list: the command list of the first multi-GPU lease -- RCCL smoke,
-    headline at 2 / 4 / 8 ranks, the strongly scaled c4, the sweep, the digest check, the 1-GPU reference points; every
+    headline at 2 / 4 / 8 ranks, the strongly scaled c4, the sweep, the digest check, the C++ multi-device example, the 1-GPU
+    reference points; every
     step has a timeout, a unique rendezvous port, a rank count that matches its name and a program that exists"""
     r = subprocess.run(["bash", os.path.join(ROOT, "tools", "first_multigpu_lease.sh"), "--list"], capture_output=True,
                        text=True, timeout=60)
     assert r.returncode == 0, r.stderr
     steps = [l.split("|", 2) for l in r.stdout.splitlines() if l.strip()]
-    assert len(steps) == 17
+    assert len(steps) == 20
     names = [s[1] for s in steps]
     order = [n.rsplit("_x", 1)[0] for n in names]
     assert order[:3] == ["rccl_smoke"] * 3, "the RCCL smoke test must come first"
@@ -134,6 +135,10 @@ def test_first_multigpu_lease_script_parses_and_names_existing_programs():
         assert int(tmo) >= 60
         n = int(name.rsplit("_x", 1)[1])
         words = cmd.split()
+        if name.startswith("cpp_multi_device"):  # the C++ product: one process, one host thread per device
+            assert os.path.exists(os.path.join(ROOT, "tests", "cpp", "example_multi_device.cpp"))
+            assert words[-2] == str(n), "asks for as many devices as the step's name says"
+            continue
         prog = [w for w in words if w.endswith(".py")][0]
         assert os.path.exists(os.path.join(ROOT, prog)), prog
         if n > 1:

@@ -30,6 +30,10 @@ done
 for N in $GPUS; do
   STEPS+=("300|digests_x$N|$TR --nproc-per-node $N --master-port {P} tools/multigpu_digests.py")
 done
+# the C++ product on every device of the node: one host thread per device, drop-in call + NTTPlan, every polynomial checked
+for N in $GPUS; do
+  STEPS+=("300|cpp_multi_device_x$N|make -s -C tests/cpp && tests/cpp/_bin/example_multi_device 16 512 $N 8")
+done
 # the single-GPU reference points the scaling table is read against
 STEPS+=("600|bench_c2_x1|python bench.py --gpus 1 --steps 20 --warmup 5")
 STEPS+=("600|bench_c4_strong_x1|python bench.py --gpus 1 --config c4 --steps 50 --warmup 10")
@@ -69,7 +73,7 @@ for s in "${STEPS[@]}"; do
   dt=$(( $(date +%s) - t0 ))
   if [ $rc -eq 0 ]; then st=PASS; elif [ $rc -eq 124 ] || [ $rc -eq 137 ]; then st=TIMEOUT; else st="FAIL(rc=$rc)"; fi
   # the one-line results of the step, if it printed any
-  res="$(grep -E '^(RCCL_SMOKE|MULTIGPU_DIGESTS|\{"metric")' "$log" | tail -n 1 | cut -c1-220)"
+  res="$(grep -E '^(RCCL_SMOKE|MULTIGPU_DIGESTS|All Correct on|\{"metric")' "$log" | tail -n 1 | cut -c1-220)"
   printf '%-8s %-22s %4ss  %s\n' "$st" "$name" "$dt" "$res" | tee -a "$OUT/VERDICT.txt"
 done
 # scaling table from the bench lines (value = whole-job NTT/s)
