@@ -95,7 +95,7 @@ EXPORTED_SYMBOLS = ["gpuntt_last_error", "gpuntt_version"] + [
               "4step_params", "plan_workspace_bytes", "plan_create", "plan_execute", "plan_fast_path",
               "plan_destroy", "operator_gpu", "4step_plan_workspace_bytes", "4step_plan_create",
               "4step_plan_execute", "4step_plan_fast_path", "4step_plan_destroy",
-              "generate_power_table", "generate_4step_w", "butterfly_unit")
+              "generate_power_table", "generate_4step_w", "butterfly_unit", "debug_recip_norm")
     for s in ("u32", "u64")] + ["gpuntt_release_workspaces", "gpuntt_set_option"]
 
 # GPUNTT_* environment variables of the A/B scripts and tests -> library options.  The C++ library reads no
@@ -566,6 +566,16 @@ def operator_gpu(op, a, b, modulus):
     out = torch.empty_like(a)
     fn = getattr(lib, "gpuntt_operator_gpu_u%d" % modulus.bits)
     _check(fn(int(op), _ptr(a), _ptr(b), _ptr(out), modulus.c(), ctypes.c_uint64(a.numel()), _stream(None)))
+    return out
+
+
+def debug_recip_norm(q):
+    """diagnostic: the preparation kernels' normalised reciprocal of every word of the device tensor q; returns a new tensor"""
+    import torch
+    _require_gpu(q)
+    out = torch.empty_like(q)
+    fn = getattr(load_library(), "gpuntt_debug_recip_norm_u%d" % (q.element_size() * 8))
+    _check(fn(_ptr(q), _ptr(out), ctypes.c_uint64(q.numel()), _stream(None)))
     return out
 
 

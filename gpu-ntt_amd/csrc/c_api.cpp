@@ -10,6 +10,15 @@
 #include "gpuntt/ntt_merge/ntt.cuh"
 #include "gpuntt_c.h"
 
+namespace gpuntt
+{
+    namespace host
+    {
+        // prep.hip (diagnostic): the preparation kernels' normalised reciprocal of every q[i]
+        template <typename T> void debug_recip_norm(const T* q, T* out, unsigned long long count, hipStream_t stream);
+    } // namespace host
+} // namespace gpuntt
+
 using namespace gpuntt;
 
 namespace
@@ -654,6 +663,13 @@ extern "C"
     {                                                                                             \
         GPUNTT_NEED(a, out)                                                                       \
         return operator_gpu<T>(op, a, b, out, modulus, count, stream);                            \
+    }                                                                                             \
+    int gpuntt_debug_recip_norm_##S(const T* q, T* out, uint64_t count, void* stream)              \
+    {                                                                                             \
+        GPUNTT_NEED(q, out)                                                                       \
+        return guarded([&] {                                                                      \
+            gpuntt::host::debug_recip_norm<T>(q, out, count, static_cast<hipStream_t>(stream));   \
+        });                                                                                       \
     }                                                                                             \
     int gpuntt_butterfly_unit_##S(int gentleman_sande, T* u, T* v, const T* roots, CM modulus,    \
                                   uint64_t count, void* stream)                                   \

@@ -275,6 +275,8 @@ namespace gpuntt
                                                                        const Modulus<uint32_t>*, const uint32_t*,
                                                                        lazy::Tw32*, unsigned*, lazy::NormConst*, hipStream_t,
                                                                        unsigned*, const FourStepVeto&, const uint32_t*);
+        // diagnostic: the preparation kernels' normalised reciprocal floor(2^(W-1+b) / q) of every q[i] (0 for q < 3 / powers of two)
+        template <typename T> void debug_recip_norm(const T* q, T* out, unsigned long long count, hipStream_t stream);
         // host Shoup companion floor(w * 2^W / q)
         inline uint64_t shoup_host(uint64_t w, uint64_t q)
         {

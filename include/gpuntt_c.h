@@ -280,6 +280,11 @@ extern "C"
     int gpuntt_operator_gpu_u64(int op, const uint64_t* a, const uint64_t* b, uint64_t* out,
                                 gpuntt_modulus64 modulus, uint64_t count, void* stream);
 
+    /* diagnostic: the normalised reciprocal floor(2^(W-1+b) / q) (b = bit length of q; 0 for q < 3 and powers of two) the
+     * preparation kernels derive for every device-side modulus -- exactness is checked against integers in the tests */
+    int gpuntt_debug_recip_norm_u32(const uint32_t* q, uint32_t* out, uint64_t count, void* stream);
+    int gpuntt_debug_recip_norm_u64(const uint64_t* q, uint64_t* out, uint64_t count, void* stream);
+
     /* diagnostic: the public device butterflies CooleyTukeyUnit (gentleman_sande = 0) / GentlemanSandeUnit (1)
      * (reference src/include/gpuntt/ntt_merge/ntt.cuh:69-92) applied to the pairs (u[i], v[i]) with roots[i], in place */
     int gpuntt_butterfly_unit_u32(int gentleman_sande, uint32_t* u, uint32_t* v, const uint32_t* roots,

@@ -647,3 +647,31 @@ def test_threads_sharing_and_owning_streams_with_growing_scratch(g):
         t.join()
     torch.cuda.synchronize()
     assert not errors, errors[:5]
+
+
+@pytest.mark.parametrize("bits", [64, 32])
+def test_preparation_reciprocal_is_exact(g, bits):
+    """floor(2^(W-1+b) / q) as the preparation kernels derive it for every device-side modulus (round 5: a double-precision
+    estimate + exact 128-bit corrections instead of a 64-step restoring division -- it sits on the critical path of every
+    drop-in RNS call).  Every Shoup quotient of an RNS call is built on it: it must be EXACT.  Edge moduli (just above /
+    below powers of two, the pool primes, 3, the largest words) and 200 000 random ones against Python integers."""
+    import torch
+    W = bits
+    rng = np.random.default_rng(bits)
+    qs = [3, 5, 6, 7, 10000, 469762049, (1 << (W - 2)) - 1, (1 << (W - 2)) + 1, (1 << (W - 1)) - 1, (1 << (W - 1)) + 1,
+          (1 << W) - 1, (1 << W) - 2, 4, 8, 1 << (W - 1), 2, 1, 0]
+    if bits == 64:
+        qs += [576460756061519873, 576460752308273153, (1 << 61) - 1, (1 << 62) - 57, (1 << 60) + 33, (1 << 59) + 1,
+               (1 << 62) + 1, (1 << 61) + 1, (1 << 33) + 1, (1 << 32) - 1, (1 << 32) + 1, (1 << 53) + 1, (1 << 53) - 1]
+    for b in range(2, W + 1):
+        qs += [(1 << (b - 1)) + 1, (1 << b) - 1, (1 << (b - 1)) + (1 << (b - 2)) if b > 2 else 3]
+    widths = rng.integers(2, W + 1, size=200000)
+    rnd = [int(rng.integers(1 << (int(b) - 1), 1 << int(b), dtype=np.uint64)) if b < 64 else
+           int(rng.integers(1 << 63, (1 << 64) - 1, dtype=np.uint64, endpoint=True)) for b in widths]
+    qs = np.array(qs + rnd, dtype=np.uint64).astype(g.np_dtype(bits))
+    got = g.to_host(g.debug_recip_norm(g.to_device(qs)))
+    torch.cuda.synchronize()
+    for q, r in zip(qs.tolist(), got.tolist()):
+        q = int(q)
+        want = 0 if (q < 3 or q & (q - 1) == 0) else (1 << (W - 1 + q.bit_length())) // q
+        assert int(r) == want, (bits, q, int(r), want)

@@ -7,6 +7,7 @@ mkdir -p "$O"
 cd "$R"
 python bench.py --steps 20 --warmup 5 > "$O/bench_line.json" 2> "$O/bench_line.err"
 python bench.py --steps 20 --warmup 5 --api plan --no-traffic --no-cpu-baseline > "$O/bench_line_plan.json" 2>/dev/null
+python bench.py --steps 20 --warmup 5 --direction inv > "$O/bench_line_c2i.json" 2> "$O/bench_line_c2i.err"
 python bench.py --config c3 --steps 5 --warmup 2 > "$O/bench_line_c3.json" 2> "$O/bench_line_c3.err"
 python bench.py --config c4 --steps 50 --warmup 10 > "$O/bench_line_c4.json" 2> "$O/bench_line_c4.err"
 python bench.py --config c5 --steps 20 --warmup 5 > "$O/bench_line_c5.json" 2> "$O/bench_line_c5.err"
