@@ -89,8 +89,10 @@ namespace gpuntt
             // extra launch; below that one generic launch is the whole job.
             if (mod_count == 1 && n_power >= (sizeof(TU) == 8 ? 5 : 11))
                 return true;
-            // RNS stacks pay for the dual launch: not worth it for tiny jobs
-            return (static_cast<unsigned long long>(batch_size) << n_power) >= (1ull << 15) &&
+            // RNS stacks: preparation launch + the transform against one launch of the Barrett kernels -- from one tile of
+            // coefficients the fast kernels win (4 polynomials of 2^12 with 4 primes: 13 us against 32 us on the generic
+            // kernels, which round 4's threshold of 2^15 coefficients still chose; profiles/r05_small_dropin.txt)
+            return (static_cast<unsigned long long>(batch_size) << n_power) >= (1ull << 12) &&
                    batch_size >= 2;
         }
 
