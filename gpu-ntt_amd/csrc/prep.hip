@@ -897,7 +897,6 @@ namespace gpuntt
                 std::atomic<int> no_scratch{0}; // test hook: behave as if the twiddle scratch could not be allocated
                 std::atomic<int> check_4step{1}; // 4-step entry points: verify the caller's three tables on the device (prep_merge_from_fourstep)
                 std::atomic<int> rns_predict{1}; // drop-in RNS calls: enqueue only the lazy family the stack needed last time
-                std::atomic<int> two_sweep_big{0}; // EXPERIMENT: 64-bit rings 2^23 / 2^24 forward in two sweeps on 16384-coefficient tiles
                 std::atomic<int> rns_force_fallback{0}; // test hook: the preparation kernel's own fall-back serves every drop-in RNS Merge call
             } g_opt;
         } // namespace
@@ -929,12 +928,6 @@ namespace gpuntt
                     return false;
                 g_opt.path = m;
             }
-            else if (k == "two_sweep_big")
-            {
-                if (!one_of({0, 1}))
-                    return false;
-                g_opt.two_sweep_big = iv;
-            }
             else if (k == "no_scratch" || k == "check_4step_tables" || k == "rns_predict" || k == "rns_force_fallback")
             {
                 if (!one_of({0, 1}))
@@ -951,7 +944,6 @@ namespace gpuntt
         }
 
         int forced_path() { return g_opt.path.load(std::memory_order_relaxed); }
-        bool lazy_two_sweep_big() { return g_opt.two_sweep_big.load(std::memory_order_relaxed) != 0; }
         static bool rns_predict_enabled() { return g_opt.rns_predict.load(std::memory_order_relaxed) != 0; }
         static bool rns_force_fallback() { return g_opt.rns_force_fallback.load(std::memory_order_relaxed) != 0; }
 
