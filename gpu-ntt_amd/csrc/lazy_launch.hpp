@@ -323,8 +323,32 @@ namespace gpuntt
         // 0 size heuristic, 1 generic kernels, 2 fast, 3 fast-strict (a call the fast kernels cannot take throws),
         // 4 generic-capped (4-step RNS overload: generic kernels on the capped shadow grid)
         int forced_path();
-        // stages handled by the contiguous pass of the fast path (option contig_k overrides, 8..12)
+        // stages handled by the contiguous pass of the two-pass plans on 4096-coefficient tiles (8..12)
         int lazy_contig_k(int n);
+        // the same for whole Merge transforms, by word size and direction: the split was swept in round 5 for every ring
+        // 2^13 .. 2^20 (profiles/r05_stage_split_sweep.txt: strided stages 4 .. 8); where another split than the rule
+        // "six strided stages" wins by more than the noise it is listed here (32-bit inverse 2^15: 9 + 6 instead of 10 + 5,
+        // 0.177 against 0.211 ms per 2^26 coefficients; the others 1-4 %).  The 4-step plans keep lazy_contig_k.
+        template <typename T> inline int lazy_contig_k_merge(int n, bool inverse)
+        {
+            if (sizeof(T) == 4)
+            {
+                if (!inverse && n >= 15 && n <= 17)
+                    return n - 7; // 8 / 9 / 10 contiguous stages behind 7 strided ones
+                if (inverse && n == 15)
+                    return 9;
+            }
+            else
+            {
+                if (!inverse && n == 15)
+                    return 8;
+                if (inverse && (n == 15 || n == 16))
+                    return 11;
+                if (inverse && n == 17)
+                    return 12;
+            }
+            return lazy_contig_k(n);
+        }
 
         // consecutive passes of one transform walk the batch in opposite directions (Infinity Cache reuse of the hand-off)
         constexpr bool lazy_reverse_passes() { return true; }
@@ -475,7 +499,7 @@ namespace gpuntt
                 a.flags |= first_in_flags | last_out_flags;
                 return launch_small_rns_lazy<T, INV>(base.n, a, stream);
             }
-            const Plan pl = make_plan_tl(pn, tl, tl == 12 ? lazy_contig_k(pn) : tl);
+            const Plan pl = make_plan_tl(pn, tl, tl == 12 ? (partial ? lazy_contig_k(pn) : lazy_contig_k_merge<T>(pn, INV)) : tl);
             const void* src = base.in;
             int fwd_bound = partial ? 16 : 1; // range bound of the values in flight (forward, 31 q range: see fwd_bound_after)
             for (int i = 0; i < pl.count; i++)
