@@ -92,7 +92,8 @@ namespace gpuntt
             // RNS stacks: preparation launch + the transform against one launch of the Barrett kernels -- from one tile of
             // coefficients the fast kernels win (4 polynomials of 2^12 with 4 primes: 13 us against 32 us on the generic
             // kernels, which round 4's threshold of 2^15 coefficients still chose; profiles/r05_small_dropin.txt)
-            return (static_cast<unsigned long long>(batch_size) << n_power) >= (1ull << 12) &&
+            // (tiny single-modulus rings -- below the sizes above -- keep round 4's threshold of 2^15 coefficients)
+            return (static_cast<unsigned long long>(batch_size) << n_power) >= (mod_count > 1 ? (1ull << 12) : (1ull << 15)) &&
                    batch_size >= 2;
         }
 
