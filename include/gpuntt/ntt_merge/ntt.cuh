@@ -184,9 +184,9 @@ namespace gpuntt
     // kernels' stage layout, n^-1 pairs, the choice between the fast (lazy-residue) and the generic
     // kernels -- is done ONCE here, on `stream`, into `workspace_device` (workspace_bytes() bytes,
     // caller-owned; nullptr = the plan allocates and owns it).  execute() then launches the transform
-    // kernels and nothing else: no allocation, no synchronisation, no preparation launch, no shadow
-    // launches for RNS stacks (the moduli are host values here, so the path is known), and it can be
-    // captured into a hipGraph without a warm-up call.  The constructor waits for `stream` before it returns
+    // kernels and nothing else: no allocation, no synchronisation, no preparation launch, no go-flag
+    // for RNS stacks (the moduli are host values here, so the kernel family is known), and it can be
+    // captured into a hipGraph at once.  The constructor waits for `stream` before it returns
     // (one host wait per plan): execute() may run on any stream with no dependency on the construction stream.
     //   table_device       the caller's table exactly as for GPU_NTT / GPU_INTT (slot i at i << n_power);
     //                      it is only read during construction (fast path) -- the generic path keeps
