@@ -675,3 +675,69 @@ def test_preparation_reciprocal_is_exact(g, bits):
         q = int(q)
         want = 0 if (q < 3 or q & (q - 1) == 0) else (1 << (W - 1 + q.bit_length())) // q
         assert int(r) == want, (bits, q, int(r), want)
+
+
+def test_fourstep_table_check_inside_a_captured_graph(g):
+    """The veto word of a captured 4-step call lives in the capture's own scratch chain (its reset is a node of the graph,
+    the epoch is baked into the kernel arguments): the graph is replayed with consistent tables, after ONE word of W was
+    rewritten in place, and after the word was restored -- oracle, the generic kernels' result for the corrupted table,
+    oracle again -- while eager 4-step calls of another ring run on the capture stream in between."""
+    import torch
+    P = O.Port(64)
+    logn, batch = 17, 3
+    p4 = g.NTTParameters4Step(logn, 64)
+    oprm = P.fourstep_params(logn)
+    x = P.splitmix(62017, 0, batch * p4.n, p4.modulus.value)
+    want = P.fourstep_ntt(x, oprm)  # natural-order result
+    t1, t2, w = (g.to_device(t) for t in p4.tables["fwd"])
+    d_nat = g.to_device(x)
+    d_in = torch.zeros_like(d_nat)
+    d_out = torch.zeros_like(d_nat)
+    d_res = torch.zeros_like(d_nat)
+    g.GPU_Transpose(d_nat, d_in, p4.n1, p4.n2, logn, batch)
+    torch.cuda.synchronize()
+    cfg_stream = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=cfg_stream):
+        g.GPU_4STEP_NTT(d_in, d_out, t1, t2, w, p4.modulus,
+                        g.ntt4step_configuration(n_power=logn, stream=torch.cuda.current_stream()), batch)
+
+    def result():
+        d_out.fill_(-5)
+        graph.replay()
+        torch.cuda.synchronize()
+        g.GPU_Transpose(d_out, d_res, p4.n1, p4.n2, logn, batch)
+        torch.cuda.synchronize()
+        return g.to_host(d_res)
+
+    # what the generic kernels make of the corrupted table
+    pos = 5 * p4.n2 + 77
+    good_word = int(w[pos])
+    w[pos] = (good_word + 1) % p4.modulus.value if (good_word + 1) % p4.modulus.value < 2**63 else 1
+    g.set_option("path", "generic")
+    try:
+        d_gen = torch.zeros_like(d_nat)
+        g.GPU_4STEP_NTT(d_in, d_gen, t1, t2, w, p4.modulus, g.ntt4step_configuration(n_power=logn), batch)
+        g.GPU_Transpose(d_gen, d_res, p4.n1, p4.n2, logn, batch)
+        torch.cuda.synchronize()
+        want_bad = g.to_host(d_res).copy()
+    finally:
+        g.set_option("path", os.environ.get("GPUNTT_PATH", "default"))
+    w[pos] = good_word
+    torch.cuda.synchronize()
+    other = g.NTTParameters4Step(14, 64)
+    ot = [g.to_device(t) for t in other.tables["fwd"]]
+    oin = g.to_device(P.splitmix(62014, 0, other.n, other.modulus.value))
+    oout = torch.zeros_like(oin)
+    for rep in range(2):
+        assert np.array_equal(result(), want), ("consistent tables", rep)
+        w[pos] = (good_word + 1) % p4.modulus.value if (good_word + 1) % p4.modulus.value < 2**63 else 1
+        torch.cuda.synchronize()
+        got = result()
+        assert np.array_equal(got, want_bad) and not np.array_equal(got, want), ("corrupted W", rep)
+        assert np.array_equal(result(), want_bad), ("corrupted W, second replay", rep)
+        w[pos] = good_word
+        with torch.cuda.stream(cfg_stream):  # eager calls on the capture stream: another chain, another veto word
+            g.GPU_4STEP_NTT(oin, oout, *ot, other.modulus, g.ntt4step_configuration(n_power=14, stream=cfg_stream), 1)
+        cfg_stream.synchronize()
+    assert np.array_equal(result(), want)
