@@ -47,11 +47,11 @@ namespace gpuntt
                     return 13;
                 if (n == 14 && big >= 14 && !inverse && polys >= 256)
                     return 14;
-                // 2^21 (2^22 forward): an 8-stage strided pass on 4096-coefficient tiles + the big
-                // contiguous tile = two sweeps instead of three
+                // 2^21 / 2^22: an 8-stage strided pass on 4096-coefficient tiles + the big contiguous tile = two sweeps
+                // instead of three (2^22 inverse since round 5: 0.631 against 0.640-0.647 ms per 2^26 coefficients)
                 if (n == 21 && big >= 13)
                     return 13;
-                if (n == 22 && big >= 14 && !inverse)
+                if (n == 22 && big >= 14)
                     return 14;
                 // (2^23 / 2^24 in two sweeps -- a strided pass of 9 / 10 stages + the 14-stage contiguous pass on
                 // 16384-coefficient tiles -- was built and measured in round 5: bit-exact, -0.8 % at 2^24 x 64, +3 % at

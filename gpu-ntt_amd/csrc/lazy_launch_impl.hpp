@@ -48,8 +48,9 @@ namespace gpuntt
                         if (!in_first && last)
                             GPUNTT_ONE(true, TLOG, LIM, true);
                     }
-                    else if constexpr (TLOG == 13)
+                    else
                     {
+                        // inverse: the contiguous first pass of the two-sweep plans (2^21 on the 8192 tile, 2^22 on the 16384 one)
                         if (in_first && !last)
                             GPUNTT_ONE(true, TLOG, 1, false);
                     }
