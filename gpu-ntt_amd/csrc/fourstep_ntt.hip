@@ -388,7 +388,7 @@ namespace gpuntt
             {
                 int k_a = 0, k_b = 0;
                 const int tli = (plan.mode == PLAN_EXECUTE && plan.inv_tile != 0) ? plan.inv_tile
-                                                                                  : host::fourstep_inv_tile<T>(n_power, lim);
+                                                                                  : host::fourstep_inv_tile<T>(n_power, lim, log_n1);
                 if (host::fourstep_inv_merge_split(n_power, log_n1, k_a, k_b, tli))
                 {
                     if (do_prep)
@@ -430,7 +430,7 @@ namespace gpuntt
                     if constexpr (sizeof(T) == 4)
                     {
                         if (wide32)
-                            host::launch_fourstep_inv_first_lazy<T, 8>(log_n1, f, stream);
+                            host::launch_fourstep_inv_first_lazy<T, 8>(log_n1, f, stream, tli);
                         else
                             host::launch_fourstep_inv_first_lazy<T, 0>(log_n1, f, stream, tli);
                     }
@@ -476,6 +476,9 @@ namespace gpuntt
                     }
                     const host::Pass pa{false, k_a, tli - log_n1};
                     const host::Pass pb{false, k_b, tli - log_n1 + k_a};
+                    // 32-bit rings behind a 16384-coefficient first tile: the strided pass on that tile as well, like the
+                    // ring's Merge plan (2^22: 100 against 139 us per 2^26 coefficients)
+                    const int stl = (sizeof(T) == 4 && tli == 14) ? 14 : 12;
                     for (int i = 1; i < passes; i++)
                     {
                         kern::LazyArgsT<T> x = r;
@@ -488,9 +491,9 @@ namespace gpuntt
                         if constexpr (sizeof(T) == 4)
                         {
                             if (wide32)
-                                host::launch_pass_lazy_u32w<true>(p, 12, false, last, x, stream);
+                                host::launch_pass_lazy_u32w<true>(p, stl, false, last, x, stream);
                             else
-                                host::launch_pass_lazy<T, true>(p, 12, false, last, x, stream);
+                                host::launch_pass_lazy<T, true>(p, stl, false, last, x, stream);
                         }
                         else
                         {
@@ -962,7 +965,7 @@ namespace gpuntt
             p->use.small_tl =
                 host::fourstep_small_tile<T>(p->n, p->inverse, static_cast<unsigned long long>(batch_hint), natural_order);
             if (p->inverse && !natural_order)
-                p->use.inv_tile = host::fourstep_inv_tile<T>(p->n, host::modulus_lim<T>(modulus));
+                p->use.inv_tile = host::fourstep_inv_tile<T>(p->n, host::modulus_lim<T>(modulus), l1);
             // the plan's own veto word: the head of the (unused) n1 region of its workspace.  The preparation kernel checks
             // the caller's three tables once, here (option check_4step_tables); tables that are not those of one root make
             // the plan a generic one -- execute() then runs the element-by-element kernels, like the drop-in call would

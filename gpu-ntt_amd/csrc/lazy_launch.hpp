@@ -200,15 +200,16 @@ namespace gpuntt
         // Stage split of the strided row passes behind it: s = n - 12 stages on the bits above the first pass, as one pass
         // (s <= 8) or two; the first of them starts at row bit 12 - log_n1 and keeps 2^(12 - k) contiguous words per tile
         // row, so k >= log_n1.  false: the shape has no such plan (2^15, 2^16: fewer stages left than log_n1)
-        // tl: tile of the first pass (12; 13 for the 64-bit ring 2^21, fourstep_inv_tile)
+        // tl: tile of the first pass (fourstep_inv_tile: 12, or the big tile of the ring's inverse Merge plan)
         inline bool fourstep_inv_merge_split(int n_power, int log_n1, int& k_a, int& k_b, int tl = 12)
         {
-            if (tl == 13)
+            if (tl >= 13)
             {
-                // one strided pass of 8 at row bit 13 - log_n1 keeps 2^4 contiguous words: 13 - log_n1 >= 4
-                k_a = n_power - 13;
+                // the big tile does tl stages, ONE strided pass does the rest (two sweeps, like the ring's Merge plan);
+                // that pass starts at row bit tl - log_n1 and wants runs of at least 2^4 contiguous words there
+                k_a = n_power - tl;
                 k_b = 0;
-                return n_power == 21 && log_n1 <= 9 && k_a == 8;
+                return k_a >= 1 && k_a <= 8 && tl - log_n1 >= 4 && log_n1 >= 4 && log_n1 <= 9;
             }
             const int s = n_power - 12;
             const int l2 = n_power - log_n1, skip = 12 - log_n1;
@@ -231,11 +232,14 @@ namespace gpuntt
             k_b = s - k_a;
             return k_b >= 1 && k_a <= 8;
         }
-        // tile of the inverse 4-step's first pass: the 64-bit ring 2^21 takes the 8192-coefficient tile (two sweeps, like
-        // its Merge plan: lazy_tile_log), everything else 4096
-        template <typename T> inline int fourstep_inv_tile(int n_power, int lim)
+        // tile of the inverse 4-step's first pass = the tile of the ring's inverse Merge plan where that plan takes a
+        // big one and the transposing kernel exists for the reference's n1 of the ring (64-bit 2^21: 8192, 2^22: 16384;
+        // 32-bit 2^20 .. 2^22: 16384 -- two sweeps instead of three); everything else, and the 61- / 62-bit families, 4096
+        template <typename T> inline int fourstep_inv_tile(int n_power, int lim, int log_n1)
         {
-            return (sizeof(T) == 8 && n_power == 21 && lim == 0 && lazy_u64_big_tiles() >= 13) ? 13 : 12;
+            if (sizeof(T) == 8)
+                return lim != 0 ? 12 : (n_power == 21 && log_n1 == 6) ? 13 : (n_power == 22 && log_n1 == 7) ? 14 : 12;
+            return (n_power >= 20 && n_power <= 22 && log_n1 == n_power - 15) ? 14 : 12;
         }
         // natural-order 4-step (extension) in Merge form: strided Merge passes + one transposing row pass
         template <typename T, int LIMSEL = 0>

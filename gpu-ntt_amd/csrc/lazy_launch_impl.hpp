@@ -270,14 +270,27 @@ namespace gpuntt
             if (tiles > 0x7fffffffull)
                 throw std::invalid_argument("batch_size * N too large for one launch");
             const unsigned grid = lazy_grid_cap<T, LIMSEL>(tiles, a.go_flag);
+            // big first tiles (fourstep_inv_tile): the shapes the reference's launch table gives those rings
+#define GPUNTT_BIG(TLG, KK)                                                                                               \
+    if (tile_log == TLG && log_n1 == KK)                                                                                   \
+    {                                                                                                                      \
+        hipLaunchKernelGGL((kern::fourstep_inv_first_lazy<T, KK, LIMSEL, TLG>), dim3(grid), dim3(kern::LTile<TLG>::NT), 0,  \
+                           stream, a);                                                                                     \
+        GPUNTT_HIP_CHECK(hipGetLastError());                                                                               \
+        return;                                                                                                            \
+    }
             if constexpr (sizeof(T) == 8 && LIMSEL == 0)
-                if (tile_log == 13 && log_n1 == 6)
-                {
-                    hipLaunchKernelGGL((kern::fourstep_inv_first_lazy<T, 6, 0, 13>), dim3(grid), dim3(kern::LTile<13>::NT), 0,
-                                       stream, a);
-                    GPUNTT_HIP_CHECK(hipGetLastError());
-                    return;
-                }
+            {
+                GPUNTT_BIG(13, 6) // 2^21 = 64 x 32768
+                GPUNTT_BIG(14, 7) // 2^22 = 128 x 32768
+            }
+            if constexpr (sizeof(T) == 4)
+            {
+                GPUNTT_BIG(14, 5) // 2^20 = 32 x 32768
+                GPUNTT_BIG(14, 6) // 2^21
+                GPUNTT_BIG(14, 7) // 2^22
+            }
+#undef GPUNTT_BIG
             if (tile_log != 12)
                 throw std::invalid_argument("internal: bad 4-step tile");
             switch (log_n1)
