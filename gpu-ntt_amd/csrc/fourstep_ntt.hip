@@ -383,7 +383,8 @@ namespace gpuntt
             // transposed), then every remaining stage inside the n2-long rows of `out` -- strided inverse passes of an
             // n2-point ring reading a prefix of the same table (2^15 / 2^16, n2 = 512: one partial contiguous pass, eight
             // rows per tile), n^-1 folded into its slot 1.  No W stream, no W product, 2^17 .. 2^20 in two sweeps instead
-            // of three.  (61- / 62-bit moduli keep the W form below.)
+            // of three -- and 2^21 / 2^22 (32-bit: 2^20 .. 2^22) as well, on the big first tile of the ring's Merge plan
+            // (host::fourstep_inv_tile).
             if constexpr (INV)
             {
                 int k_a = 0, k_b = 0;

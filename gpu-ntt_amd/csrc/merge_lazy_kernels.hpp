@@ -1415,8 +1415,9 @@ namespace gpuntt
         // of a, i.e. inside the n2-long rows of `out`: ordinary strided inverse passes of an n2-point ring (host side:
         // fourstep_run_lazy), whose twiddle slots are a prefix of the ring's own table.  No W stream, no W product.
         // a.n = log2 N, a.n2_log = log2 n2, a.poly_shift = log2 N; blocks in merge_pass_lazy's order.
-        // TLOG = 13 (64-bit ring 2^21): the 8192-coefficient tile does 13 stages, which leaves one strided pass of 8 --
-        // two sweeps, like the Merge plan of that ring
+        // TLOG = 13 / 14 (host::fourstep_inv_tile: 64-bit rings 2^21 / 2^22, 32-bit rings 2^20 .. 2^22): the big tile of the
+        // ring's inverse Merge plan does 13 / 14 stages, which leaves ONE strided pass of at most 8 -- two sweeps, like
+        // the Merge plan of that ring
         template <typename T, int L1, int LIM = 0, int TLOG = 12>
         __global__ __launch_bounds__(LTile<TLOG>::NT, (LOcc<TLOG, T>::WAVES)) void fourstep_inv_first_lazy(LazyArgsT<T> a)
         {

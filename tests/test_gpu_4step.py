@@ -441,7 +441,7 @@ def test_one_launch_rings_every_polynomial_repeatedly(g, bits, logn, batch):
 
 
 @pytest.mark.parametrize("bits,logn,batch", [(64, 13, 5), (64, 14, 7), (64, 15, 40), (32, 16, 24), (64, 16, 9), (64, 17, 12),
-                                             (32, 20, 5), (64, 21, 3), (32, 22, 2)])
+                                             (32, 20, 5), (64, 21, 3), (32, 22, 2), (32, 21, 3), (64, 22, 3)])
 def test_inverse_in_merge_form_every_polynomial_repeatedly(g, bits, logn, batch):
     """The inverse 4-step above one tile is the ring's inverse Merge plan with the transposition on its FIRST pass
     (kern::fourstep_inv_first_lazy) and the remaining stages inside the n2-long rows: one partial contiguous pass for
@@ -473,6 +473,53 @@ def test_inverse_in_merge_form_every_polynomial_repeatedly(g, bits, logn, batch)
         plan.close()
     finally:
         g.set_option("path", "default")
+
+
+def test_fourstep_u32_30_bit_modulus_on_the_big_tiles(g):
+    """32-bit rings 2^20 .. 2^22 with a 30-bit prime: the pool primes of those rings lie below 2^29 and take the
+    LIMIT = 8 family, so the default 32-bit family on the 16384-coefficient tiles (forward Merge plan behind the
+    transposed gather; inverse: transposing first pass on the big tile + one strided pass, host::fourstep_inv_tile) is
+    reached with a prime of our own.  Tables generated on the device; expected values from the Merge oracle through
+    GPU_4STEP_NTT(transpose(x)) == MergeNTT(x) and transpose(GPU_4STEP_NTT(y, INVERSE)) == x."""
+    import torch
+    from gpu_utils import find_ntt_factors
+    P = O.Port(32)
+    g.set_option("path", "fast-strict")
+    try:
+        for logn, batch in ((20, 3), (21, 2), (22, 3)):
+            q, omega, psi = find_ntt_factors(30, logn)
+            m = g.Modulus(q, bits=32)
+            assert m.bit == 30
+            shape = g.NTTParameters4Step(logn, 32)
+            n, n1, n2 = shape.n, shape.n1, shape.n2
+            oprm = P.merge_params(logn, O.X_N_minus, (q, omega, psi))
+            x = P.splitmix(5100 + logn, 0, batch * n, q)
+            y = np.concatenate([P.merge_ntt(x[p * n:(p + 1) * n], oprm) for p in range(batch)])
+            for inverse in (False, True):
+                r = pow(omega, -1, q) if inverse else omega
+                kind = g.INVERSE if inverse else g.FORWARD
+                w = torch.zeros(n, dtype=torch.int32, device="cuda")
+                t1 = torch.zeros(n1 >> 1, dtype=torch.int32, device="cuda")
+                t2 = torch.zeros(n2 >> 1, dtype=torch.int32, device="cuda")
+                g.GPU_Generate4StepW(w, r, m, logn, kind)
+                g.GPU_GeneratePowerTable(t1, pow(r, n // n1, q), m, int(np.log2(n1)) - 1, True)
+                g.GPU_GeneratePowerTable(t2, pow(r, n // n2, q), m, int(np.log2(n2)) - 1, True)
+                cfg = g.ntt4step_configuration(n_power=logn, ntt_type=kind, mod_inverse=pow(n, -1, q) if inverse else 0)
+                src = x.reshape(batch, n1, n2).transpose(0, 2, 1).reshape(-1).copy() if not inverse else y
+                d_in = g.to_device(src)
+                d_out = torch.zeros_like(d_in)
+                for it in range(2):
+                    d_out.zero_()
+                    g.GPU_4STEP_NTT(d_in, d_out, t1, t2, w, m, cfg, batch)
+                    torch.cuda.synchronize()
+                    got = g.to_host(d_out)
+                    if not inverse:
+                        assert np.array_equal(got, y), ("forward", logn, it)
+                    else:
+                        back = got.reshape(batch, n1, n2).transpose(0, 2, 1).reshape(-1)
+                        assert np.array_equal(back, x), ("inverse", logn, it)
+    finally:
+        g.set_option("path", os.environ.get("GPUNTT_PATH", "default"))
 
 
 def test_fourstep_seeded_random_shapes_both_directions(g):
