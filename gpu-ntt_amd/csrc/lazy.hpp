@@ -245,29 +245,60 @@ namespace gpuntt
         {
         };
 
+        // 64-bit register pair whose low word is `lo` and whose high word is anything at all (no instruction): the
+        // accumulator a 32-bit multiply-add chain starts from
+        __device__ __forceinline__ uint64_t pair_lo(uint32_t lo)
+        {
+            const uint32_t hi = __builtin_nondeterministic_value(lo);
+            return (static_cast<uint64_t>(hi) << 32) | lo;
+        }
+
         // ---- 32-bit: exact-quotient Shoup product in [0, 2q); q < 2^30 => LIMIT 4, q < 2^29 => LIMIT 8 --------
-        template <int LIM> struct Mod32
+        // The product is ONE v_mul_hi_u32 (quotient) and TWO v_mad_u64_u32 chained through a 64-bit accumulator whose
+        // high word is dead -- x * w, then + qh * (2^32 - q) -- and the chain starts from the butterfly's own U
+        // (mul_acc), so U + T costs three instructions where mul_hi / mul_lo / mul_lo / sub / add costs five:
+        // v_mad_u64_u32 issues at the full rate on gfx950 (tools/ubench_bfly32: forward butterfly 30.8 -> 22.6 SIMD
+        // cycles, inverse 31.9 -> 28.0; profiles/ubench_bfly32_r05.txt).  VQ: per-lane moduli (q in a vector register).
+        template <int LIM, bool VQ = false> struct Mod32
         {
             static constexpr int TB = 2;
             static constexpr int LIMIT = LIM;
             static constexpr int MAX_BIT = (LIM == 8) ? 29 : 30;
             uint32_t q;
+            uint32_t qneg; // 2^32 - q
 
-            __device__ __forceinline__ void set(uint32_t modulus, const NormConst&) { q = modulus; }
+            __device__ __forceinline__ void set(uint32_t modulus, const NormConst&)
+            {
+                q = modulus;
+                qneg = 0u - modulus;
+            }
             __device__ __forceinline__ uint32_t reduce_2q(uint32_t x) const { return csub<2>(x); }
             __device__ __forceinline__ uint32_t kq(int k) const { return q * static_cast<uint32_t>(k); }
             __device__ __forceinline__ bool hi_norm() const { return false; }
 
+            // UNI: the twiddle is wave-uniform (scalar registers)
             template <bool UNI = false> __device__ __forceinline__ uint32_t mul(uint32_t x, const Tw32& t) const
             {
                 const uint32_t qh = __umulhi(x, t.wp);
-                return x * t.w - qh * q;
+                return lo32(mad32<!VQ>(qh, qneg, mad32z<UNI>(x, t.w)));
             }
             // acc + T, T = x * w (mod q) + {0, 1} q
             template <bool UNI, bool ZERO = false>
             __device__ __forceinline__ uint32_t mul_acc(uint32_t x, const Tw32& t, uint32_t acc) const
             {
-                return acc + mul<UNI>(x, t);
+                const uint32_t qh = __umulhi(x, t.wp);
+                const uint64_t a = ZERO ? mad32z<UNI>(x, t.w) : mad32<UNI>(x, t.w, pair_lo(acc));
+                return lo32(mad32<!VQ>(qh, qneg, a));
+            }
+            // 2 x + k (k wave-uniform unless VQ): one v_lshl_add_u32
+            __device__ __forceinline__ uint32_t shl1_add(uint32_t x, uint32_t k) const
+            {
+                uint32_t d;
+                if constexpr (VQ)
+                    asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(d) : "v"(x), "v"(k));
+                else
+                    asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(d) : "v"(x), "s"(k));
+                return d;
             }
 
             // x < 2*k*q:  min(x, x - k*q) as unsigned (the difference wraps above x when x < k*q)
@@ -280,7 +311,7 @@ namespace gpuntt
         template <> struct Mod<uint32_t, 0, false> : Mod32<4>
         {
         };
-        template <> struct Mod<uint32_t, 0, true> : Mod32<4> // plain C arithmetic: the same code serves per-lane moduli
+        template <> struct Mod<uint32_t, 0, true> : Mod32<4, true> // per-lane moduli
         {
         };
         // moduli below 2^29 (the reference's 32-bit pools: 469762049, ...): twice the headroom, a range correction

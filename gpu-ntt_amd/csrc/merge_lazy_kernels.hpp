@@ -856,20 +856,12 @@ namespace gpuntt
                                 unit = (tw.w == 1);
                             // U' = U + T comes out of the product's own multiply-add chain;
                             // V' = U - T + TB q = 2 U + TB q - U'  (mod 2^W; the true value is below LIMIT q)
-                            // (32-bit words: the separate product is one instruction shorter)
-                            if constexpr (sizeof(T) == 8)
                             {
                                 const T nu = unit ? static_cast<T>(U + v[j1]) : m.template mul_acc<UNI_TW>(v[j1], tw, U);
                                 v[j0] = nu;
-                                // 2 U + TB q as ONE v_lshl_add_u64, then one 64-bit subtract: kept opaque so that
+                                // 2 U + TB q as ONE v_lshl_add_u64 / _u32, then one subtract: kept opaque so that
                                 // the sum is not re-associated into shift, subtract, add (a fourth instruction)
                                 v[j1] = static_cast<T>(m.shl1_add(U, m.kq(M::TB)) - nu);
-                            }
-                            else
-                            {
-                                const T Tm = unit ? v[j1] : m.template mul<UNI_TW>(v[j1], tw);
-                                v[j0] = U + Tm;
-                                v[j1] = U + m.kq(M::TB) - Tm;
                             }
                         }
                         else
