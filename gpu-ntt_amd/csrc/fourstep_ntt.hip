@@ -286,7 +286,7 @@ namespace gpuntt
                 if (INV && mods_dev != nullptr)
                     s.ninv_arr = ws_ninv;
                 s.go_flag = go_flag;
-                s.norm = lazy::make_norm_const(static_cast<uint64_t>(mod.value), static_cast<uint64_t>(mod.bit));
+                s.norm = lazy::norm_const_of(mod.value, mod.bit);
                 s.norm_arr = norm_arr;
                 s.total = static_cast<unsigned long long>(batch_size) << n_power;
                 s.n = n_power;
@@ -337,7 +337,7 @@ namespace gpuntt
                     f.q_mu = mod.mu;
                     f.ninv = TW{0, 0};
                     f.go_flag = go_flag;
-                    f.norm = lazy::make_norm_const(static_cast<uint64_t>(mod.value), static_cast<uint64_t>(mod.bit));
+                    f.norm = lazy::norm_const_of(mod.value, mod.bit);
                     f.norm_arr = norm_arr;
                     f.n2_log = log_n1; // row stride of the transposed side
                     f.total = static_cast<unsigned long long>(batch_size) << n_power;
@@ -413,7 +413,7 @@ namespace gpuntt
                     f.q_mu = mod.mu;
                     f.ninv = TW{0, 0};
                     f.go_flag = go_flag;
-                    f.norm = lazy::make_norm_const(static_cast<uint64_t>(mod.value), static_cast<uint64_t>(mod.bit));
+                    f.norm = lazy::norm_const_of(mod.value, mod.bit);
                     f.norm_arr = norm_arr;
                     f.n2_log = log_n2; // row stride of the transposed side
                     f.total = static_cast<unsigned long long>(batch_size) << n_power;
@@ -536,7 +536,7 @@ namespace gpuntt
             a.ninv_arr = nullptr;
             a.ninv = lazy::Tw<T>{0, 0};
             a.go_flag = nullptr;
-            a.norm = lazy::make_norm_const(static_cast<uint64_t>(mod.value), static_cast<uint64_t>(mod.bit));
+            a.norm = lazy::norm_const_of(mod.value, mod.bit);
             a.norm_arr = nullptr;
             a.n2_log = log_n1;  // row stride of the column-major (n2 x n1) side
             a.row_log = log_n2; // row stride of the row-major (n1 x n2) side

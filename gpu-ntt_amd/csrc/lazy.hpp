@@ -77,6 +77,16 @@ namespace gpuntt
             return n;
         }
 
+        // 32-bit words: x < 2^32 -> [0, 2q) with k = hi32(x * M), M = floor(2^32 / q) (k is floor(x / q) or one less), the
+        // same record with sh = c = 0; 64-bit words: make_norm_const
+        template <typename T> __host__ __device__ inline NormConst norm_const_of(T q, T bit)
+        {
+            if constexpr (sizeof(T) == 4)
+                return NormConst{0u, 0u, q >= 3u ? static_cast<uint32_t>(0x100000000ull / q) : 0u, 0u};
+            else
+                return make_norm_const(static_cast<uint64_t>(q), static_cast<uint64_t>(bit));
+        }
+
         // d = a * b + c (32 x 32 + 64 -> 64) pinned to ONE v_mad_u64_u32.  SB: b is wave-uniform and is
         // read straight from a scalar register (a VOP3 instruction may name one).  The carry-out lands
         // in a dead scalar pair.  Written as asm because the compiler narrows a 64-bit product whose
@@ -266,13 +276,19 @@ namespace gpuntt
             static constexpr int MAX_BIT = (LIM == 8) ? 29 : 30;
             uint32_t q;
             uint32_t qneg; // 2^32 - q
+            uint32_t M;    // floor(2^32 / q) (norm_const_of)
 
-            __device__ __forceinline__ void set(uint32_t modulus, const NormConst&)
+            __device__ __forceinline__ void set(uint32_t modulus, const NormConst& n)
             {
                 q = modulus;
                 qneg = 0u - modulus;
+                M = n.M;
             }
-            __device__ __forceinline__ uint32_t reduce_2q(uint32_t x) const { return csub<2>(x); }
+            // any x < 2^32 -> [0, 2q): v_mul_hi_u32 + v_mad_u64_u32
+            template <bool HI = false> __device__ __forceinline__ uint32_t reduce_2q(uint32_t x) const
+            {
+                return lo32(mad32<!VQ>(__umulhi(x, M), qneg, pair_lo(x)));
+            }
             __device__ __forceinline__ uint32_t kq(int k) const { return q * static_cast<uint32_t>(k); }
             __device__ __forceinline__ bool hi_norm() const { return false; }
 
@@ -326,6 +342,8 @@ namespace gpuntt
         {
             if constexpr (sizeof(T) == 8 && B > 4)
                 return m.template csub<1>(m.template reduce_2q<HI>(x)); // 9-10 instructions instead of 4 x 4
+            if constexpr (sizeof(T) == 4 && B > 4)
+                return m.template csub<1>(m.template reduce_2q<HI>(x)); // 4 instructions instead of 3 x 2
             if constexpr (B > 8)
                 x = m.template csub<8>(x);
             if constexpr (B > 4)

@@ -206,7 +206,7 @@ namespace gpuntt
             a.mod_order = mod_order;
             a.poly_order = poly_order;
             a.mul_in = mul_in;
-            a.norm = lazy::make_norm_const(static_cast<uint64_t>(m.value), static_cast<uint64_t>(m.bit));
+            a.norm = lazy::norm_const_of(m.value, m.bit);
             a.norm_arr = norm_arr;
             a.total = static_cast<unsigned long long>(batch_size) << n_power;
             a.n = n_power;
@@ -314,7 +314,7 @@ namespace gpuntt
             a.ninv = TW{0, 0};
             if (INV)
                 a.ninv = TW{ninv, host::shoup_host(ninv, modulus.value)};
-            a.norm = lazy::make_norm_const(static_cast<uint64_t>(modulus.value), static_cast<uint64_t>(modulus.bit));
+            a.norm = lazy::norm_const_of(modulus.value, modulus.bit);
             a.total = 1ull << nv;
             a.n = nv;
             a.poly_shift = nv;
@@ -1140,7 +1140,7 @@ namespace gpuntt
                 a.q = m0.value;
                 a.q_bit = m0.bit;
                 a.q_mu = m0.mu;
-                a.norm = lazy::make_norm_const(static_cast<uint64_t>(m0.value), static_cast<uint64_t>(m0.bit));
+                a.norm = lazy::norm_const_of(m0.value, m0.bit);
                 if (p.inverse)
                     a.ninv = lazy::Tw<T>{p.ninv[0], host::shoup_host(p.ninv[0], m0.value)};
             }

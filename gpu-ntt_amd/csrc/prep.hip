@@ -278,7 +278,7 @@ namespace gpuntt
                             over31 = true;
                         // normalisation constants of modulus i (one 64-bit division each): one LANE per modulus
                         if (blockIdx.x == 0 && norm_arr != nullptr && go_flag != nullptr)
-                            norm_arr[i] = lazy::make_norm_const(md.value, md.bit);
+                            norm_arr[i] = lazy::norm_const_of(md.value, md.bit);
                     }
                     const bool any_bad = __ballot(bad) != 0ull, any62 = __ballot(w62) != 0ull, any61 = __ballot(w61) != 0ull,
                                any_over31 = __ballot(over31) != 0ull;
@@ -572,7 +572,7 @@ namespace gpuntt
                     if (host_state != nullptr)
                         *host_state = state;
                     if (norm_arr != nullptr)
-                        norm_arr[0] = lazy::make_norm_const(md.value, md.bit);
+                        norm_arr[0] = lazy::norm_const_of(md.value, md.bit);
                 }
             }
             if (gid == 0 && veto != nullptr)
