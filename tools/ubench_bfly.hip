@@ -27,6 +27,76 @@ __device__ __forceinline__ uint64_t mul_r1(const Mod<uint64_t>& m, uint64_t x, c
     return x * t.w + qh * m.qneg;
 }
 
+// ---- two independent products, their multiply-add chains interleaved statement by statement and pinned (asm volatile);
+// chain A sends its carry-outs to vcc, chain B to a scalar pair, so neighbouring statements share no register and the
+// compiler has no reason to put an s_nop between them (round 5, profiles/ubench_bfly32_r05.txt, last note)
+template <bool SB> __device__ __forceinline__ uint64_t vmad32(uint32_t a, uint32_t b, uint64_t c)
+{
+    uint64_t d, cy;
+    if constexpr (SB)
+        asm volatile("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(cy) : "v"(a), "s"(b), "v"(c));
+    else
+        asm volatile("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(cy) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+template <bool SB> __device__ __forceinline__ uint64_t vmad32z(uint32_t a, uint32_t b)
+{
+    uint64_t d, cy;
+    if constexpr (SB)
+        asm volatile("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(d), "=s"(cy) : "v"(a), "s"(b));
+    else
+        asm volatile("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(d), "=s"(cy) : "v"(a), "v"(b));
+    return d;
+}
+template <bool SB> __device__ __forceinline__ uint64_t cmad32(uint32_t a, uint32_t b, uint64_t c)
+{
+    uint64_t d;
+    if constexpr (SB)
+        asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b), "v"(c) : "vcc");
+    else
+        asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c) : "vcc");
+    return d;
+}
+template <bool SB> __device__ __forceinline__ uint64_t cmad32z(uint32_t a, uint32_t b)
+{
+    uint64_t d;
+    if constexpr (SB)
+        asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(d) : "v"(a), "s"(b) : "vcc");
+    else
+        asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b) : "vcc");
+    return d;
+}
+template <bool UNI>
+__device__ __forceinline__ void mul_acc2(const Mod<uint64_t>& m, uint64_t xa, const Tw64& ta, uint64_t acca, uint64_t xb,
+                                         const Tw64& tb, uint64_t accb, uint64_t& ra, uint64_t& rb)
+{
+    const uint32_t xa0 = lo32(xa), xa1 = hi32(xa), xb0 = lo32(xb), xb1 = hi32(xb);
+    const uint32_t ha2 = __umulhi(xa0, hi32(ta.wp)), hb2 = __umulhi(xb0, hi32(tb.wp));
+    const uint32_t ha1 = __umulhi(xa1, lo32(ta.wp)), hb1 = __umulhi(xb1, lo32(tb.wp));
+    uint64_t qa = cmad32<false>(xa1, hi32(ta.wp), static_cast<uint64_t>(ha1));
+    uint64_t qb = vmad32<false>(xb1, hi32(tb.wp), static_cast<uint64_t>(hb1));
+    asm volatile("v_mad_u64_u32 %0, vcc, %1, 1, %2" : "=v"(qa) : "v"(ha2), "v"(qa) : "vcc");
+    uint64_t cy;
+    asm volatile("v_mad_u64_u32 %0, %1, %2, 1, %3" : "=v"(qb), "=s"(cy) : "v"(hb2), "v"(qb));
+    uint64_t ca = cmad32z<UNI>(xa0, hi32(ta.w));
+    uint64_t cb = vmad32z<UNI>(xb0, hi32(tb.w));
+    ca = cmad32<UNI>(xa1, lo32(ta.w), ca);
+    cb = vmad32<UNI>(xb1, lo32(tb.w), cb);
+    ca = cmad32<true>(lo32(qa), hi32(m.qneg), ca);
+    cb = vmad32<true>(lo32(qb), hi32(m.qneg), cb);
+    ca = cmad32<true>(hi32(qa), lo32(m.qneg), ca);
+    cb = vmad32<true>(hi32(qb), lo32(m.qneg), cb);
+    uint64_t a = cmad32<UNI>(xa0, lo32(ta.w), acca);
+    uint64_t b = vmad32<UNI>(xb0, lo32(tb.w), accb);
+    uint32_t ah, bh;
+    asm volatile("v_add_u32 %0, %1, %2" : "=v"(ah) : "v"(hi32(a)), "v"(lo32(ca)));
+    asm volatile("v_add_u32 %0, %1, %2" : "=v"(bh) : "v"(hi32(b)), "v"(lo32(cb)));
+    a = (static_cast<uint64_t>(ah) << 32) | lo32(a);
+    b = (static_cast<uint64_t>(bh) << 32) | lo32(b);
+    ra = cmad32<true>(lo32(qa), lo32(m.qneg), a);
+    rb = vmad32<true>(lo32(qb), lo32(m.qneg), b);
+}
+
 template <int VARIANT, bool UNI, bool CSUB>
 __global__ __launch_bounds__(256, 4) void bfly_rounds(uint64_t* out, const Tw64* tw, uint64_t q, int iters)
 {
@@ -48,6 +118,30 @@ __global__ __launch_bounds__(256, 4) void bfly_rounds(uint64_t* out, const Tw64*
         for (int s = 0; s < 4; s++)
         {
             const int jb = 3 - s;
+            if (VARIANT == 2)
+            {
+#pragma unroll
+                for (int h = 0; h < 8; h += 2)
+                {
+                    const int ja0 = (h & ((1 << jb) - 1)) | ((h >> jb) << (jb + 1)), ja1 = ja0 | (1 << jb);
+                    const int hb = h + 1;
+                    const int jb0 = (hb & ((1 << jb) - 1)) | ((hb >> jb) << (jb + 1)), jb1 = jb0 | (1 << jb);
+                    const Tw64 wa = t[(off + (ja0 >> (jb + 1))) & 7], wb = t[(off + (jb0 >> (jb + 1))) & 7];
+                    uint64_t Ua = v[ja0], Ub = v[jb0];
+                    if (CSUB && (s & 1))
+                    {
+                        Ua = m.csub<8>(Ua);
+                        Ub = m.csub<8>(Ub);
+                    }
+                    uint64_t na, nb;
+                    mul_acc2<UNI>(m, v[ja1], wa, Ua, v[jb1], wb, Ub, na, nb);
+                    v[ja0] = na;
+                    v[jb0] = nb;
+                    v[ja1] = (Ua << 1) + m.kq(4) - na;
+                    v[jb1] = (Ub << 1) + m.kq(4) - nb;
+                }
+            }
+            else
 #pragma unroll
             for (int h = 0; h < 8; h++)
             {
@@ -139,6 +233,7 @@ int main(int argc, char** argv)
     {
         run<0, false, true>("r1 mul, lane twiddles, csub/2", d_out, d_tw, q, occ);
         run<1, false, true>("mad chain, lane twiddles, csub/2", d_out, d_tw, q, occ);
+        run<2, false, true>("two chains interleaved + pinned, lane tw", d_out, d_tw, q, occ);
         run<0, true, true>("r1 mul, scalar twiddles, csub/2", d_out, d_tw, q, occ);
         run<1, true, true>("mad chain, scalar twiddles, csub/2", d_out, d_tw, q, occ);
         run<0, false, false>("r1 mul, lane twiddles, no csub", d_out, d_tw, q, occ);
