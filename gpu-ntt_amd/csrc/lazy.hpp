@@ -120,6 +120,7 @@ namespace gpuntt
             uint64_t qneg; // 2^64 - q
             NormConst nc;
             uint32_t zero; // 0, pinned to v127 where the quotient chain needs a zero high word (mul_acc_raw)
+            uint32_t one;  // 1, opaque to the optimiser (mul_acc_raw)
 
             __device__ __forceinline__ void set(uint64_t modulus, const NormConst& n)
             {
@@ -128,6 +129,7 @@ namespace gpuntt
                 nc = n;
                 // opaque to the optimiser: a constant 0 would be re-materialised (one v_mov per use)
                 asm("v_mov_b32 %0, 0" : "=v"(zero));
+                asm("v_mov_b32 %0, 1" : "=v"(one));
             }
             // x < 32 q  ->  [0, 2q): quotient estimate from the top bits, one 32 x 64 multiply-subtract.
             // HI: the modulus has >= 48 bits (nc.hi), the top bits are the high word as it stands
@@ -180,14 +182,22 @@ namespace gpuntt
                         : "=v"(qh), "=s"(carry)
                         : "v"(x1), "v"(lo32(t.wp)), "v"(hi32(t.wp)), "{v127}"(zero)
                         : "v126");
-                // + h2 as a multiply-add by 1: adding a 32-bit value to a 64-bit one otherwise
-                // costs a zero-extending move plus a 64-bit add
-                asm("v_mad_u64_u32 %0, %1, %2, 1, %3" : "=v"(qh), "=s"(carry) : "v"(h2), "v"(qh));
-                uint64_t c = mad32z<UNI>(x0, hi32(t.w));
-                c = mad32<UNI>(x1, lo32(t.w), c);
+                // The multiply-adds by the twiddle and by h2 are plain C++: the compiler selects v_mad_u64_u32 itself for
+                // zext(a) * zext(b) + c64 and -- unlike behind an inline-asm statement, where it assumes a forwarding hazard
+                // and puts an s_nop in front of every dependent instruction -- knows that nothing has to wait (register-
+                // only loop, whole chain in C++: 71.2 -> 67.8 SIMD cycles per butterfly at 4 waves per SIMD, 76.6 -> 71.1
+                // at 2, 108.9 -> 84.2 at 1; tools/ubench_bfly, round 5).  `one` is an opaque 1 (+ h2 as a multiply-add:
+                // adding a 32-bit value to a 64-bit one otherwise costs a zero-extending move plus a 64-bit add).
+                // The three multiply-adds by the words of -q stay asm (they also keep the cross-term accumulator whole: with
+                // only its low word live the compiler narrows the chain to v_mul_lo_u32 + v_add3_u32): the
+                // compiler's divergence analysis loses the modulus of some kernels to vector registers and then multiplies
+                // by a 64-bit word (two multiply-adds and two moves each).
+                qh = static_cast<uint64_t>(h2) * one + qh;
+                uint64_t c = static_cast<uint64_t>(x0) * hi32(t.w);
+                c = static_cast<uint64_t>(x1) * lo32(t.w) + c;
                 c = mad32<!VQ>(lo32(qh), hi32(qneg), c);
                 c = mad32<!VQ>(hi32(qh), lo32(qneg), c);
-                uint64_t a = ZERO ? mad32z<UNI>(x0, lo32(t.w)) : mad32<UNI>(x0, lo32(t.w), acc);
+                uint64_t a = ZERO ? static_cast<uint64_t>(x0) * lo32(t.w) : static_cast<uint64_t>(x0) * lo32(t.w) + acc;
                 // the cross sum goes into the accumulator's high word BEFORE the last multiply-add, so the result
                 // leaves the chain as one 64-bit register pair (with the add last, the compiler started the
                 // butterfly's 64-bit subtraction on the halves: a third instruction in a third of the butterflies)

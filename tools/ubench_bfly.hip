@@ -97,12 +97,49 @@ __device__ __forceinline__ void mul_acc2(const Mod<uint64_t>& m, uint64_t xa, co
     rb = vmad32<true>(lo32(qb), lo32(m.qneg), b);
 }
 
+__device__ __forceinline__ uint32_t keep32(uint32_t x)
+{
+    asm("" : "+v"(x));
+    return x;
+}
+// the chain in plain C++ -- the compiler selects v_mad_u64_u32 itself and knows there is no hazard behind it (no s_nop); an
+// empty asm that "uses" all 64 bits of the cross-term accumulator keeps it from narrowing that chain to v_mul_lo_u32 + v_add3_u32
+__device__ __forceinline__ uint64_t keep64(uint64_t x)
+{
+    asm("" : "+v"(x));
+    return x;
+}
+template <bool UNI> __device__ __forceinline__ uint64_t mul_acc_c(const Mod<uint64_t>& m, uint64_t x, const Tw64& t, uint64_t acc, uint32_t one)
+{
+    const uint32_t x0 = lo32(x), x1 = hi32(x);
+    const uint32_t h2 = __umulhi(x0, hi32(t.wp));
+    uint64_t qh, carry;
+    asm("v_mul_hi_u32 v126, %2, %3\n\tv_mad_u64_u32 %0, %1, %2, %4, v[126:127]"
+        : "=v"(qh), "=s"(carry)
+        : "v"(x1), "v"(lo32(t.wp)), "v"(hi32(t.wp)), "{v127}"(m.zero)
+        : "v126");
+    qh = static_cast<uint64_t>(h2) * one + qh;
+    uint64_t c = static_cast<uint64_t>(x0) * hi32(t.w);
+    c = static_cast<uint64_t>(x1) * lo32(t.w) + c;
+    c = static_cast<uint64_t>(lo32(qh)) * hi32(m.qneg) + c;
+    c = static_cast<uint64_t>(hi32(qh)) * lo32(m.qneg) + c;
+    c = keep64(c);
+    uint64_t a = static_cast<uint64_t>(x0) * lo32(t.w) + acc;
+    uint32_t ah;
+    asm("v_add_u32 %0, %1, %2" : "=v"(ah) : "v"(hi32(a)), "v"(lo32(c)));
+    a = (static_cast<uint64_t>(ah) << 32) | lo32(a);
+    a = static_cast<uint64_t>(lo32(qh)) * lo32(m.qneg) + a;
+    return a;
+}
+
 template <int VARIANT, bool UNI, bool CSUB>
 __global__ __launch_bounds__(256, 4) void bfly_rounds(uint64_t* out, const Tw64* tw, uint64_t q, int iters)
 {
     Mod<uint64_t> m;
     m.set(q, make_norm_const(q, 60));
     uint64_t v[16];
+    uint32_t one; // 1, opaque to the optimiser
+    asm("v_mov_b32 %0, 1" : "=v"(one));
 #pragma unroll
     for (int j = 0; j < 16; j++)
         v[j] = (threadIdx.x * 16 + j) * 0x9E3779B97F4A7C15ull % q;
@@ -151,7 +188,13 @@ __global__ __launch_bounds__(256, 4) void bfly_rounds(uint64_t* out, const Tw64*
                 uint64_t U = v[j0];
                 if (CSUB && (s & 1))
                     U = m.csub<8>(U);
-                if (VARIANT == 0)
+                if (VARIANT == 3)
+                {
+                    const uint64_t nu = mul_acc_c<UNI>(m, v[j1], w, U, one);
+                    v[j0] = nu;
+                    v[j1] = (U << 1) + m.kq(4) - nu;
+                }
+                else if (VARIANT == 0)
                 {
                     const uint64_t T = mul_r1(m, v[j1], w);
                     v[j0] = U + T;
@@ -234,6 +277,7 @@ int main(int argc, char** argv)
         run<0, false, true>("r1 mul, lane twiddles, csub/2", d_out, d_tw, q, occ);
         run<1, false, true>("mad chain, lane twiddles, csub/2", d_out, d_tw, q, occ);
         run<2, false, true>("two chains interleaved + pinned, lane tw", d_out, d_tw, q, occ);
+        run<3, false, true>("chain in C++ (compiler's own mads), lane tw", d_out, d_tw, q, occ);
         run<0, true, true>("r1 mul, scalar twiddles, csub/2", d_out, d_tw, q, occ);
         run<1, true, true>("mad chain, scalar twiddles, csub/2", d_out, d_tw, q, occ);
         run<0, false, false>("r1 mul, lane twiddles, no csub", d_out, d_tw, q, occ);
