@@ -147,7 +147,7 @@ namespace gpuntt
                                                    const kern::SlowArgs<uint32_t>*);
 
         // 4-step transform of a ring that fits one tile in one launch: 64-bit 2^12 (tile 12), 2^13 (tile 13), 2^14 forward
-        // (tile 14); 32-bit 2^12 (tile 12), 2^13 (tile 13), 2^14 (tile 14).  a.tw = Merge table of the ring
+        // calls of at least 256 transforms (tile 14); 32-bit 2^12 (tile 12), 2^13 (tile 13), 2^14 (tile 14).  a.tw = Merge table of the ring
         // (launch_prep_merge_from_fourstep).  fourstep_small_tile: the tile such a call runs on, 0 = ring too large
         template <typename T>
         inline int fourstep_small_tile(int n_power, bool inverse, unsigned long long polys, bool natural = false)
@@ -157,12 +157,9 @@ namespace gpuntt
             // its own, which no Merge plan uses
             if (sizeof(T) == 4 && n_power == 13)
                 return 13;
-            // 64-bit 2^14, inverse: the Merge plans keep two sweeps on 4096-coefficient tiles there (the one-tile inverse
-            // measured 9 % slower than that), but the 4-step alternative is the two-phase W form -- 0.504 ms per 2^26
-            // coefficients against 0.381 forward -- so the inverse 4-step takes the 16384-coefficient tile as well
-            // (reference layout only: the natural-order variant of that kernel spills at the tile's 128-VGPR budget)
-            if (sizeof(T) == 8 && n_power == 14 && inverse && !natural && lazy_u64_big_tiles() >= 14 && polys >= 256)
-                return 14;
+            // (64-bit 2^14, inverse: two sweeps like the ring's Merge plan -- transposing first pass + one partial row pass,
+            // fourstep_inv_merge_split -- 0.438-0.440 ms per 2^26 coefficients against 0.452 for the one-tile kernel
+            // rounds 3 and 4 ran there, which is gone)
             const int tl = lazy_tile_log<T>(n_power, inverse, polys);
             return (n_power >= 12 && n_power == tl) ? tl : 0;
         }

@@ -359,9 +359,9 @@ namespace gpuntt
                     GPUNTT_SMALL(12, 12);
                 else if (tile_log == 13 && n == 13)
                     GPUNTT_SMALL(13, 13);
-                else if (tile_log == 14 && n == 14 && !(INV && NAT))
+                else if (tile_log == 14 && n == 14 && !INV)
                 {
-                    if constexpr (!(INV && NAT))
+                    if constexpr (!INV) // (the inverse of that ring runs in two sweeps: fourstep_small_tile)
                         GPUNTT_SMALL(14, 14);
                 }
                 else
