@@ -183,3 +183,17 @@ def test_merge_stress_rns_stacks_every_polynomial_twice(g):
         torch.cuda.synchronize()
         assert np.array_equal(g.to_host(o2), want), ("plan forward", logn, batch, widths)
         plan.close()
+
+
+def test_u32_random_modulus_widths_every_polynomial():
+    """The in-suite slice of tools/stress_u32.py (round 5: the 32-bit butterflies became multiply-add chains and the final
+    normalisation one quotient estimate by floor(2^32 / q)): 20 s of seeded random 32-bit calls -- primes of 12 .. 30 bits
+    (both lazy families and moduli far below the word size), rings 2^4 .. 2^20, X^N+1 / X^N-1, both directions, single
+    modulus (drop-in, NTTPlan) and RNS stacks of 2 .. 4 primes -- EVERY polynomial against the oracle."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_u32.py"), "20261002", "20"], capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "u32 stress OK" in r.stdout, r.stdout[-2000:]
