@@ -332,6 +332,14 @@ namespace gpuntt
         // 0.177 against 0.211 ms per 2^26 coefficients; the others 1-4 %).  The 4-step plans keep lazy_contig_k.
         template <typename T> inline int lazy_contig_k_merge(int n, bool inverse)
         {
+#ifdef GPUNTT_EXP_CK // stage-split sweeps (experimental builds only): GPUNTT_CK = stages of the contiguous pass
+            if (const char* e = std::getenv("GPUNTT_CK"))
+            {
+                const int k = std::atoi(e);
+                if (k >= 8 && k <= 12 && n - k >= 1 && n - k <= 8)
+                    return k;
+            }
+#endif
             if (sizeof(T) == 4)
             {
                 if (!inverse && n >= 15 && n <= 17)
