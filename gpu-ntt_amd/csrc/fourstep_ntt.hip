@@ -207,9 +207,11 @@ namespace gpuntt
                                int batch_size, hipStream_t stream, const Modulus<T>* mods_dev = nullptr,
                                const T* ninv_dev = nullptr, const unsigned** go_flag_out = nullptr,
                                const PlanUse<T>& plan = PlanUse<T>(), int dev_family = 0, unsigned* host_state = nullptr,
-                               const host::FourStepVeto& veto = host::FourStepVeto())
+                               const host::FourStepVeto& veto = host::FourStepVeto(), bool* self_fallback = nullptr)
         {
             using TW = lazy::Tw<T>;
+            if (self_fallback != nullptr)
+                *self_fallback = false;
             if (plan.mode != PLAN_NONE && mods_dev != nullptr)
                 return false;
             // device-side modulus (the RNS overload with one modulus), dev_family:
@@ -293,6 +295,19 @@ namespace gpuntt
                 s.poly_shift = n_power;
                 s.mod_count = 1;
                 s.flags = vf;
+                // checked drop-in call with a host-side modulus: ONE fast kernel is enqueued, and when the table check
+                // takes the call away it runs the element-by-element algorithm on its tile itself
+                // (kern::fourstep_tile_generic) -- nothing behind the call.  (path = fast-strict: the veto must leave the
+                // output untouched, the tests look for that.)
+                if (vf != 0u && veto.check && plan.mode == PLAN_NONE && host::forced_path() != 3 && log_n1 == kern::XP_L1)
+                {
+                    s.flags |= kern::F_SELF_FALLBACK;
+                    s.fs_n1 = n1_table;
+                    s.fs_n2 = n2_table;
+                    s.fs_w = w_table;
+                    if (self_fallback != nullptr)
+                        *self_fallback = true;
+                }
                 if constexpr (sizeof(T) == 8)
                 {
                     if (lim == 8)
@@ -790,14 +805,17 @@ namespace gpuntt
                 // host-side modulus: the fast kernels, and -- unless option check_4step_tables is off -- the generic
                 // kernels behind the veto word, which run only when the table check took the call away from them
                 const host::FourStepVeto veto = fourstep_veto<T>(l1, l2, stream);
+                bool self_fallback = false;
                 const bool done =
                     (ntt_type == FORWARD)
                         ? fourstep_run_lazy<T, false>(in, out, n1_table, n2_table, w_table, mod, ninv, n_power, l1, l2, batch_size,
-                                                      stream, nullptr, nullptr, nullptr, PlanUse<T>(), 0, nullptr, veto)
+                                                      stream, nullptr, nullptr, nullptr, PlanUse<T>(), 0, nullptr, veto,
+                                                      &self_fallback)
                         : fourstep_run_lazy<T, true>(in, out, n1_table, n2_table, w_table, mod, ninv, n_power, l1, l2, batch_size,
-                                                     stream, nullptr, nullptr, nullptr, PlanUse<T>(), 0, nullptr, veto);
-                if (done && (!veto.check || host::forced_path() == 3))
-                    return; // (fast-strict: test hook, no generic shadow launches)
+                                                     stream, nullptr, nullptr, nullptr, PlanUse<T>(), 0, nullptr, veto,
+                                                     &self_fallback);
+                if (done && (!veto.check || host::forced_path() == 3 || self_fallback))
+                    return; // (fast-strict: test hook, no generic shadow launches; one-tile rings: the fast kernel is its own fall-back)
                 if (done)
                     skip_flag = veto.flag(); // all families = "return unless the state is GO_GENERIC"
                 else if (host::forced_path() == 3) // test hook, like the Merge entry points

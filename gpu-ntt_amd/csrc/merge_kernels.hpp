@@ -52,8 +52,10 @@ namespace gpuntt
             F_REVERSE = 128u, // fast kernels: walk the tiles from the last to the first (see run_transform_lazy)
             F_COLMOD = 64u, // PerCoefficient RNS: the modulus follows the COLUMN (flat & (2^n2_log - 1)) % mod_count
             F_PLAIN_ORDER = 256u, // fast kernels: poly-minor block order without the XCD grouping (GPUNTT_XCD_ORDER=0, A/B timing)
-            F_VETO_ONLY = 512u // fast kernels: the go-flag only carries a veto (4-step calls with a host-side modulus: the
-                               // host picked the kernel families, the table check may still hand the call to the generic kernels)
+            F_VETO_ONLY = 512u, // fast kernels: the go-flag only carries a veto (4-step calls with a host-side modulus: the
+                                // host picked the kernel families, the table check may still hand the call to the generic kernels)
+            F_SELF_FALLBACK = 1024u // one-tile 4-step kernels: when the veto fires, run the element-by-element algorithm on
+                                    // the tile yourself (kern::fourstep_tile_generic) -- nothing is enqueued behind the call
         };
 
         template <typename T> struct PassArgs

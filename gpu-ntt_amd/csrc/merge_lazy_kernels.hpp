@@ -35,6 +35,9 @@ namespace gpuntt
             const int* mod_order;            // *_Modulus_Ordered: prime of slot mi is mod_order[mi]
             const int* poly_order;           // *_Poly_Ordered: polynomial p lives in slot poly_order[p]
             const T* mul_in;                 // GPU_PolyMul: canonical operand multiplied into the final forward store, or nullptr
+            const T* fs_n1;                  // one-tile 4-step calls with F_SELF_FALLBACK: the caller's own three tables
+            const T* fs_n2;
+            const T* fs_w;
             int lim;                         // 64-bit words: 0, or 8 / 4 = a 61- / 62-bit modulus in the call -> the LIMIT = 8 / 4 kernels (host-side switch)
             int host_allow_31q;              // host side only: the preparation kernel of this drop-in RNS call may name the 31 q family
             int n2_log;                      // 4-step transposing passes: log2 of the row stride of the transposed side
@@ -1444,13 +1447,70 @@ namespace gpuntt
         // with the transposition of the natural-order side done in LDS (XP above).  a.tw = Merge table of the ring.
         // NAT: the natural-order extension (NTT_4STEP_CPU order on the spectrum side, Xp::small_nat_fwd / small_nat_inv) instead of the
         // reference layout (Xp::small_fwd / small_inv)
+        // The element-by-element algorithm of the generic kernels (merge_kernels.hpp: merge_pass<FST> -- n1-point transforms
+        // of the rows of the n2 x n1 input with n1_table, product with W[address], transposed -- and the n2-point row
+        // transforms with n2_table, n^-1 at the end of an inverse; reference src/lib/ntt_4step/ntt_4step.cu:68-743,
+        // 1049-1058, 776-779) on ONE polynomial that fills the tile, in LDS, with the Barrett operators the generic
+        // kernels use (bit for bit the same results for ANY three tables).  What a one-tile 4-step call computes when the
+        // table check took the call away from the fast kernel: no generic launches behind such calls (F_SELF_FALLBACK).
+        // Speed is beside the point (one thread per butterfly and stage, block barriers).
+        template <typename T, int TLOG, bool INV>
+        __device__ void fourstep_tile_generic(const LazyArgsT<T>& a, T* lds, unsigned long long poly, const dev::ModCtx<T>& m,
+                                              T ninv)
+        {
+            constexpr int NT = LTile<TLOG>::NT, N = 1 << TLOG, L1 = XP_L1, L2 = TLOG - XP_L1;
+            static_assert(N == NT * EPT, "16 coefficients per thread");
+            const int t = threadIdx.x;
+            const T* in = static_cast<const T*>(a.in) + (poly << TLOG);
+            T* out = a.out + (poly << TLOG);
+            for (int e = t; e < N; e += NT)
+                lds[e] = in[e];
+            __syncthreads();
+            auto stages = [&](const T* table, int lg) {
+                for (int s = 0; s < lg; s++)
+                {
+                    const int P = INV ? s : (lg - 1 - s); // distance 2^P: Cooley-Tukey from the top, Gentleman-Sande from the bottom
+                    for (int b = t; b < N / 2; b += NT)
+                    {
+                        const int e0 = ((b >> P) << (P + 1)) | (b & ((1 << P) - 1)), e1 = e0 | (1 << P);
+                        const unsigned idx = static_cast<unsigned>(e0) & ((1u << lg) - 1u);
+                        const T w = table[idx >> (P + 1)];
+                        T U = lds[e0], V = lds[e1];
+                        if constexpr (INV)
+                            dev::gs_butterfly(U, V, w, m);
+                        else
+                            dev::ct_butterfly(U, V, w, m);
+                        lds[e0] = U;
+                        lds[e1] = V;
+                    }
+                    __syncthreads();
+                }
+            };
+            stages(a.fs_n1, L1);
+            // out[(i << l2) + r] = row r, element i, times W[(i << l2) + r]
+            T tmp[EPT];
+#pragma unroll
+            for (int k = 0; k < EPT; k++)
+            {
+                const unsigned o = static_cast<unsigned>(t + NT * k);
+                const unsigned i = o >> L2, r = o & ((1u << L2) - 1u);
+                tmp[k] = m.mul(lds[(r << L1) | i], a.fs_w[o]);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < EPT; k++)
+                lds[t + NT * k] = tmp[k];
+            __syncthreads();
+            stages(a.fs_n2, L2);
+            for (int e = t; e < N; e += NT)
+                out[e] = INV ? m.mul(lds[e], ninv) : lds[e];
+        }
+
         template <typename T, int TLOG, bool INV, int K, int LIM = 0, bool NAT = false>
         __global__ __launch_bounds__(LTile<TLOG>::NT, (LOcc<TLOG, T>::WAVES)) void fourstep_small_lazy(LazyArgsT<T> a)
         {
             static_assert(K >= 12 && K == TLOG, "one-tile 4-step rings fill their tile: 32 x n2 with n2 >= 128");
             __shared__ T lds[LTile<TLOG>::LDS_ELEMS];
-            if (not_my_call<T, LIM>(a.go_flag, a.flags))
-                return;
             T qv = a.q, qb = a.q_bit, qm = a.q_mu;
             if (a.mods != nullptr)
             {
@@ -1459,6 +1519,16 @@ namespace gpuntt
                 qb = md.bit;
                 qm = md.mu;
             }
+            if constexpr (!NAT)
+                if ((a.flags & F_SELF_FALLBACK) != 0u && a.go_flag != nullptr && *a.go_flag == GO_GENERIC)
+                {
+                    const dev::ModCtx<T> em{qv, qb, qm};
+                    const T ninv = (a.ninv_arr != nullptr) ? a.ninv_arr[0].w : a.ninv.w;
+                    fourstep_tile_generic<T, TLOG, INV>(a, lds, blockIdx.x, em, ninv);
+                    return;
+                }
+            if (not_my_call<T, LIM>(a.go_flag, a.flags))
+                return;
             for_each_block<WalksTiles<T, LIM>::value>(
                 static_cast<unsigned>((a.total + LTile<TLOG>::TILE - 1) >> TLOG), [&](unsigned bidx, unsigned) {
                     pass_body<T, TLOG, INV, true, K, 1, true, Fst::none, LIM,
