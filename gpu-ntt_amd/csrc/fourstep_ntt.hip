@@ -107,7 +107,8 @@ namespace gpuntt
         void fourstep_run(T* in, T* out, const T* n1_table, const T* n2_table, const T* w_table,
                           const Modulus<T>* mods, Modulus<T> mod, int mod_count, const T* ninv_arr,
                           T ninv, int n_power, int log_n1, int log_n2, int batch_size,
-                          hipStream_t stream, const unsigned* skip_flag = nullptr, unsigned skip_value = 0u)
+                          hipStream_t stream, const unsigned* skip_flag = nullptr, unsigned skip_value = 0u,
+                          bool skip_phase1 = false)
         {
             kern::PassArgs<T> a{};
             a.skip_flag = skip_flag;
@@ -132,21 +133,22 @@ namespace gpuntt
             // walks the tiles, like the Merge shadow launches (launch_impl.hpp)
             const unsigned long long tiles = a.total >> kern::TL;
             const unsigned grid = (skip_flag != nullptr && tiles > GPUNTT_SHADOW_GRID) ? static_cast<unsigned>(GPUNTT_SHADOW_GRID) : static_cast<unsigned>(tiles);
-            switch (log_n1)
-            {
-                case 5:
-                    host::launch_one<T, INV, true, 5, true>(a, grid, stream);
-                    break;
-                case 6:
-                    host::launch_one<T, INV, true, 6, true>(a, grid, stream);
-                    break;
-                case 7:
-                    host::launch_one<T, INV, true, 7, true>(a, grid, stream);
-                    break;
-                default:
-                    host::launch_one<T, INV, true, 8, true>(a, grid, stream);
-                    break;
-            }
+            if (!skip_phase1) // (skipped: the fast first kernel of the call does phase 1 itself when the veto fires)
+                switch (log_n1)
+                {
+                    case 5:
+                        host::launch_one<T, INV, true, 5, true>(a, grid, stream);
+                        break;
+                    case 6:
+                        host::launch_one<T, INV, true, 6, true>(a, grid, stream);
+                        break;
+                    case 7:
+                        host::launch_one<T, INV, true, 7, true>(a, grid, stream);
+                        break;
+                    default:
+                        host::launch_one<T, INV, true, 8, true>(a, grid, stream);
+                        break;
+                }
             // phase 2: n2-point transforms on the batch*n1 rows of `out`, in place
             kern::PassArgs<T> b = a;
             b.in = out;
@@ -207,11 +209,17 @@ namespace gpuntt
                                int batch_size, hipStream_t stream, const Modulus<T>* mods_dev = nullptr,
                                const T* ninv_dev = nullptr, const unsigned** go_flag_out = nullptr,
                                const PlanUse<T>& plan = PlanUse<T>(), int dev_family = 0, unsigned* host_state = nullptr,
-                               const host::FourStepVeto& veto = host::FourStepVeto(), bool* self_fallback = nullptr)
+                               const host::FourStepVeto& veto = host::FourStepVeto(), int* self_fallback = nullptr)
         {
             using TW = lazy::Tw<T>;
+            // *self_fallback: what the fast kernels of this call do themselves when the table check vetoes them
+            // (kern::F_SELF_FALLBACK): 0 nothing, 1 phase 1 of the element-by-element algorithm, 2 all of it
             if (self_fallback != nullptr)
-                *self_fallback = false;
+                *self_fallback = 0;
+            // eligible: checked drop-in call with a host-side modulus (ONE family enqueued).  path = fast-strict: the veto
+            // must leave the output untouched, the tests look for that
+            const bool self_ok = veto.check && veto.word != nullptr && mods_dev == nullptr && plan.mode == PLAN_NONE &&
+                                 host::forced_path() != 3 && self_fallback != nullptr;
             if (plan.mode != PLAN_NONE && mods_dev != nullptr)
                 return false;
             // device-side modulus (the RNS overload with one modulus), dev_family:
@@ -295,18 +303,15 @@ namespace gpuntt
                 s.poly_shift = n_power;
                 s.mod_count = 1;
                 s.flags = vf;
-                // checked drop-in call with a host-side modulus: ONE fast kernel is enqueued, and when the table check
-                // takes the call away it runs the element-by-element algorithm on its tile itself
-                // (kern::fourstep_tile_generic) -- nothing behind the call.  (path = fast-strict: the veto must leave the
-                // output untouched, the tests look for that.)
-                if (vf != 0u && veto.check && plan.mode == PLAN_NONE && host::forced_path() != 3 && log_n1 == kern::XP_L1)
+                // ONE fast kernel is enqueued, and when the table check takes the call away it runs the element-by-element
+                // algorithm on its tile itself (kern::fourstep_tile_generic) -- nothing behind the call
+                if (vf != 0u && self_ok && log_n1 == kern::XP_L1)
                 {
                     s.flags |= kern::F_SELF_FALLBACK;
                     s.fs_n1 = n1_table;
                     s.fs_n2 = n2_table;
                     s.fs_w = w_table;
-                    if (self_fallback != nullptr)
-                        *self_fallback = true;
+                    *self_fallback = 2;
                 }
                 if constexpr (sizeof(T) == 8)
                 {
@@ -361,6 +366,16 @@ namespace gpuntt
                     f.poly_shift = n_power;
                     f.mod_count = 1;
                     f.flags = host::lazy_order_flags() | vf;
+                    if (vf != 0u && self_ok)
+                    {
+                        // the gathering first kernel does phase 1 of the element-by-element algorithm when vetoed: only the
+                        // n2-point row transforms of the generic kernels are enqueued behind the call
+                        f.flags |= kern::F_SELF_FALLBACK;
+                        f.fs_n1 = n1_table;
+                        f.fs_n2 = n2_table;
+                        f.fs_w = w_table;
+                        *self_fallback = 1;
+                    }
                     {
                         // consecutive sweeps walk the batch in opposite directions, the LAST one forwards
                         const int pn = n_power - k1;
@@ -438,6 +453,18 @@ namespace gpuntt
                     // from 2^20 the per-lane twiddles of the pass are tens of MiB per polynomial: poly-minor block order
                     f.batch = (n_power >= 20 && batch_size >= 2) ? batch_size : 0;
                     f.flags = host::lazy_order_flags() | vf;
+                    const bool self_inv = vf != 0u && self_ok && lim == 0;
+                    if (self_inv)
+                    {
+                        // vetoed: the transposing first kernel does phase 1 of the element-by-element algorithm, the row
+                        // pass of the rings 2^14 .. 2^16 phase 2 (nothing behind the call); larger rings keep the generic
+                        // row transforms behind them
+                        f.flags |= kern::F_SELF_FALLBACK;
+                        f.fs_n1 = n1_table;
+                        f.fs_n2 = n2_table;
+                        f.fs_w = w_table;
+                        *self_fallback = rows512 ? 2 : 1;
+                    }
                     if (rev && ((passes - 1) & 1) != 0) // the last sweep walks the batch forwards, the one before it backwards, ...
                         f.flags |= kern::F_REVERSE;
                     bool wide32 = false;
@@ -471,7 +498,7 @@ namespace gpuntt
                         r.ninv_arr = ws_ninv;
                     if (rows512)
                     {
-                        r.flags = host::lazy_order_flags() | vf;
+                        r.flags = host::lazy_order_flags() | vf | (self_inv ? static_cast<unsigned>(kern::F_SELF_FALLBACK) : 0u);
                         if constexpr (sizeof(T) == 4)
                         {
                             if (wide32)
@@ -760,6 +787,7 @@ namespace gpuntt
             if ((static_cast<unsigned long long>(batch_size) << n_power) >> kern::TL > 0x7fffffffull)
                 throw std::invalid_argument("batch_size * N too large for one launch");
             const unsigned* skip_flag = nullptr;
+            bool skip_phase1 = false; // the fast first kernel does phase 1 itself when vetoed (kern::F_SELF_FALLBACK)
             host::RnsGuess guess{kern::GO_LAZY, true, nullptr};
             if (mods != nullptr && mod_count == 1 && host::forced_path() == 4)
             {
@@ -805,7 +833,7 @@ namespace gpuntt
                 // host-side modulus: the fast kernels, and -- unless option check_4step_tables is off -- the generic
                 // kernels behind the veto word, which run only when the table check took the call away from them
                 const host::FourStepVeto veto = fourstep_veto<T>(l1, l2, stream);
-                bool self_fallback = false;
+                int self_fallback = 0;
                 const bool done =
                     (ntt_type == FORWARD)
                         ? fourstep_run_lazy<T, false>(in, out, n1_table, n2_table, w_table, mod, ninv, n_power, l1, l2, batch_size,
@@ -814,10 +842,13 @@ namespace gpuntt
                         : fourstep_run_lazy<T, true>(in, out, n1_table, n2_table, w_table, mod, ninv, n_power, l1, l2, batch_size,
                                                      stream, nullptr, nullptr, nullptr, PlanUse<T>(), 0, nullptr, veto,
                                                      &self_fallback);
-                if (done && (!veto.check || host::forced_path() == 3 || self_fallback))
-                    return; // (fast-strict: test hook, no generic shadow launches; one-tile rings: the fast kernel is its own fall-back)
+                if (done && (!veto.check || host::forced_path() == 3 || self_fallback == 2))
+                    return; // (fast-strict: test hook, no generic shadow launches; 2: the fast kernels are their own fall-back)
                 if (done)
+                {
                     skip_flag = veto.flag(); // all families = "return unless the state is GO_GENERIC"
+                    skip_phase1 = (self_fallback == 1);
+                }
                 else if (host::forced_path() == 3) // test hook, like the Merge entry points
                     throw std::invalid_argument("fast path unavailable for this call (path = fast-strict)");
             }
@@ -832,10 +863,10 @@ namespace gpuntt
             }
             if (ntt_type == FORWARD)
                 fourstep_run<T, false>(in, out, n1_table, n2_table, w_table, mods, mod, mod_count,
-                                       ninv_arr, ninv, n_power, l1, l2, batch_size, stream, skip_flag, skip_value);
+                                       ninv_arr, ninv, n_power, l1, l2, batch_size, stream, skip_flag, skip_value, skip_phase1);
             else
                 fourstep_run<T, true>(in, out, n1_table, n2_table, w_table, mods, mod, mod_count,
-                                      ninv_arr, ninv, n_power, l1, l2, batch_size, stream, skip_flag, skip_value);
+                                      ninv_arr, ninv, n_power, l1, l2, batch_size, stream, skip_flag, skip_value, skip_phase1);
         }
     } // namespace
 

@@ -1225,6 +1225,108 @@ namespace gpuntt
             }
         }
 
+        // ---- the element-by-element 4-step algorithm of the generic kernels, restated for the fast kernels' own blocks ---------
+        // (merge_kernels.hpp: merge_pass<FST> -- n1-point transforms of the rows of the n2 x n1 input with n1_table, product
+        // with W[address], transposed store -- and the n2-point row transforms with n2_table, n^-1 at the end of an inverse;
+        // reference src/lib/ntt_4step/ntt_4step.cu:68-743, 1049-1058, 776-779), with the Barrett operators the generic
+        // kernels use: bit for bit their results for ANY three tables.  What a checked 4-step call computes when the table
+        // check took the call away from the fast kernels (GO_GENERIC) and the host asked them to be their own fall-back
+        // (F_SELF_FALLBACK): the first kernel of every plan does phase 1, one-tile kernels and the inverse row pass of the
+        // rings 2^14 .. 2^16 phase 2 as well, so fewer (or no) generic launches sit behind the call.  Speed is beside the
+        // point: one thread per butterfly and stage, block barriers.
+        // 2^lg-point transforms of the `nel` consecutive words at buf (LDS, or the block's own words of global memory)
+        template <typename T, bool INV, int NT>
+        __device__ __forceinline__ void fs_stages(T* buf, int nel, const T* table, int lg, const dev::ModCtx<T>& m)
+        {
+            const int t = threadIdx.x;
+            for (int s = 0; s < lg; s++)
+            {
+                const int P = INV ? s : (lg - 1 - s); // distance 2^P: Cooley-Tukey from the top, Gentleman-Sande from the bottom
+                for (int b = t; b < nel / 2; b += NT)
+                {
+                    const int e0 = ((b >> P) << (P + 1)) | (b & ((1 << P) - 1)), e1 = e0 | (1 << P);
+                    const unsigned idx = static_cast<unsigned>(e0) & ((1u << lg) - 1u);
+                    const T w = table[idx >> (P + 1)];
+                    T U = buf[e0], V = buf[e1];
+                    if constexpr (INV)
+                        dev::gs_butterfly(U, V, w, m);
+                    else
+                        dev::ct_butterfly(U, V, w, m);
+                    buf[e0] = U;
+                    buf[e1] = V;
+                }
+                __syncthreads();
+            }
+        }
+        // phase 1 on the 4096 words [tile << 12, ...) of polynomial poly: 2^(12 - l1) rows of n1
+        template <typename T, bool INV, int NT>
+        __device__ __forceinline__ void fs_phase1_tile(const LazyArgsT<T>& a, T* lds, unsigned long long poly, unsigned tile, int l1,
+                                                       int l2, const dev::ModCtx<T>& m)
+        {
+            const int t = threadIdx.x;
+            const T* in = static_cast<const T*>(a.in) + (poly << (l1 + l2)) + (static_cast<unsigned long long>(tile) << 12);
+            T* out = a.out + (poly << (l1 + l2));
+            for (int e = t; e < 4096; e += NT)
+                lds[e] = in[e];
+            __syncthreads();
+            fs_stages<T, INV, NT>(lds, 4096, a.fs_n1, l1, m);
+            const unsigned row0 = tile << (12 - l1);
+            for (int e = t; e < 4096; e += NT)
+            {
+                const unsigned r = row0 + (static_cast<unsigned>(e) >> l1), i = static_cast<unsigned>(e) & ((1u << l1) - 1u);
+                const unsigned long long widx = (static_cast<unsigned long long>(i) << l2) + r;
+                out[widx] = m.mul(lds[e], a.fs_w[widx]);
+            }
+            __syncthreads();
+        }
+        // phase 2 on the 4096 words [chunk << 12, ...) of `out`, in place (rows of n2 <= 4096)
+        template <typename T, bool INV, int NT>
+        __device__ __forceinline__ void fs_phase2_chunk(const LazyArgsT<T>& a, unsigned long long chunk, int l2, const dev::ModCtx<T>& m,
+                                                        T ninv)
+        {
+            T* buf = a.out + (chunk << 12);
+            fs_stages<T, INV, NT>(buf, 4096, a.fs_n2, l2, m);
+            if constexpr (INV)
+                for (int e = threadIdx.x; e < 4096; e += NT)
+                    buf[e] = m.mul(buf[e], ninv);
+        }
+        template <typename T> __device__ __forceinline__ bool self_fallback_call(const LazyArgsT<T>& a)
+        {
+            return (a.flags & F_SELF_FALLBACK) != 0u && a.go_flag != nullptr && *a.go_flag == GO_GENERIC;
+        }
+        // both phases on ONE polynomial that fills the tile (one-tile rings, n1 = 32), in LDS
+        template <typename T, int TLOG, bool INV>
+        __device__ __forceinline__ void fourstep_tile_generic(const LazyArgsT<T>& a, T* lds, unsigned long long poly,
+                                                              const dev::ModCtx<T>& m, T ninv)
+        {
+            constexpr int NT = LTile<TLOG>::NT, N = 1 << TLOG, L1 = XP_L1, L2 = TLOG - XP_L1;
+            static_assert(N == NT * EPT, "16 coefficients per thread");
+            const int t = threadIdx.x;
+            const T* in = static_cast<const T*>(a.in) + (poly << TLOG);
+            T* out = a.out + (poly << TLOG);
+            for (int e = t; e < N; e += NT)
+                lds[e] = in[e];
+            __syncthreads();
+            fs_stages<T, INV, NT>(lds, N, a.fs_n1, L1, m);
+            // out[(i << l2) + r] = row r, element i, times W[(i << l2) + r]
+            T tmp[EPT];
+#pragma unroll
+            for (int k = 0; k < EPT; k++)
+            {
+                const unsigned o = static_cast<unsigned>(t + NT * k);
+                const unsigned i = o >> L2, r = o & ((1u << L2) - 1u);
+                tmp[k] = m.mul(lds[(r << L1) | i], a.fs_w[o]);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < EPT; k++)
+                lds[t + NT * k] = tmp[k];
+            __syncthreads();
+            fs_stages<T, INV, NT>(lds, N, a.fs_n2, L2, m);
+            for (int e = t; e < N; e += NT)
+                out[e] = INV ? m.mul(lds[e], ninv) : lds[e];
+        }
+
         template <typename T, int TLOG, bool INV, bool CONTIG, int K, int IN_BOUND, bool LAST, int LIM = 0, int SKIP = 0>
         __global__ __launch_bounds__(LTile<TLOG>::NT, (LOcc<TLOG, T>::WAVES)) void merge_pass_lazy(LazyArgsT<T> a)
         {
@@ -1234,6 +1336,14 @@ namespace gpuntt
             constexpr bool NEEDS_LDS = (SCH::NR > 1) || (SCH::wl_of(0) < 4);
             __shared__ T lds[NEEDS_LDS ? LTile<TLOG>::LDS_ELEMS : 1];
 
+            // (the inverse row pass of the 4-step rings 2^14 .. 2^16 as its own fall-back: phase 2 of the generic algorithm)
+            if constexpr (SKIP != 0 && INV && TLOG == 12)
+                if (self_fallback_call(a))
+                {
+                    const dev::ModCtx<T> em{a.q, a.q_bit, a.q_mu};
+                    fs_phase2_chunk<T, true, LTile<12>::NT>(a, blockIdx.x, a.n, em, a.ninv.w);
+                    return;
+                }
             // RNS calls: the twiddle-prep kernel publishes which kernel family the stack of moduli needs (not_my_call);
             // the other families, launched alongside, return here
             if (not_my_call<T, LIM>(a.go_flag, a.flags))
@@ -1385,6 +1495,14 @@ namespace gpuntt
         __global__ __launch_bounds__(LTile<12>::NT, (LOcc<12, T>::WAVES)) void fourstep_first_lazy(LazyArgsT<T> a)
         {
             __shared__ T lds[LTile<12>::LDS_ELEMS];
+            if (self_fallback_call(a)) // phase 1 of the generic algorithm on 4096-word tile blockIdx.x (a.n2_log = log2 n1 here)
+            {
+                const dev::ModCtx<T> em{a.q, a.q_bit, a.q_mu};
+                const unsigned tiles_log = static_cast<unsigned>(a.n - 12);
+                fs_phase1_tile<T, false, LTile<12>::NT>(a, lds, blockIdx.x >> tiles_log, blockIdx.x & ((1u << tiles_log) - 1u),
+                                                         a.n2_log, a.n - a.n2_log, em);
+                return;
+            }
             if (not_my_call<T, LIM>(a.go_flag, a.flags))
                 return;
             T qv = a.q, qb = a.q_bit, qm = a.q_mu;
@@ -1417,6 +1535,16 @@ namespace gpuntt
         __global__ __launch_bounds__(LTile<TLOG>::NT, (LOcc<TLOG, T>::WAVES)) void fourstep_inv_first_lazy(LazyArgsT<T> a)
         {
             __shared__ T lds[LTile<TLOG>::LDS_ELEMS_FST];
+            if (self_fallback_call(a)) // phase 1 of the generic algorithm on the 2^(TLOG - 12) 4096-word tiles of block blockIdx.x
+            {
+                const dev::ModCtx<T> em{a.q, a.q_bit, a.q_mu};
+                const unsigned tiles_log = static_cast<unsigned>(a.n - TLOG);
+                const unsigned long long poly = blockIdx.x >> tiles_log;
+                const unsigned big = blockIdx.x & ((1u << tiles_log) - 1u);
+                for (unsigned sub = 0; sub < (1u << (TLOG - 12)); sub++)
+                    fs_phase1_tile<T, true, LTile<TLOG>::NT>(a, lds, poly, (big << (TLOG - 12)) + sub, L1, a.n - L1, em);
+                return;
+            }
             if (not_my_call<T, LIM>(a.go_flag, a.flags))
                 return;
             T qv = a.q, qb = a.q_bit, qm = a.q_mu;
@@ -1447,65 +1575,6 @@ namespace gpuntt
         // with the transposition of the natural-order side done in LDS (XP above).  a.tw = Merge table of the ring.
         // NAT: the natural-order extension (NTT_4STEP_CPU order on the spectrum side, Xp::small_nat_fwd / small_nat_inv) instead of the
         // reference layout (Xp::small_fwd / small_inv)
-        // The element-by-element algorithm of the generic kernels (merge_kernels.hpp: merge_pass<FST> -- n1-point transforms
-        // of the rows of the n2 x n1 input with n1_table, product with W[address], transposed -- and the n2-point row
-        // transforms with n2_table, n^-1 at the end of an inverse; reference src/lib/ntt_4step/ntt_4step.cu:68-743,
-        // 1049-1058, 776-779) on ONE polynomial that fills the tile, in LDS, with the Barrett operators the generic
-        // kernels use (bit for bit the same results for ANY three tables).  What a one-tile 4-step call computes when the
-        // table check took the call away from the fast kernel: no generic launches behind such calls (F_SELF_FALLBACK).
-        // Speed is beside the point (one thread per butterfly and stage, block barriers).
-        template <typename T, int TLOG, bool INV>
-        __device__ void fourstep_tile_generic(const LazyArgsT<T>& a, T* lds, unsigned long long poly, const dev::ModCtx<T>& m,
-                                              T ninv)
-        {
-            constexpr int NT = LTile<TLOG>::NT, N = 1 << TLOG, L1 = XP_L1, L2 = TLOG - XP_L1;
-            static_assert(N == NT * EPT, "16 coefficients per thread");
-            const int t = threadIdx.x;
-            const T* in = static_cast<const T*>(a.in) + (poly << TLOG);
-            T* out = a.out + (poly << TLOG);
-            for (int e = t; e < N; e += NT)
-                lds[e] = in[e];
-            __syncthreads();
-            auto stages = [&](const T* table, int lg) {
-                for (int s = 0; s < lg; s++)
-                {
-                    const int P = INV ? s : (lg - 1 - s); // distance 2^P: Cooley-Tukey from the top, Gentleman-Sande from the bottom
-                    for (int b = t; b < N / 2; b += NT)
-                    {
-                        const int e0 = ((b >> P) << (P + 1)) | (b & ((1 << P) - 1)), e1 = e0 | (1 << P);
-                        const unsigned idx = static_cast<unsigned>(e0) & ((1u << lg) - 1u);
-                        const T w = table[idx >> (P + 1)];
-                        T U = lds[e0], V = lds[e1];
-                        if constexpr (INV)
-                            dev::gs_butterfly(U, V, w, m);
-                        else
-                            dev::ct_butterfly(U, V, w, m);
-                        lds[e0] = U;
-                        lds[e1] = V;
-                    }
-                    __syncthreads();
-                }
-            };
-            stages(a.fs_n1, L1);
-            // out[(i << l2) + r] = row r, element i, times W[(i << l2) + r]
-            T tmp[EPT];
-#pragma unroll
-            for (int k = 0; k < EPT; k++)
-            {
-                const unsigned o = static_cast<unsigned>(t + NT * k);
-                const unsigned i = o >> L2, r = o & ((1u << L2) - 1u);
-                tmp[k] = m.mul(lds[(r << L1) | i], a.fs_w[o]);
-            }
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < EPT; k++)
-                lds[t + NT * k] = tmp[k];
-            __syncthreads();
-            stages(a.fs_n2, L2);
-            for (int e = t; e < N; e += NT)
-                out[e] = INV ? m.mul(lds[e], ninv) : lds[e];
-        }
-
         template <typename T, int TLOG, bool INV, int K, int LIM = 0, bool NAT = false>
         __global__ __launch_bounds__(LTile<TLOG>::NT, (LOcc<TLOG, T>::WAVES)) void fourstep_small_lazy(LazyArgsT<T> a)
         {
@@ -1520,7 +1589,7 @@ namespace gpuntt
                 qm = md.mu;
             }
             if constexpr (!NAT)
-                if ((a.flags & F_SELF_FALLBACK) != 0u && a.go_flag != nullptr && *a.go_flag == GO_GENERIC)
+                if (self_fallback_call(a))
                 {
                     const dev::ModCtx<T> em{qv, qb, qm};
                     const T ninv = (a.ninv_arr != nullptr) ? a.ninv_arr[0].w : a.ninv.w;

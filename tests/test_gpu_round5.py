@@ -223,7 +223,8 @@ def _fourstep_call(g, p4, tabs, d_in, batch, inverse, how):
     return g.to_host(d_out), None
 
 
-@pytest.mark.parametrize("bits,logn", [(64, 12), (64, 13), (64, 14), (64, 16), (32, 12), (32, 13), (32, 14), (32, 18), (64, 20)])
+@pytest.mark.parametrize("bits,logn", [(64, 12), (64, 13), (64, 14), (64, 16), (64, 17), (32, 12), (32, 13), (32, 14), (32, 15), (32, 18),
+                                       (64, 20), (32, 20), (64, 21)])
 def test_fourstep_exact_for_any_tables_by_default(g, bits, logn):
     """VERDICT r4 weak #1 / missing #2.  The reference multiplies by W[address] element by element and walks n2_table
     (src/lib/ntt_4step/ntt_4step.cu:1049-1058, 776-779); the fast path derives every twiddle from n1_table and one row of
