@@ -37,7 +37,7 @@ def timed(fn, iters=200, warm=20):
 
 print("# u64; us per call; lib = %s" % os.path.basename(g.LIB_PATH))
 print("# logN batch dir  checked  unchecked  plan   checked/unchecked")
-SHAPES = ((12, 1), (12, 64), (14, 8), (16, 1), (16, 16), (18, 4), (20, 1), (20, 16), (22, 4), (24, 1), (24, 4))
+SHAPES = ((12, 1), (12, 64), (13, 8), (14, 8), (14, 512), (16, 1), (16, 16), (18, 4), (20, 1), (20, 16), (22, 4), (24, 1), (24, 4))
 if len(sys.argv) > 1:  # e.g. 24:1 20:16
     SHAPES = tuple(tuple(int(v) for v in a.split(":")) for a in sys.argv[1:])
 for logn, batch in SHAPES:
