@@ -209,17 +209,21 @@ namespace gpuntt
                                int batch_size, hipStream_t stream, const Modulus<T>* mods_dev = nullptr,
                                const T* ninv_dev = nullptr, const unsigned** go_flag_out = nullptr,
                                const PlanUse<T>& plan = PlanUse<T>(), int dev_family = 0, unsigned* host_state = nullptr,
-                               const host::FourStepVeto& veto = host::FourStepVeto(), int* self_fallback = nullptr)
+                               const host::FourStepVeto& veto = host::FourStepVeto(), int* self_fallback = nullptr,
+                               bool dev_self = false)
         {
             using TW = lazy::Tw<T>;
             // *self_fallback: what the fast kernels of this call do themselves when the table check vetoes them
             // (kern::F_SELF_FALLBACK): 0 nothing, 1 phase 1 of the element-by-element algorithm, 2 all of it
             if (self_fallback != nullptr)
                 *self_fallback = 0;
-            // eligible: checked drop-in call with a host-side modulus (ONE family enqueued).  path = fast-strict: the veto
-            // must leave the output untouched, the tests look for that
-            const bool self_ok = veto.check && veto.word != nullptr && mods_dev == nullptr && plan.mode == PLAN_NONE &&
-                                 host::forced_path() != 3 && self_fallback != nullptr;
+            // eligible: drop-in calls behind which exactly ONE family of fast kernels is enqueued -- checked calls with a
+            // host-side modulus, and calls with a device-side modulus for which the host predicts the default family and
+            // enqueues nothing else (dev_self; the kernels then run the element-by-element algorithm whenever the call turns
+            // out not to be theirs: vetoed tables, a modulus of another family or outside the fast kernels' domain).
+            // path = fast-strict: a veto must leave the output untouched, the tests look for that
+            const bool self_ok = plan.mode == PLAN_NONE && host::forced_path() != 3 && self_fallback != nullptr &&
+                                 (mods_dev == nullptr ? (veto.check && veto.word != nullptr) : (dev_self && dev_family == 0));
             if (plan.mode != PLAN_NONE && mods_dev != nullptr)
                 return false;
             // device-side modulus (the RNS overload with one modulus), dev_family:
@@ -305,7 +309,7 @@ namespace gpuntt
                 s.flags = vf;
                 // ONE fast kernel is enqueued, and when the table check takes the call away it runs the element-by-element
                 // algorithm on its tile itself (kern::fourstep_tile_generic) -- nothing behind the call
-                if (vf != 0u && self_ok && log_n1 == kern::XP_L1)
+                if (self_ok && go_flag != nullptr && log_n1 == kern::XP_L1)
                 {
                     s.flags |= kern::F_SELF_FALLBACK;
                     s.fs_n1 = n1_table;
@@ -366,7 +370,7 @@ namespace gpuntt
                     f.poly_shift = n_power;
                     f.mod_count = 1;
                     f.flags = host::lazy_order_flags() | vf;
-                    if (vf != 0u && self_ok)
+                    if (self_ok && go_flag != nullptr)
                     {
                         // the gathering first kernel does phase 1 of the element-by-element algorithm when vetoed: only the
                         // n2-point row transforms of the generic kernels are enqueued behind the call
@@ -453,7 +457,7 @@ namespace gpuntt
                     // from 2^20 the per-lane twiddles of the pass are tens of MiB per polynomial: poly-minor block order
                     f.batch = (n_power >= 20 && batch_size >= 2) ? batch_size : 0;
                     f.flags = host::lazy_order_flags() | vf;
-                    const bool self_inv = vf != 0u && self_ok && lim == 0;
+                    const bool self_inv = self_ok && go_flag != nullptr && lim == 0;
                     if (self_inv)
                     {
                         // vetoed: the transposing first kernel does phase 1 of the element-by-element algorithm, the row
@@ -788,6 +792,7 @@ namespace gpuntt
                 throw std::invalid_argument("batch_size * N too large for one launch");
             const unsigned* skip_flag = nullptr;
             bool skip_phase1 = false; // the fast first kernel does phase 1 itself when vetoed (kern::F_SELF_FALLBACK)
+            int self_fb = 0;          // device-side modulus: what fourstep_run_lazy reports for the default family's kernels
             host::RnsGuess guess{kern::GO_LAZY, true, nullptr};
             if (mods != nullptr && mod_count == 1 && host::forced_path() == 4)
             {
@@ -805,19 +810,24 @@ namespace gpuntt
                 // one root (prep.hip)
                 const host::FourStepVeto veto = fourstep_veto<T>(l1, l2, stream);
                 guess = host::rns_guess(mods, 1, static_cast<int>(sizeof(T)) | 0x40, ntt_type == INVERSE, nullptr, true); // (0x40: the 4-step entry keeps its own slot)
+                const bool only_default = !guess.all_families && guess.state == kern::GO_LAZY;
                 auto enqueue = [&](int family, const unsigned** flag_out) {
+                    // only_default: this is the ONE family enqueued for the call -- its kernels may be their own fall-back
+                    int* self = (family == 0 && only_default) ? &self_fb : nullptr;
                     if (ntt_type == FORWARD)
                         return fourstep_run_lazy<T, false>(in, out, n1_table, n2_table, w_table, Modulus<T>(), T(0), n_power, l1, l2,
                                                            batch_size, stream, mods, ninv_arr, flag_out, PlanUse<T>(), family,
-                                                           guess.state_out, veto);
+                                                           guess.state_out, veto, self, self != nullptr);
                     return fourstep_run_lazy<T, true>(in, out, n1_table, n2_table, w_table, Modulus<T>(), T(0), n_power, l1, l2,
                                                       batch_size, stream, mods, ninv_arr, flag_out, PlanUse<T>(), family,
-                                                      guess.state_out, veto);
+                                                      guess.state_out, veto, self, self != nullptr);
                 };
-                const bool only_default = !guess.all_families && guess.state == kern::GO_LAZY;
                 // the first enqueue prepares the table and publishes the flag; with it the default family unless another
                 // one is predicted
                 enqueue((guess.all_families || only_default) ? 0 : -1, &skip_flag);
+                if (self_fb == 2 && skip_flag != nullptr)
+                    return; // the default family's kernels serve whatever the preparation kernel finds
+                skip_phase1 = (self_fb == 1 && skip_flag != nullptr);
                 if constexpr (sizeof(T) == 8)
                 {
                     if (skip_flag != nullptr)

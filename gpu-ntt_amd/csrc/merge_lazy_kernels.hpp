@@ -1290,9 +1290,25 @@ namespace gpuntt
                 for (int e = threadIdx.x; e < 4096; e += NT)
                     buf[e] = m.mul(buf[e], ninv);
         }
-        template <typename T> __device__ __forceinline__ bool self_fallback_call(const LazyArgsT<T>& a)
+        // "this call is not mine and the host enqueued nothing else for it": the table check vetoed it (host-side modulus), or the
+        // device-side modulus turned out to need another family than the one the host predicted -- or none
+        template <typename T, int LIM> __device__ __forceinline__ bool self_fallback_call(const LazyArgsT<T>& a)
         {
-            return (a.flags & F_SELF_FALLBACK) != 0u && a.go_flag != nullptr && *a.go_flag == GO_GENERIC;
+            return (a.flags & F_SELF_FALLBACK) != 0u && not_my_call<T, LIM>(a.go_flag, a.flags);
+        }
+        // modulus and n^-1 of a 4-step call (one modulus: host-side, or slot 0 of the device array) for the Barrett operators
+        template <typename T> __device__ __forceinline__ dev::ModCtx<T> fs_modulus(const LazyArgsT<T>& a)
+        {
+            if (a.mods != nullptr)
+            {
+                const Modulus<T> md = a.mods[0];
+                return dev::ModCtx<T>{md.value, md.bit, md.mu};
+            }
+            return dev::ModCtx<T>{a.q, a.q_bit, a.q_mu};
+        }
+        template <typename T> __device__ __forceinline__ T fs_ninv(const LazyArgsT<T>& a)
+        {
+            return (a.ninv_arr != nullptr) ? a.ninv_arr[0].w : a.ninv.w;
         }
         // both phases on ONE polynomial that fills the tile (one-tile rings, n1 = 32), in LDS
         template <typename T, int TLOG, bool INV>
@@ -1338,10 +1354,9 @@ namespace gpuntt
 
             // (the inverse row pass of the 4-step rings 2^14 .. 2^16 as its own fall-back: phase 2 of the generic algorithm)
             if constexpr (SKIP != 0 && INV && TLOG == 12)
-                if (self_fallback_call(a))
+                if (self_fallback_call<T, LIM>(a))
                 {
-                    const dev::ModCtx<T> em{a.q, a.q_bit, a.q_mu};
-                    fs_phase2_chunk<T, true, LTile<12>::NT>(a, blockIdx.x, a.n, em, a.ninv.w);
+                    fs_phase2_chunk<T, true, LTile<12>::NT>(a, blockIdx.x, a.n, fs_modulus(a), fs_ninv(a));
                     return;
                 }
             // RNS calls: the twiddle-prep kernel publishes which kernel family the stack of moduli needs (not_my_call);
@@ -1495,9 +1510,9 @@ namespace gpuntt
         __global__ __launch_bounds__(LTile<12>::NT, (LOcc<12, T>::WAVES)) void fourstep_first_lazy(LazyArgsT<T> a)
         {
             __shared__ T lds[LTile<12>::LDS_ELEMS];
-            if (self_fallback_call(a)) // phase 1 of the generic algorithm on 4096-word tile blockIdx.x (a.n2_log = log2 n1 here)
+            if (self_fallback_call<T, LIM>(a)) // phase 1 of the generic algorithm on 4096-word tile blockIdx.x (a.n2_log = log2 n1 here)
             {
-                const dev::ModCtx<T> em{a.q, a.q_bit, a.q_mu};
+                const dev::ModCtx<T> em = fs_modulus(a);
                 const unsigned tiles_log = static_cast<unsigned>(a.n - 12);
                 fs_phase1_tile<T, false, LTile<12>::NT>(a, lds, blockIdx.x >> tiles_log, blockIdx.x & ((1u << tiles_log) - 1u),
                                                          a.n2_log, a.n - a.n2_log, em);
@@ -1535,9 +1550,9 @@ namespace gpuntt
         __global__ __launch_bounds__(LTile<TLOG>::NT, (LOcc<TLOG, T>::WAVES)) void fourstep_inv_first_lazy(LazyArgsT<T> a)
         {
             __shared__ T lds[LTile<TLOG>::LDS_ELEMS_FST];
-            if (self_fallback_call(a)) // phase 1 of the generic algorithm on the 2^(TLOG - 12) 4096-word tiles of block blockIdx.x
+            if (self_fallback_call<T, LIM>(a)) // phase 1 of the generic algorithm on the 2^(TLOG - 12) 4096-word tiles of block blockIdx.x
             {
-                const dev::ModCtx<T> em{a.q, a.q_bit, a.q_mu};
+                const dev::ModCtx<T> em = fs_modulus(a);
                 const unsigned tiles_log = static_cast<unsigned>(a.n - TLOG);
                 const unsigned long long poly = blockIdx.x >> tiles_log;
                 const unsigned big = blockIdx.x & ((1u << tiles_log) - 1u);
@@ -1589,11 +1604,9 @@ namespace gpuntt
                 qm = md.mu;
             }
             if constexpr (!NAT)
-                if (self_fallback_call(a))
+                if (self_fallback_call<T, LIM>(a))
                 {
-                    const dev::ModCtx<T> em{qv, qb, qm};
-                    const T ninv = (a.ninv_arr != nullptr) ? a.ninv_arr[0].w : a.ninv.w;
-                    fourstep_tile_generic<T, TLOG, INV>(a, lds, blockIdx.x, em, ninv);
+                    fourstep_tile_generic<T, TLOG, INV>(a, lds, blockIdx.x, fs_modulus(a), fs_ninv(a));
                     return;
                 }
             if (not_my_call<T, LIM>(a.go_flag, a.flags))

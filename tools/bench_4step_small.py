@@ -38,8 +38,12 @@ def timed(fn, iters=200, warm=20):
 print("# u64; us per call; lib = %s" % os.path.basename(g.LIB_PATH))
 print("# logN batch dir  checked  unchecked  plan   checked/unchecked")
 SHAPES = ((12, 1), (12, 64), (13, 8), (14, 8), (14, 512), (16, 1), (16, 16), (18, 4), (20, 1), (20, 16), (22, 4), (24, 1), (24, 4))
-if len(sys.argv) > 1:  # e.g. 24:1 20:16
-    SHAPES = tuple(tuple(int(v) for v in a.split(":")) for a in sys.argv[1:])
+RNS = "--rns" in sys.argv  # the RNS overload with ONE device-side modulus (how the reference's examples call the entry point)
+ARGS = [a for a in sys.argv[1:] if a != "--rns"]
+if ARGS:  # e.g. 24:1 20:16
+    SHAPES = tuple(tuple(int(v) for v in a.split(":")) for a in ARGS)
+if RNS:
+    print("# RNS overload, one device-side modulus")
 for logn, batch in SHAPES:
     p4 = g.NTTParameters4Step(logn, 64)
     for inverse in (False, True):
@@ -49,6 +53,11 @@ for logn, batch in SHAPES:
         d_in = g.to_device(np.random.default_rng(logn).integers(0, p4.modulus.value, size=batch * p4.n, dtype=np.uint64))
         d_out = torch.zeros_like(d_in)
         call = lambda: g.GPU_4STEP_NTT(d_in, d_out, *tabs, p4.modulus, cfg, batch)  # noqa: E731
+        if RNS:
+            mods = g.modulus_array_to_device([p4.modulus], 64)
+            ninv = g.to_device(np.array([p4.n_inv], dtype=np.uint64))
+            rcfg = g.ntt4step_rns_configuration(n_power=logn, ntt_type=g.INVERSE if inverse else g.FORWARD, mod_inverse=ninv)
+            call = lambda: g.GPU_4STEP_NTT(d_in, d_out, *tabs, mods, rcfg, batch, 1)  # noqa: E731
         g.set_option("check_4step_tables", "1")
         t_c = timed(call, iters=100 if logn >= 22 else 200)
         g.set_option("check_4step_tables", "0")
