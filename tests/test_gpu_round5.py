@@ -742,3 +742,88 @@ def test_fourstep_table_check_inside_a_captured_graph(g):
             g.GPU_4STEP_NTT(oin, oout, *ot, other.modulus, g.ntt4step_configuration(n_power=14, stream=cfg_stream), 1)
         cfg_stream.synchronize()
     assert np.array_equal(result(), want)
+
+
+@pytest.mark.parametrize("logn,inverse", [(12, False), (13, True), (16, False), (16, True), (18, True)])
+def test_fourstep_rns_overload_captured_then_modulus_and_tables_rewritten(g, logn, inverse):
+    """GPU_4STEP_NTT through the RNS overload with ONE device-side modulus (the reference examples' calling style),
+    captured into a hipGraph while the host predicts the default kernel family: only that family is baked into the graph
+    and its kernels are their own fall-back (kern::F_SELF_FALLBACK).  The graph is replayed (a) as captured, (b) after the
+    device buffers -- modulus, n^-1 and all three tables -- were rewritten IN PLACE with those of a 61-bit prime (another
+    kernel family: nothing enqueued for it), (c) after one W word of those was corrupted, (d) with the original contents
+    again.  Every replay must return what the element-by-element kernels (path = generic, eager) compute from the same
+    buffers."""
+    import torch
+    from gpu_utils import find_ntt_factors
+    shape = g.NTTParameters4Step(logn, 64)
+    n, n1, n2, batch = shape.n, shape.n1, shape.n2, 3
+    kind = g.INVERSE if inverse else g.FORWARD
+
+    def tables_for(q, omega):
+        m = g.Modulus(q, bits=64)
+        r = pow(omega, -1, q) if inverse else omega
+        w = torch.zeros(n, dtype=torch.int64, device="cuda")
+        t1 = torch.zeros(n1 >> 1, dtype=torch.int64, device="cuda")
+        t2 = torch.zeros(n2 >> 1, dtype=torch.int64, device="cuda")
+        g.GPU_Generate4StepW(w, r, m, logn, kind)
+        g.GPU_GeneratePowerTable(t1, pow(r, n // n1, q), m, int(np.log2(n1)) - 1, True)
+        g.GPU_GeneratePowerTable(t2, pow(r, n // n2, q), m, int(np.log2(n2)) - 1, True)
+        torch.cuda.synchronize()
+        return m, t1, t2, w
+
+    qa, wa, _ = find_ntt_factors(60, logn)
+    qb, wb, _ = find_ntt_factors(61, logn)
+    ma, a1, a2, aw = tables_for(qa, wa)
+    mb, b1, b2, bw = tables_for(qb, wb)
+    t1, t2, w = a1.clone(), a2.clone(), aw.clone()
+    mods = g.modulus_array_to_device([ma], 64)
+    mods_b = g.modulus_array_to_device([mb], 64)
+    mods_a = mods.clone()
+    ninv = g.to_device(np.array([pow(n, -1, qa)], dtype=np.uint64))
+    ninv_a, ninv_b = ninv.clone(), g.to_device(np.array([pow(n, -1, qb)], dtype=np.uint64))
+    d_in = g.to_device(np.random.default_rng(700 + logn).integers(0, min(qa, qb), size=batch * n, dtype=np.uint64))
+    d_out = torch.zeros_like(d_in)
+
+    def cfg(stream=None):
+        return g.ntt4step_rns_configuration(n_power=logn, ntt_type=kind, mod_inverse=ninv, stream=stream)
+
+    for _ in range(3):  # the prediction settles on the default family
+        g.GPU_4STEP_NTT(d_in, d_out, t1, t2, w, mods, cfg(), batch, 1)
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=s):
+        g.GPU_4STEP_NTT(d_in, d_out, t1, t2, w, mods, cfg(torch.cuda.current_stream()), batch, 1)
+
+    def replay():
+        d_out.fill_(-9)
+        graph.replay()
+        torch.cuda.synchronize()
+        return g.to_host(d_out).copy()
+
+    def generic():
+        g.set_option("path", "generic")
+        try:
+            ref = torch.zeros_like(d_in)
+            g.GPU_4STEP_NTT(d_in, ref, t1, t2, w, mods, cfg(), batch, 1)
+            torch.cuda.synchronize()
+            return g.to_host(ref).copy()
+        finally:
+            g.set_option("path", os.environ.get("GPUNTT_PATH", "default"))
+
+    def install(m_dev, nv, x1, x2, xw):
+        mods.copy_(m_dev); ninv.copy_(nv); t1.copy_(x1); t2.copy_(x2); w.copy_(xw)
+        torch.cuda.synchronize()
+
+    want_a = generic()
+    assert np.array_equal(replay(), want_a), "as captured"
+    install(mods_b, ninv_b, b1, b2, bw)
+    want_b = generic()
+    assert not np.array_equal(want_b, want_a)
+    assert np.array_equal(replay(), want_b), "61-bit modulus written over the captured buffers"
+    w[n // 2 + 3] ^= 1
+    torch.cuda.synchronize()
+    want_c = generic()
+    assert np.array_equal(replay(), want_c), "61-bit modulus, one W word corrupted"
+    install(mods_a, ninv_a, a1, a2, aw)
+    assert np.array_equal(replay(), want_a), "original contents again"
