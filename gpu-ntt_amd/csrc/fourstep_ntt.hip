@@ -408,6 +408,40 @@ namespace gpuntt
                     if constexpr (sizeof(T) == 4)
                         if (mods_dev == nullptr && host::lazy_lim31_enabled() && host::lazy_wide_modulus32(mod.value))
                             r.lim = 8;
+                    {
+                        // rings 2^14 .. 2^17: ONE contiguous pass is left and the n2-long rows of `out` fit its tiles -- the
+                        // pass runs as an instantiation of its own that does the n2-point phase of the element-by-element
+                        // algorithm when the call is not the fast kernels' (launch_fourstep_fwd_last_lazy): nothing behind
+                        const int pn = n_power - k1;
+                        const host::Plan rp = host::make_plan_tl(pn, tlf, tlf == 12 ? host::lazy_contig_k(pn) : tlf);
+                        if (self_ok && go_flag != nullptr && tlf == 12 && rp.count == 1 && (pn == 9 || pn == 11) && log_n2 <= 12)
+                        {
+                            kern::LazyArgsT<T> a = r; // what run_transform_lazy hands that pass
+                            a.p_lo = 0;
+                            a.batch = 0;
+                            a.flags |= kern::F_SELF_FALLBACK;
+                            if constexpr (sizeof(T) == 8)
+                            {
+                                if (r.lim == 8)
+                                    host::launch_fourstep_fwd_last_lazy<T, 8>(pn, a, stream);
+                                else if (r.lim == 4)
+                                    host::launch_fourstep_fwd_last_lazy<T, 4>(pn, a, stream);
+                                else if (r.lim == 31)
+                                    host::launch_fourstep_fwd_last_lazy<T, 31>(pn, a, stream);
+                                else
+                                    host::launch_fourstep_fwd_last_lazy<T, 0>(pn, a, stream);
+                            }
+                            else
+                            {
+                                if (r.lim == 8)
+                                    host::launch_fourstep_fwd_last_lazy<T, 8>(pn, a, stream);
+                                else
+                                    host::launch_fourstep_fwd_last_lazy<T, 0>(pn, a, stream);
+                            }
+                            *self_fallback = 2;
+                            return true;
+                        }
+                    }
                     host::run_transform_lazy<T, false>(r, 0u, 0u, stream, tlf, n_power - k1);
                     return true;
                 }

@@ -170,6 +170,15 @@ namespace gpuntt
         extern template void launch_fourstep_small_lazy<uint64_t, true>(int, int, const kern::LazyArgsT<uint64_t>&, hipStream_t, bool);
         extern template void launch_fourstep_small_lazy<uint32_t, false>(int, int, const kern::LazyArgsT<uint32_t>&, hipStream_t, bool);
         extern template void launch_fourstep_small_lazy<uint32_t, true>(int, int, const kern::LazyArgsT<uint32_t>&, hipStream_t, bool);
+        // forward 4-step, rings 2^14 .. 2^17: the single contiguous pass behind the first kernel, able to be its own fall-back
+        // (lazy_launch_impl.hpp); LIMSEL 0 / 31 / 8 / 4 (64-bit), 0 / 8 (32-bit)
+        template <typename T, int LIMSEL> void launch_fourstep_fwd_last_lazy(int k, const kern::LazyArgsT<T>& a, hipStream_t stream);
+        extern template void launch_fourstep_fwd_last_lazy<uint64_t, 0>(int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
+        extern template void launch_fourstep_fwd_last_lazy<uint64_t, 31>(int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
+        extern template void launch_fourstep_fwd_last_lazy<uint64_t, 8>(int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
+        extern template void launch_fourstep_fwd_last_lazy<uint64_t, 4>(int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
+        extern template void launch_fourstep_fwd_last_lazy<uint32_t, 0>(int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
+        extern template void launch_fourstep_fwd_last_lazy<uint32_t, 8>(int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
         // forward 4-step, first pass of the ring's Merge plan reading the transposed input (kern::fourstep_first_lazy):
         // k = 5 .. 8 stages, k >= log2 n1 = a.n2_log
         template <typename T, int LIMSEL = 0>

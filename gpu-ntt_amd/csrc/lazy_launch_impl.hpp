@@ -339,6 +339,31 @@ namespace gpuntt
             GPUNTT_HIP_CHECK(hipGetLastError());
         }
 
+        // forward 4-step, rings 2^14 .. 2^17 (n2 <= 4096): the ONE contiguous pass behind the gathering first kernel as
+        // instantiations of its own (SKIP = 1: a marker, merge_lazy_kernels.hpp) -- exactly the kernel run_transform_lazy
+        // would launch for that pass, plus the n2-point phase of the element-by-element algorithm for vetoed calls
+        // (kern::F_SELF_FALLBACK): nothing is enqueued behind such a call.  k = stages of the pass (9 or 11)
+        template <typename T, int LIMSEL>
+        void launch_fourstep_fwd_last_lazy(int k, const kern::LazyArgsT<T>& a, hipStream_t stream)
+        {
+            constexpr int LIM = lazy::Mod<T, LIMSEL>::LIMIT;
+            const unsigned long long tiles = a.total >> 12;
+            if (tiles == 0)
+                return;
+            if (tiles > 0x7fffffffull)
+                throw std::invalid_argument("batch_size * N too large for one launch");
+            const unsigned grid = lazy_grid_cap<T, LIMSEL>(tiles, a.go_flag);
+            if (k == 9)
+                hipLaunchKernelGGL((kern::merge_pass_lazy<T, 12, false, true, 9, LIM, true, LIMSEL, 1>), dim3(grid),
+                                   dim3(kern::LTile<12>::NT), 0, stream, a);
+            else if (k == 11)
+                hipLaunchKernelGGL((kern::merge_pass_lazy<T, 12, false, true, 11, LIM, true, LIMSEL, 1>), dim3(grid),
+                                   dim3(kern::LTile<12>::NT), 0, stream, a);
+            else
+                throw std::invalid_argument("internal: bad forward 4-step last pass");
+            GPUNTT_HIP_CHECK(hipGetLastError());
+        }
+
         // 4-step transform of a ring that fits one tile: the whole transform in one launch (fourstep_small_lazy);
         // natural: the natural-order extension (spectrum side in NTT_4STEP_CPU order)
         template <typename T, bool INV, bool NAT>

@@ -13,4 +13,5 @@ void launch_pass_lazy_u32w<false>(const Pass& p, int tile_log, bool in_first, bo
         return dispatch_tl<uint32_t, 13, false, 8>(p, in_first, last, a, stream);
     throw std::invalid_argument("internal: unsupported tile size in the fast path");
 }
+template void launch_fourstep_fwd_last_lazy<uint32_t, 8>(int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
 } }

@@ -5,4 +5,5 @@ template void launch_pass_lazy<uint64_t, false>(const Pass&, int, bool, bool, co
 template void launch_fourstep_small_lazy<uint64_t, false>(int, int, const kern::LazyArgsT<uint64_t>&, hipStream_t, bool);
 template void launch_fourstep_first_lazy<uint64_t>(int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
 template void launch_fourstep_nat_last_lazy<uint64_t, 0>(int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
+template void launch_fourstep_fwd_last_lazy<uint64_t, 0>(int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
 } }

@@ -12,4 +12,5 @@ void launch_pass_lazy31(const Pass& p, int tile_log, bool in_first, bool last, c
         return dispatch_tl<uint64_t, 14, false, 31>(p, in_first, last, a, stream);
     throw std::invalid_argument("internal: unsupported tile size in the fast path");
 }
+template void launch_fourstep_fwd_last_lazy<uint64_t, 31>(int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
 } }

@@ -4,4 +4,5 @@ namespace gpuntt { namespace host {
 template void launch_pass_lazy_lim<false, 4>(const Pass&, bool, bool, const kern::LazyArgsT<uint64_t>&, hipStream_t);
 template void launch_fourstep_lim<false, 4>(int, int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
 template void launch_fourstep_nat_last_lazy<uint64_t, 4>(int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
+template void launch_fourstep_fwd_last_lazy<uint64_t, 4>(int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
 } }

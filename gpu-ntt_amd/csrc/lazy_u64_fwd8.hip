@@ -3,4 +3,5 @@
 namespace gpuntt { namespace host {
 template void launch_pass_lazy_lim<false, 8>(const Pass&, bool, bool, const kern::LazyArgsT<uint64_t>&, hipStream_t);
 template void launch_fourstep_lim<false, 8>(int, int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
+template void launch_fourstep_fwd_last_lazy<uint64_t, 8>(int, const kern::LazyArgsT<uint64_t>&, hipStream_t);
 } }

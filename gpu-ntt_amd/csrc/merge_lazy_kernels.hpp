@@ -1347,16 +1347,24 @@ namespace gpuntt
         __global__ __launch_bounds__(LTile<TLOG>::NT, (LOcc<TLOG, T>::WAVES)) void merge_pass_lazy(LazyArgsT<T> a)
         {
             using M = lazy::Mod<T, LIM>;
-            using SCH = PassSched<TLOG, INV, CONTIG, K, IN_BOUND, M::LIMIT, M::TB, SKIP>;
+            // forward kernels: SKIP != 0 is only a MARKER -- the last pass of a forward 4-step whose n2-long rows fit one tile
+            // (host::launch_fourstep_fwd_last_lazy), instantiations of their own that can carry the fall-back below
+            constexpr int SK = INV ? SKIP : 0;
+            using SCH = PassSched<TLOG, INV, CONTIG, K, IN_BOUND, M::LIMIT, M::TB, SK>;
             // single-round passes with coalesced register windows never touch LDS
             constexpr bool NEEDS_LDS = (SCH::NR > 1) || (SCH::wl_of(0) < 4);
             __shared__ T lds[NEEDS_LDS ? LTile<TLOG>::LDS_ELEMS : 1];
 
-            // (the inverse row pass of the 4-step rings 2^14 .. 2^16 as its own fall-back: phase 2 of the generic algorithm)
-            if constexpr (SKIP != 0 && INV && TLOG == 12)
+            // (the inverse row pass of the 4-step rings 2^14 .. 2^16 and the forward last pass of 2^14 .. 2^17 as their own
+            // fall-back: phase 2 of the generic algorithm on the block's 4096 words; inverse: a.n = log2 n2, forward: a.n =
+            // log2 N and a.n2_log = log2 n1)
+            if constexpr (SKIP != 0 && TLOG == 12 && CONTIG)
                 if (self_fallback_call<T, LIM>(a))
                 {
-                    fs_phase2_chunk<T, true, LTile<12>::NT>(a, blockIdx.x, a.n, fs_modulus(a), fs_ninv(a));
+                    if constexpr (INV)
+                        fs_phase2_chunk<T, true, LTile<12>::NT>(a, blockIdx.x, a.n, fs_modulus(a), fs_ninv(a));
+                    else
+                        fs_phase2_chunk<T, false, LTile<12>::NT>(a, blockIdx.x, a.n - a.n2_log, fs_modulus(a), T(0));
                     return;
                 }
             // RNS calls: the twiddle-prep kernel publishes which kernel family the stack of moduli needs (not_my_call);
@@ -1399,7 +1407,7 @@ namespace gpuntt
                 qb = md.bit;
                 qm = md.mu;
             }
-            pass_body<T, TLOG, INV, CONTIG, K, IN_BOUND, LAST, Fst::none, LIM, Xp::none, SKIP>(a, lds, qv, qb, qm, mi, 0, 0, blk);
+            pass_body<T, TLOG, INV, CONTIG, K, IN_BOUND, LAST, Fst::none, LIM, Xp::none, SK>(a, lds, qv, qb, qm, mi, 0, 0, blk);
                 });
         }
 

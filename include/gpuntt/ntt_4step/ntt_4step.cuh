@@ -30,8 +30,8 @@
 //   synchronisation -- and tables that are anything else (the reference's timing program passes random words with n1 / n2
 //   swapped, benchmark/bench_4step_ntt.cu:80-90) hand the call, on the device, to the element-by-element algorithm: bit
 //   for bit what the tables say.  (Who runs it: the fast kernels themselves as far as their blocks can -- all of it for
-//   rings up to 2^13, large 2^14 batches and the inverses up to 2^16, the n1-point phase for every ring -- and the
-//   element-by-element Barrett kernels enqueued behind the call for the rest.)  A FourStepPlan checks once, in its constructor
+//   rings up to 2^16 and forward 2^17, the n1-point phase for every ring -- and the element-by-element Barrett kernels
+//   enqueued behind the call for the rest.)  A FourStepPlan checks once, in its constructor
 //   (fast_path() tells).  GPU_NTT_SetOption("check_4step_tables", "0") opts out for callers that guarantee the layout
 //   above (no check, no generic launches behind the call).
 #pragma once
