@@ -100,7 +100,7 @@ EXPORTED_SYMBOLS = ["gpuntt_last_error", "gpuntt_version"] + [
 
 # GPUNTT_* environment variables of the A/B scripts and tests -> library options.  The C++ library reads no
 # environment variable; this harness forwards them once, when it loads the library.
-ENV_OPTIONS = {"GPUNTT_PATH": ("path", None)}
+ENV_OPTIONS = {"GPUNTT_PATH": ("path", None), "GPUNTT_U32_E32": ("u32_e32", lambda v: int(v, 0))}
 
 
 def set_option(name, value):

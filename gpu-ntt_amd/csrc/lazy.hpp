@@ -269,7 +269,11 @@ namespace gpuntt
         // accumulator a 32-bit multiply-add chain starts from
         __device__ __forceinline__ uint64_t pair_lo(uint32_t lo)
         {
-            const uint32_t hi = __builtin_nondeterministic_value(lo);
+            // (an empty asm per use: every pair gets a high half of its OWN that no instruction writes --
+            // __builtin_nondeterministic_value is ONE frozen value per function, which the compiler then copies into the
+            // odd register of every pair: 99 v_mov per wave in the single-sweep 32-bit kernel, round 5)
+            uint32_t hi;
+            asm("" : "=v"(hi) : "v"(lo));
             return (static_cast<uint64_t>(hi) << 32) | lo;
         }
 

@@ -1,0 +1,34 @@
+// lazy_e32.hip -- instantiates the 32-coefficients-per-lane single-sweep kernels of the 32-bit rings 2^12 .. 2^15.
+#include "lazy_launch.hpp"
+#include "merge_e32_kernels.hpp"
+namespace gpuntt { namespace host {
+template <bool INV> void launch_ring_e32(int n, int lim, const kern::LazyArgsT<uint32_t>& a, hipStream_t stream)
+{
+    const unsigned long long polys = a.total >> n;
+    if (polys == 0)
+        return;
+    if (polys > 0x7fffffffull)
+        throw std::invalid_argument("batch_size * N too large for one launch");
+    const dim3 grid(static_cast<unsigned>(polys));
+#define GPUNTT_E32(TL_)                                                                                                  \
+    case TL_:                                                                                                            \
+        if (lim == 8)                                                                                                    \
+            hipLaunchKernelGGL((kern::merge_ring_e32<TL_, INV, 8>), grid, dim3(kern::ETile<TL_>::NT), 0, stream, a);     \
+        else                                                                                                             \
+            hipLaunchKernelGGL((kern::merge_ring_e32<TL_, INV, 0>), grid, dim3(kern::ETile<TL_>::NT), 0, stream, a);     \
+        break;
+    switch (n)
+    {
+        GPUNTT_E32(12)
+        GPUNTT_E32(13)
+        GPUNTT_E32(14)
+        GPUNTT_E32(15)
+        default:
+            throw std::invalid_argument("internal: no 32-coefficients-per-lane kernel for this ring");
+    }
+#undef GPUNTT_E32
+    GPUNTT_HIP_CHECK(hipGetLastError());
+}
+template void launch_ring_e32<false>(int, int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
+template void launch_ring_e32<true>(int, int, const kern::LazyArgsT<uint32_t>&, hipStream_t);
+} }

@@ -78,6 +78,19 @@ namespace gpuntt
             return (n >= 20 && n <= 22) ? 14 : 12;
         }
 
+        // The 32-coefficients-per-lane geometry of the 32-bit single-sweep rings (merge_e32_kernels.hpp, lazy_e32.hip): bit n
+        // of the mask set = Merge transforms of the ring 2^n run on it (option u32_e32; rings 2^12 .. 2^15).  The ring 2^15
+        // then takes ONE sweep on a 32768-coefficient tile instead of two on 4096-coefficient ones; 4-step plans keep
+        // lazy_tile_log.  The prepared table of a tile is the same for both geometries.
+        unsigned lazy_e32_mask();
+        template <bool INV> void launch_ring_e32(int n, int lim, const kern::LazyArgsT<uint32_t>& a, hipStream_t stream);
+        template <typename T> inline int lazy_tile_log_merge(int n, bool inverse = false, unsigned long long polys = 0)
+        {
+            if (sizeof(T) == 4 && n == 15 && ((lazy_e32_mask() >> 15) & 1u) != 0u)
+                return 15;
+            return lazy_tile_log<T>(n, inverse, polys);
+        }
+
         // Library-owned scratch for the prepared twiddles of the drop-in calls: one chain of buffers per (device, stream)
         // for eager calls, one per (device, stream, capture) for calls made while the stream is being captured into a
         // hipGraph; stream-ordered reuse inside a chain.  A buffer is never freed or synchronised on before
@@ -502,9 +515,20 @@ namespace gpuntt
         {
             const int tl = (sizeof(T) == 8 && base.lim && base.lim != 31)
                                ? 12
-                               : (forced_tl ? forced_tl : lazy_tile_log<T>(base.n, INV, base.total >> base.n));
+                               : (forced_tl ? forced_tl : lazy_tile_log_merge<T>(base.n, INV, base.total >> base.n));
             const int pn = (!INV && low_stages > 0) ? low_stages : base.n;
             const bool partial = pn != base.n;
+            // 32-bit rings that fill their tile: the 32-coefficients-per-lane kernels (one polynomial per block).  A table
+            // laid out for the 32768-coefficient tile has no other kernel; GPU_PolyMul's fused product keeps the old ones
+            if constexpr (sizeof(T) == 4)
+                if (!partial && base.n == tl && tl >= 12 && tl <= 15 && base.mul_in == nullptr &&
+                    (tl == 15 || ((lazy_e32_mask() >> tl) & 1u) != 0u) && (base.total & ((1ull << tl) - 1ull)) == 0ull)
+                {
+                    kern::LazyArgsT<uint32_t> a = base;
+                    a.p_lo = 0;
+                    a.flags |= first_in_flags | last_out_flags;
+                    return launch_ring_e32<INV>(tl, base.lim, a, stream);
+                }
             // RNS stack of rings below one tile: the tile holds polynomials of different moduli.  From 1024 coefficients a
             // wave lies in one polynomial and the ordinary kernels pick the modulus per wave (merge_pass_lazy); rings of
             // 16 .. 512 coefficients take the per-lane-modulus form of the same pass

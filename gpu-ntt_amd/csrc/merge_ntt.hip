@@ -143,7 +143,7 @@ namespace gpuntt
             const bool neg = (poly == ReductionPolynomial::X_N_plus);
             int lim = (mods == nullptr) ? needs_lim<TU>(m) : 0;
             const bool inverse = ninv_dev != nullptr || ninv_single != nullptr;
-            const int tl = lim ? 12 : host::lazy_tile_log<TU>(n_power, inverse, static_cast<unsigned long long>(batch_size));
+            const int tl = lim ? 12 : host::lazy_tile_log_merge<TU>(n_power, inverse, static_cast<unsigned long long>(batch_size));
             // forward, host-side modulus with 31 q < 2^64: the LIMIT = 31 kernels
             if constexpr (sizeof(TU) == 8)
                 if (lim == 0 && mods == nullptr && !inverse && host::lazy_lim31_enabled() &&
@@ -1030,7 +1030,7 @@ namespace gpuntt
                     fast = false;
             }
             p->fast = fast;
-            p->tile_log = p->lim ? 12 : host::lazy_tile_log<T>(n_power, inverse, static_cast<unsigned long long>(batch_hint));
+            p->tile_log = p->lim ? 12 : host::lazy_tile_log_merge<T>(n_power, inverse, static_cast<unsigned long long>(batch_hint));
             if constexpr (sizeof(T) == 8)
             {
                 // forward plans whose every modulus has 31 q < 2^64: the LIMIT = 31 kernels

@@ -898,6 +898,7 @@ namespace gpuntt
                 std::atomic<int> check_4step{1}; // 4-step entry points: verify the caller's three tables on the device (prep_merge_from_fourstep)
                 std::atomic<int> rns_predict{1}; // drop-in RNS calls: enqueue only the lazy family the stack needed last time
                 std::atomic<int> rns_force_fallback{0}; // test hook: the preparation kernel's own fall-back serves every drop-in RNS Merge call
+                std::atomic<int> u32_e32{0xf000}; // 32-bit Merge rings served by the 32-coefficients-per-lane kernels (bit n = ring 2^n)
             } g_opt;
         } // namespace
 
@@ -938,11 +939,18 @@ namespace gpuntt
                                                                     : g_opt.rns_predict;
                 dst = iv;
             }
+            else if (k == "u32_e32")
+            {
+                if (!is_num || lv < 0 || (lv & ~0xf000L) != 0)
+                    return false; // a mask over the rings 2^12 .. 2^15
+                g_opt.u32_e32 = iv;
+            }
             else
                 return false;
             return true;
         }
 
+        unsigned lazy_e32_mask() { return static_cast<unsigned>(g_opt.u32_e32.load(std::memory_order_relaxed)); }
         int forced_path() { return g_opt.path.load(std::memory_order_relaxed); }
         static bool rns_predict_enabled() { return g_opt.rns_predict.load(std::memory_order_relaxed) != 0; }
         static bool rns_force_fallback() { return g_opt.rns_force_fallback.load(std::memory_order_relaxed) != 0; }
