@@ -91,7 +91,7 @@ def _timed_cpu(run_one, polys_total, threads, seconds):
     return done / (time.perf_counter() - t0)
 
 
-def cpu_baseline(cfg, case, y_gpu_sample):
+def cpu_baseline(cfg, case, y_gpu_sample, check_only=False):
     """The CPU leg (the only place bench.py touches oracle/): the reference's own CPU transform
     (oracle/_ref, kind 'reference'; this repo's C restatement, kind 'port', when the prebuilt file is absent)
     timed on a bounded sample of the same workload on this host, once on one thread and once on every host
@@ -113,6 +113,8 @@ def cpu_baseline(cfg, case, y_gpu_sample):
         ok = np.array_equal(y, y_gpu_sample[:n])
         if not ok:
             raise SystemExit("bench: GPU result differs from the CPU reference path")
+        if check_only:
+            return {"gpu_output_bit_exact": True, "kind": kind, "polynomials": 1}
         return {"value": 1.0 / dt, "unit": "NTT/s", "cores": 1, "kind": kind, "gpu_output_bit_exact": True,
                 "sample": "one forward NTT_4STEP_CPU::ntt of N=2^%d on one host core, %.1f s" % (logn, dt)}
     poly = O.X_N_minus if cfg["poly"] == "minus" else O.X_N_plus
@@ -131,6 +133,8 @@ def cpu_baseline(cfg, case, y_gpu_sample):
     y = np.concatenate(run_one(0, polys))
     if not np.array_equal(y, y_gpu_sample):
         raise SystemExit("bench: GPU result differs from the CPU reference path")
+    if check_only:
+        return {"gpu_output_bit_exact": True, "kind": kind, "polynomials": polys}
     v1 = _timed_cpu(run_one, polys, 1, CPU_SECONDS)
     how = "batch-parallel ctypes calls from a thread pool"
     if threads > 1 and cfg["kind"] != "rns" and hasattr(B, "merge_ntt_mt"):
@@ -440,6 +444,7 @@ def build_case(g, cfg, rank, world, dev, api, inplace=True):
             case["plan"][0].execute(d_in, d_mid, batch)
             case["plan"][1].execute(d_mid, d_back, batch)
         step, other_step = (plan_step, dropin_step) if api == "plan" else (dropin_step, plan_step)
+        case.update(tables_fwd=tf, tables_inv=ti, cfg_fwd=cf, cfg_inv=ci)
         case.update(step=step, x=base, other_step=lambda: other_step, d_in=d_in, d_out=d_mid, d_back=d_back, distinct=distinct,
                     table=tf[2], modulus=p4.modulus.value, transforms_per_step=2 * batch, p4=p4, run_shard=None)
     return case
@@ -526,6 +531,175 @@ def c4_shard_overheads(g, cfg, dev, shard_batch=1024):
     except Exception as e:  # informational
         out["plan_hipgraph"] = {"error": repr(e)}
     plan.close()
+    return out
+
+
+# ------------------------------------------------------------------ the other BASELINE configs
+# What the default run (C2 forward, the headline) times BESIDE its line, so that one driver-owned run witnesses every
+# BASELINE.json config: (key, config, direction, steps, warmup).  Same HIP-event bracket on the launch stream, same
+# bit-exact check against the reference CPU build, PMC traffic from two child passes over all of them.
+OTHER_CONFIGS = (("c2_inv", "c2", "inv", 20, 5), ("c5", "c5", "fwd", 20, 5), ("c5_inv", "c5", "inv", 20, 5),
+                 ("c4", "c4", "fwd", 40, 10), ("c4_inv", "c4", "inv", 40, 10), ("c3", "c3", "fwd", 4, 1))
+OTHER_CHILD_CALLS = 3
+
+
+def _other_cfg(name, direction):
+    cfg = dict(CONFIGS[name], name=name, direction=direction)
+    return cfg, (cfg["kind"] != "4step")
+
+
+def other_configs_child(g, dev):
+    """PMC child pass (`--child --other-configs`): every OTHER_CONFIGS entry, OTHER_CHILD_CALLS calls each, between two
+    mark kernels -- the dispatches before the second mark (case set-up, the first out-of-place call) are not counted."""
+    import torch
+    mark = torch.empty(1, dtype=torch.float64, device=dev)
+    for k, (_, name, direction, _, _) in enumerate(OTHER_CONFIGS):
+        cfg, inplace = _other_cfg(name, direction)
+        case = build_case(g, cfg, 0, 1, dev, "dropin", inplace)
+        mark.fill_(float(2 * k))
+        case.get("first", case["step"])()
+        torch.cuda.synchronize()
+        mark.fill_(float(2 * k + 1))
+        for _ in range(OTHER_CHILD_CALLS):
+            case["step"]()
+        torch.cuda.synchronize()
+        del case
+        torch.cuda.empty_cache()
+
+
+def other_configs_traffic():
+    """HBM bytes per call of every OTHER_CONFIGS entry: two rocprofv3 --pmc child passes (FETCH_SIZE x2 on gfx950,
+    WRITE_SIZE -- separate passes, MI355X_MICROARCH.md) of `bench.py --child --other-configs`."""
+    import glob
+    import shutil
+    import sqlite3
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="gpuntt_other_pmc_", dir="/tmp")
+    per = [0.0] * len(OTHER_CONFIGS)
+    try:
+        for counter, corr in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
+            out = os.path.join(tmp, counter)
+            cmd = [rocprof, "--pmc", counter, "-d", out, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
+                   "--child", "--other-configs"]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True,
+                               timeout=600)
+            dbs = glob.glob(out + "/**/*.db", recursive=True)
+            if r.returncode != 0 or not dbs:
+                return None, "rocprofv3 --pmc %s failed: %s" % (counter, (r.stderr or r.stdout)[-300:])
+            c = sqlite3.connect(dbs[0])
+            names = [x[0] for x in c.execute("select name from sqlite_master where type='table'")]
+            t = lambda p: [n for n in names if n.startswith(p)][0]  # noqa: E731
+            q = (f"select s.kernel_name, d.start, sum(p.value) from {t('rocpd_pmc_event')} p "
+                 f"join {t('rocpd_info_pmc')} i on p.pmc_id=i.id "
+                 f"join {t('rocpd_kernel_dispatch')} d on p.event_id=d.event_id "
+                 f"join {t('rocpd_info_kernel_symbol')} s on d.kernel_id=s.id "
+                 f"where i.name='{counter}' group by d.id order by d.start")
+            idx = -1
+            for name, _start, kb in c.execute(q):
+                if SWEEP_MARK in name:
+                    idx += 1
+                elif "gpuntt" in name and idx >= 0 and idx % 2 == 1 and idx // 2 < len(per):
+                    per[idx // 2] += kb * 1024.0 * corr / OTHER_CHILD_CALLS
+            if idx != 2 * len(OTHER_CONFIGS) - 1:
+                return None, "marks in the %s pass: %d, expected %d" % (counter, idx + 1, 2 * len(OTHER_CONFIGS))
+        return per, {"method": "rocprofv3 --pmc, two child passes over all the other configs, this run",
+                     "fetch_correction": 2.0, "calls_profiled_per_config": OTHER_CHILD_CALLS}
+    except Exception as e:
+        return None, "traffic measurement failed: %r" % (e,)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def _time_calls(step, steps, warmup):
+    """K calls between two HIP events on the launch stream, after a clock settle and W warm-up calls -> ms per call"""
+    import torch
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.1:
+        step()
+        torch.cuda.synchronize()
+    for _ in range(warmup):
+        step()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(steps):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / steps
+
+
+def run_other_configs(g, dev, args):
+    """Every BASELINE config the headline does not time (and the inverse directions), on this GPU, in this run: ms per
+    call (HIP events), fraction of the 8 TB/s peak on algorithmic bytes, PMC traffic over algorithmic bytes, and the
+    GPU output checked bit for bit against the reference CPU build (the same checker as `cpu_baseline`)."""
+    import torch
+    t_start = time.perf_counter()
+    out = {}
+    for key, name, direction, steps, warmup in OTHER_CONFIGS:
+        try:
+            cfg, inplace = _other_cfg(name, direction)
+            case = build_case(g, cfg, 0, 1, dev, "dropin", inplace)
+            case.get("first", case["step"])()
+            torch.cuda.synchronize()
+            n, bits = case["n"], cfg["bits"]
+            polys = min(16, case["batch"])
+            if cfg["kind"] == "rns":
+                polys = max(cfg["mod_count"], polys - polys % cfg["mod_count"])
+            y_first = gpu_sample_for_check(g, cfg, case, polys)
+            ms = _time_calls(case["step"], steps, warmup)
+            per_step = case["transforms_per_step"]
+            alg = 2 * n * (bits // 8) * per_step
+            ent = {"workload": cfg["workload"], "ms_per_call": ms, "steps": steps, "warmup": warmup,
+                   "transforms_per_call": per_step, "value_ntt_per_s": per_step / (ms * 1e-3),
+                   "algorithmic_bytes_per_call": alg, "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                   "in_place": inplace, "api": "dropin"}
+            if cfg["kind"] != "4step":
+                case["x_sample"] = case["x"][:polys * n]
+            else:
+                p4 = case["p4"]
+                case["x_sample"] = np.ascontiguousarray(case["x"][:n].reshape(p4.n2, p4.n1).T).reshape(-1)
+                # the two calls of the pair on their own (same buffers)
+                fwd_only = lambda: g.GPU_4STEP_NTT(case["d_in"], case["d_out"], *case["tables_fwd"], p4.modulus, case["cfg_fwd"], case["batch"])  # noqa: E731
+                inv_only = lambda: g.GPU_4STEP_NTT(case["d_out"], case["d_back"], *case["tables_inv"], p4.modulus, case["cfg_inv"], case["batch"])  # noqa: E731
+                ent["forward_call_ms"] = _time_calls(fwd_only, steps, 1)
+                ent["inverse_call_ms"] = _time_calls(inv_only, steps, 1)
+            if not args.no_cpu_baseline:
+                chk = cpu_baseline(cfg, case, y_first, check_only=True)
+                ent["bit_exact"] = bool(chk["gpu_output_bit_exact"])
+                ent["checked"] = "%d polynomial(s) against the %s CPU transform" % (chk["polynomials"], chk["kind"])
+                if cfg["kind"] == "4step":
+                    if not np.array_equal(y_first, gpu_sample_for_check(g, cfg, case, 1)):
+                        raise RuntimeError("the timed 4-step calls left a different result in their output buffer")
+                    ent["batch_check"] = fourstep_buffers_check(case)
+                    ent["bit_exact"] = ent["bit_exact"] and ent["batch_check"]["forward_copies_identical"] and \
+                        ent["batch_check"]["inverse_returns_input"]
+            out[key] = ent
+            del case
+            torch.cuda.empty_cache()
+        except SystemExit as e:  # a failed bit-exact check must be visible, not fatal to the headline
+            out[key] = {"error": str(e), "bit_exact": False}
+        except Exception as e:
+            out[key] = {"error": repr(e)}
+    try:
+        sh = c4_shard_overheads(g, dict(CONFIGS["c4"]), dev)
+        out["c4_shard_of_8"] = {"workload": "Merge-NTT Data32 log2N=14, one GPU's 1024-polynomial shard of the 8-way sharded batch",
+                                "dropin_us": sh["dropin"]["device_us"], "plan_us": sh["plan"]["device_us"],
+                                "plan_hipgraph_us": sh.get("plan_hipgraph", {}).get("device_us"),
+                                "ideal_us_from_whole_batch": (out.get("c4", {}).get("ms_per_call") or 0.0) * 1e3 / 8.0}
+    except Exception as e:
+        out["c4_shard_of_8"] = {"error": repr(e)}
+    if not args.no_traffic:
+        per, info = other_configs_traffic()
+        if per is not None:
+            for (key, *_), b in zip(OTHER_CONFIGS, per):
+                if key in out and "algorithmic_bytes_per_call" in out[key]:
+                    out[key]["traffic"] = b
+                    out[key]["traffic_over_algorithmic"] = b / out[key]["algorithmic_bytes_per_call"]
+        out["traffic_info"] = info
+    out["seconds"] = time.perf_counter() - t_start
     return out
 
 
@@ -804,6 +978,9 @@ def main():
                          "(reference benchmark/bench_merge_ntt.cu:137-141 times both); c3 is a forward + inverse pair")
     ap.add_argument("--cpu-polys", type=int, default=64)
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)  # PMC child pass: calls only
+    ap.add_argument("--other-configs", action="store_true", help=argparse.SUPPRESS)  # with --child: the other configs' pass
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="default run (c2 forward, 1 GPU): do not time the other BASELINE configs beside the headline")
     ap.add_argument("--sweep", action="store_true",
                     help="log2N sweep (Merge and 4-Step, forward), one JSON line per ring size with PMC bytes and the CPU column")
     ap.add_argument("--sweep-kinds", default="merge,4step")
@@ -844,6 +1021,9 @@ def main():
     dist, rank, world = dist_mod.init_process_group(backend, dev)
     global REDUCE_DEV
     REDUCE_DEV = dev if backend == "nccl" else "cpu"
+    if args.child and args.other_configs:
+        other_configs_child(g, dev)
+        return
     if args.sweep:
         run_sweep(g, args, dist_mod, dist, rank, world, dev)
         if dist is not None:
@@ -1008,6 +1188,13 @@ def main():
                         raise SystemExit("bench: 4-step batch check failed: %r" % (chk,))
                     line["cpu_baseline"]["checked_buffer"] = "polynomial 0 of the buffer the timed GPU_4STEP_NTT calls wrote"
                     line["batch_check"] = chk
+            if (args.config == "c2" and args.direction == "fwd" and args.api == "dropin" and world == 1
+                    and not args.out_of_place and not args.no_other_configs):
+                # (after everything the headline needs: nothing here can change `value`)
+                try:
+                    line["other_configs"] = run_other_configs(g, dev, args)
+                except Exception as e:
+                    line["other_configs"] = {"error": repr(e)}
             print(json.dumps(line), flush=True)
 
     # The RCCL legs around the transform (table broadcast, scatter, gather) are informational and have never run on
