@@ -200,6 +200,21 @@ class Port:
             assert rc == 0
         return out
 
+    def fourstep_ntt_tables(self, x, prm, n1_table, n2_table, W, inverse=False, q=None, n_inv=None):
+        """NTT_4STEP_CPU::ntt / ::intt on CALLER-SUPPLIED natural-order tables (n1/2, n2/2, N words) instead of the
+        parameter set's own (ntt_4step_cpu.cu:33-111: the class computes whatever its public tables say); q / n_inv
+        replace the modulus / the final scaling."""
+        d = dict(prm)
+        tag = "inv" if inverse else "fwd"
+        d["n1_" + tag] = np.ascontiguousarray(n1_table[:prm["n1"] >> 1], dtype=self.T)
+        d["n2_" + tag] = np.ascontiguousarray(n2_table[:prm["n2"] >> 1], dtype=self.T)
+        d["W_" + tag] = np.ascontiguousarray(W[:prm["n"]], dtype=self.T)
+        if q is not None:
+            d["mod"] = self.modulus(q)
+        if n_inv is not None:
+            d["n_inv"] = int(n_inv)
+        return self.fourstep_ntt(x, d, inverse)
+
     def fourstep_intt_first_transpose(self, x, prm):
         x = np.ascontiguousarray(x, dtype=self.T)
         out = np.empty_like(x)
@@ -323,6 +338,18 @@ class Ref:
         x = np.ascontiguousarray(x, dtype=self.T)
         out = np.empty_like(x)
         self.f("4step_run")(prm["handle"], mode, _ptr(x), _ptr(out), x.size // prm["n"])
+        return out
+
+    def fourstep_run_tables(self, x, prm, n1_table, n2_table, W, inverse=False, q=None, n_inv=None):
+        """the reference's NTT_4STEP_CPU on caller-supplied natural-order tables (ref_driver.cpp: fourstep_run_tables)"""
+        x = np.ascontiguousarray(x, dtype=self.T)
+        out = np.empty_like(x)
+        t1 = np.ascontiguousarray(n1_table[:prm["n1"] >> 1], dtype=self.T)
+        t2 = np.ascontiguousarray(n2_table[:prm["n2"] >> 1], dtype=self.T)
+        w = np.ascontiguousarray(W[:prm["n"]], dtype=self.T)
+        self.f("4step_run_tables")(prm["logn"], int(inverse), _ptr(t1), _ptr(t2), _ptr(w), self.c(q or 0),
+                                   self.c(prm["n_inv"] if n_inv is None else n_inv), _ptr(x), _ptr(out),
+                                   x.size // prm["n"])
         return out
 
     def mt19937_uniform(self, seed, q, count):

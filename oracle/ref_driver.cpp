@@ -197,6 +197,42 @@ namespace
         }
     }
 
+    // NTT_4STEP_CPU<T> on CALLER-SUPPLIED tables: the public table vectors of NTTParameters4Step<T> (reference
+    // src/include/gpuntt/common/nttparameters.cuh:119-170, natural order: n1/2, n2/2 and N words) of the chosen direction are
+    // overwritten before the CPU class is built from the parameter set, so ::ntt / ::intt compute whatever those
+    // tables say (src/lib/ntt_4step/ntt_4step_cpu.cu:33-111) -- the CPU-side meaning of a GPU_4STEP_NTT call with
+    // arbitrary tables (src/lib/ntt_4step/ntt_4step.cu:1049-1058, 776-779).  q != 0 replaces the modulus, n_inv the
+    // final scaling of ::intt.
+    template <typename T>
+    void fourstep_run_tables(int logn, int inverse, const T* n1_table, const T* n2_table, const T* W, T q, T n_inv,
+                             const T* in, T* out, int batch)
+    {
+        NTTParameters4Step<T> p(logn, ReductionPolynomial::X_N_minus);
+        if (q != 0)
+            p.modulus = Modulus<T>(q);
+        const size_t h1 = static_cast<size_t>(p.n1) >> 1, h2 = static_cast<size_t>(p.n2) >> 1, n = p.n;
+        if (inverse)
+        {
+            p.n1_based_inverse_root_of_unity_table.assign(n1_table, n1_table + h1);
+            p.n2_based_inverse_root_of_unity_table.assign(n2_table, n2_table + h2);
+            p.W_inverse_root_of_unity_table.assign(W, W + n);
+            p.n_inv = n_inv;
+        }
+        else
+        {
+            p.n1_based_root_of_unity_table.assign(n1_table, n1_table + h1);
+            p.n2_based_root_of_unity_table.assign(n2_table, n2_table + h2);
+            p.W_root_of_unity_table.assign(W, W + n);
+        }
+        NTT_4STEP_CPU<T> cpu(p);
+        for (int b = 0; b < batch; b++)
+        {
+            std::vector<T> v(in + b * n, in + (b + 1) * n);
+            std::vector<T> r = inverse ? cpu.intt(v) : cpu.ntt(v);
+            std::memcpy(out + b * n, r.data(), n * sizeof(T));
+        }
+    }
+
     template <typename T>
     void schoolbook(const T* a, const T* b, T* out, int n, T q, int poly)
     {
@@ -252,6 +288,13 @@ namespace
     void ref##S##_4step_run(void* h, int mode, const T* in, T* out, int batch)       \
     {                                                                                \
         fourstep_run<T>(h, mode, in, out, batch);                                    \
+    }                                                                                \
+    void ref##S##_4step_run_tables(int logn, int inverse, const T* n1_table,         \
+                                   const T* n2_table, const T* W, T q, T n_inv,      \
+                                   const T* in, T* out, int batch)                   \
+    {                                                                                \
+        fourstep_run_tables<T>(logn, inverse, n1_table, n2_table, W, q, n_inv, in,   \
+                               out, batch);                                          \
     }                                                                                \
     void ref##S##_schoolbook(const T* a, const T* b, T* out, int n, T q, int poly)   \
     {                                                                                \

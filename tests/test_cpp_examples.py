@@ -66,3 +66,43 @@ def test_native_benchmark_program_runs():
         lines = [json.loads(l) for l in _run("bench_ntt", algo, dt, first, last, 1, 32).splitlines() if l.startswith("{")]
         assert [d["log2N"] for d in lines] == list(range(first, last + 1))
         assert all(d["us"] > 0 and d["plan_us"] > 0 and d["graph_us"] > 0 for d in lines)
+
+
+@pytest.mark.gpu
+def test_multi_device_benchmark_program_agrees_with_bench_py(pkg):
+    """tests/cpp/bench_multi_device.cpp: resident shards, one host thread per device, HIP events, max over the devices --
+    the 1 / 2 / 4 / 8-GPU table of the product from C++ (tools/first_multigpu_lease.sh runs it on the first multi-GPU
+    node).  On this one-GPU box: the N = 1 lines are bit-exact and agree with the same calls timed through the Python
+    harness (what bench.py times) within a few per cent."""
+    import json
+    import time
+    import numpy as np
+    import torch
+    g = pkg
+    g.load_library()
+    for cfg, bits, logn, polys, steps in (("c2", 64, 16, 1024, 20), ("c4", 32, 14, 8192, 50)):
+        lines = [json.loads(l) for l in _run("bench_multi_device", cfg, steps, 5, "1,2").splitlines() if l.startswith("{")]
+        assert [d["n_gpus"] for d in lines] == list(range(1, min(2, torch.cuda.device_count()) + 1))
+        d = lines[0]
+        assert d["bit_exact_vs_NTTCPU"] is True and d["polys_per_gpu"] == polys and d["ms_per_step"] > 0
+        # the same call through the C ABI / Python harness
+        prm = g.NTTParameters(logn, g.X_N_minus, bits)
+        # random residues like the program's shard: at the socket power cap the time depends on the data (an all-zero
+        # batch runs C2 8 % faster)
+        one = np.random.default_rng(2).integers(0, prm.modulus.value, size=1 << logn, dtype=np.uint64).astype(g.np_dtype(bits))
+        x = g.to_device(one).repeat(polys)
+        table = g.to_device(prm.forward_table_device_order)
+        c = g.ntt_configuration(n_power=logn, ntt_type=g.FORWARD, reduction_poly=g.X_N_minus)
+        step = lambda: g.GPU_NTT_Inplace(x, table, prm.modulus, c, polys)  # noqa: E731
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < 0.3:
+            step()
+            torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            step()
+        e1.record()
+        torch.cuda.synchronize()
+        py_ms = e0.elapsed_time(e1) / steps
+        assert abs(d["ms_per_step"] - py_ms) / py_ms < 0.06, (cfg, d["ms_per_step"], py_ms)

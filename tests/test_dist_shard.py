@@ -123,7 +123,7 @@ def test_first_multigpu_lease_script_parses_and_names_existing_programs():
                        text=True, timeout=60)
     assert r.returncode == 0, r.stderr
     steps = [l.split("|", 2) for l in r.stdout.splitlines() if l.strip()]
-    assert len(steps) == 20
+    assert len(steps) == 22
     names = [s[1] for s in steps]
     order = [n.rsplit("_x", 1)[0] for n in names]
     assert order[:3] == ["rccl_smoke"] * 3, "the RCCL smoke test must come first"
@@ -135,6 +135,10 @@ def test_first_multigpu_lease_script_parses_and_names_existing_programs():
         assert int(tmo) >= 60
         n = int(name.rsplit("_x", 1)[1])
         words = cmd.split()
+        if name.startswith("cpp_bench_"):  # the timed C++ program: every device count of the node in one run
+            assert os.path.exists(os.path.join(ROOT, "tests", "cpp", "bench_multi_device.cpp"))
+            assert words[-1] == "1,2,4,8" and words[-4] in ("c2", "c4")
+            continue
         if name.startswith("cpp_multi_device"):  # the C++ product: one process, one host thread per device
             assert os.path.exists(os.path.join(ROOT, "tests", "cpp", "example_multi_device.cpp"))
             assert words[-2] == str(n), "asks for as many devices as the step's name says"

@@ -361,6 +361,29 @@ def test_largest_rings_sparse_known_answer(g, bits, logn, poly):
     assert np.array_equal(g.to_host(d), r)
 
 
+@pytest.mark.parametrize("logn", [27, 28])
+def test_largest_rings_reference_digest(g, golden_dir, logn):
+    """One whole forward transform at n_power 27 and 28 against the digest of NTTCPU<Data64>::ntt from the reference
+    build (tests/golden/digests_large.json, tools/make_golden_large.py; the input is the seeded splitmix stream)."""
+    import hashlib
+    import json
+    import torch
+    rec = next(r for r in json.load(open(os.path.join(golden_dir, "digests_large.json")))["cases"] if r["logn"] == logn)
+    poly, bits, n = rec["poly"], rec["bits"], 1 << logn
+    prm = g.NTTParameters(logn, poly, bits)
+    assert (prm.modulus.value, prm.omega, prm.psi) == (rec["q"], rec["omega"], rec["psi"])
+    x = O.Port(bits).splitmix(rec["seed"], 0, n, rec["q"])
+    assert hashlib.sha256(x.tobytes()).hexdigest() == rec["sha256_input"]
+    d = g.to_device(x)
+    del x
+    fwd = g.to_device(prm.forward_table_device_order)
+    g.GPU_NTT_Inplace(d, fwd, prm.modulus, g.ntt_configuration(n_power=logn, ntt_type=g.FORWARD, reduction_poly=poly), 1)
+    torch.cuda.synchronize()
+    y = g.to_host(d)
+    assert [int(v) for v in y[:4]] == rec["first_words"] and [int(v) for v in y[-4:]] == rec["last_words"]
+    assert hashlib.sha256(y.tobytes()).hexdigest() == rec["sha256_forward"]
+
+
 @pytest.mark.parametrize("qbits", [61, 62])
 def test_61_and_62_bit_moduli_on_the_fast_kernels(g, qbits):
     """61- and 62-bit moduli (the top of the reference's documented domain, modular_arith.cuh:66-67) run on the

@@ -98,6 +98,56 @@ def test_fourstep_matches_reference_build(bits):
         R.fourstep_free(rp)
 
 
+@needs_ref
+@pytest.mark.parametrize("bits", [32, 64])
+def test_fourstep_on_caller_supplied_tables_matches_reference_build(bits):
+    """NTT_4STEP_CPU computes whatever its parameter set's public tables say (ntt_4step_cpu.cu:33-111) -- the CPU-side
+    meaning of a GPU_4STEP_NTT call with arbitrary tables (ntt_4step.cu:1049-1058, 776-779).  The restatement on
+    caller-supplied tables (Port.fourstep_ntt_tables) against the reference's own class with its six public table
+    vectors overwritten (oracle/ref_driver.cpp: fourstep_run_tables): consistent tables, single corrupted words,
+    random tables, a word that is not a residue, another modulus."""
+    P, R = O.Port(bits), O.Ref(bits)
+    dt = P.T
+    for logn in (12, 13, 15):
+        pp, rp = P.fourstep_params(logn), R.fourstep_params(logn)
+        q, n, n1, n2 = pp["mod"][0], pp["n"], pp["n1"], pp["n2"]
+        rng = np.random.default_rng(900 + logn + bits)
+        x = P.splitmix(4400 + logn, 0, 2 * n, q)
+        for inverse in (False, True):
+            tag = "inv" if inverse else "fwd"
+            t1, t2, w = pp["n1_" + tag], pp["n2_" + tag], pp["W_" + tag]
+            assert np.array_equal(t1, rp["n1_" + tag]) and np.array_equal(w, rp["W_" + tag])
+            cases = {"own tables": (t1, t2, w)}
+            wb = w.copy()
+            wb[int(rng.integers(0, n))] = dt(int(rng.integers(0, q)))
+            cases["one W word"] = (t1, t2, wb)
+            cases["random W"] = (t1, t2, rng.integers(0, q, size=n, dtype=np.uint64).astype(dt))
+            t1b, t2b = t1.copy(), t2.copy()
+            t1b[int(rng.integers(0, t1.size))] = dt(int(rng.integers(0, q)))
+            t2b[int(rng.integers(0, t2.size))] = dt(int(rng.integers(0, q)))
+            cases["one word of each small table"] = (t1b, t2b, w)
+            cases["everything random"] = tuple(rng.integers(0, q, size=t.size, dtype=np.uint64).astype(dt)
+                                               for t in (t1, t2, w))
+            wq = w.copy()
+            wq[5] = dt(q)
+            cases["a word equal to q"] = (t1, t2, wq)
+            for name, (a, b, c) in cases.items():
+                got = P.fourstep_ntt_tables(x, pp, a, b, c, inverse)
+                want = R.fourstep_run_tables(x, rp, a, b, c, inverse)
+                assert np.array_equal(got, want), (bits, logn, tag, name)
+                if name == "own tables":
+                    assert np.array_equal(got, P.fourstep_ntt(x, pp, inverse))
+                    assert np.array_equal(want, R.fourstep_run(x, rp, 1 if inverse else 0))
+            # another modulus with the same (now meaningless) tables reduced below it, n^-1 replaced as well
+            q2 = 10007 if bits == 32 else 1000003
+            x2 = (x % dt(q2)).astype(dt)
+            tabs = tuple((t % dt(q2)).astype(dt) for t in (t1, t2, w))
+            got = P.fourstep_ntt_tables(x2, pp, *tabs, inverse, q=q2, n_inv=77)
+            want = R.fourstep_run_tables(x2, rp, *tabs, inverse, q=q2, n_inv=77)
+            assert np.array_equal(got, want), (bits, logn, tag, "modulus %d" % q2)
+        R.fourstep_free(rp)
+
+
 @pytest.mark.parametrize("bits", [32, 64])
 def test_merge_golden_full_vectors(bits, golden_dir):
     P = O.Port(bits)

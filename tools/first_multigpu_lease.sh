@@ -34,6 +34,10 @@ done
 for N in $GPUS; do
   STEPS+=("300|cpp_multi_device_x$N|make -s -C tests/cpp && tests/cpp/_bin/example_multi_device 16 512 $N 8")
 done
+# ... and TIMED: resident shards, one host thread per device, HIP events, max over the devices -- the scaling table of the
+# product without Python or RCCL (tests/cpp/bench_multi_device.cpp prints one JSON line per device count, 1 included)
+STEPS+=("600|cpp_bench_c2_x1|make -s -C tests/cpp && tests/cpp/_bin/bench_multi_device c2 20 5 1,2,4,8")
+STEPS+=("600|cpp_bench_c4_x1|make -s -C tests/cpp && tests/cpp/_bin/bench_multi_device c4 50 10 1,2,4,8")
 # the single-GPU reference points the scaling table is read against
 STEPS+=("600|bench_c2_x1|python bench.py --gpus 1 --steps 20 --warmup 5")
 STEPS+=("600|bench_c4_strong_x1|python bench.py --gpus 1 --config c4 --steps 50 --warmup 10")
@@ -73,7 +77,7 @@ for s in "${STEPS[@]}"; do
   dt=$(( $(date +%s) - t0 ))
   if [ $rc -eq 0 ]; then st=PASS; elif [ $rc -eq 124 ] || [ $rc -eq 137 ]; then st=TIMEOUT; else st="FAIL(rc=$rc)"; fi
   # the one-line results of the step, if it printed any
-  res="$(grep -E '^(RCCL_SMOKE|MULTIGPU_DIGESTS|All Correct on|\{"metric")' "$log" | tail -n 1 | cut -c1-220)"
+  res="$(grep -E '^(RCCL_SMOKE|MULTIGPU_DIGESTS|All Correct on|\{"metric"|\{"program")' "$log" | tail -n 1 | cut -c1-220)"
   printf '%-8s %-22s %4ss  %s\n' "$st" "$name" "$dt" "$res" | tee -a "$OUT/VERDICT.txt"
 done
 # scaling table from the bench lines (value = whole-job NTT/s)
@@ -93,6 +97,17 @@ for cfg in ("bench_c2", "bench_c4_strong"):
         if name.startswith(cfg + "_x"):
             eff = (v / (n * base[1])) if base else float("nan")
             print("%-20s n_gpus=%d  value=%.4g NTT/s  ms_per_step=%.4f  efficiency_vs_x1=%.3f" % (cfg, n, v, ms, eff))
+PY
+# the same table from the C++ program's lines
+python - "$OUT" <<'PY' | tee -a "$OUT/VERDICT.txt"
+import glob, json, os, sys
+for f in sorted(glob.glob(os.path.join(sys.argv[1], "*_cpp_bench_*.log"))):
+    rows = [json.loads(l) for l in open(f) if l.startswith('{"program"')]
+    base = next((r for r in rows if r["n_gpus"] == 1), None)
+    for r in rows:
+        eff = r["value_ntt_per_s"] / (r["n_gpus"] * base["value_ntt_per_s"]) if base else float("nan")
+        print("cpp %-4s n_gpus=%d  value=%.4g NTT/s  ms_per_step=%.4f  efficiency_vs_x1=%.3f  bit_exact=%s"
+              % (r["config"], r["n_gpus"], r["value_ntt_per_s"], r["ms_per_step"], eff, r["bit_exact_vs_NTTCPU"]))
 PY
 grep -q -E '^(FAIL|TIMEOUT)' "$OUT/VERDICT.txt" && exit 1
 exit 0
