@@ -142,6 +142,10 @@ namespace gpuntt
             unsigned state;      // predicted go-flag state (kern::GO_*); meaningful when !all_families
             bool all_families;
             unsigned* state_out; // device pointer of the host-mapped word for the preparation kernel, or nullptr
+            bool unsure = false;         // nothing is known about this stack yet (first call with this moduli buffer), or its last
+                                         // call found moduli outside the lazy families' domain
+            bool shadow_generic = false; // set by the entry point: the generic kernels are enqueued behind the call, so the
+                                         // preparation kernel must not transform the batch itself
         };
         // order: the mod_order array of a *_Modulus_Ordered call (a different subset of the stack may classify differently), else nullptr
         // exact (the 4-step entry point, whose kernels match the go-flag state exactly and keep the generic kernels behind

@@ -184,7 +184,8 @@ namespace gpuntt
                 slow.col_log = -1;
                 slow.flags = io_flags & (kern::F_SIGNED_IN | kern::F_SCALE | kern::F_CENTERED);
                 slow.inverse = inverse ? 1 : 0;
-                slow.enabled = forced_path() == 3 ? 0 : 1; // fast-strict: the lazy families must own the call
+                // fast-strict: the lazy families must own the call; shadow_generic: the generic kernels behind the call do
+                slow.enabled = (forced_path() == 3 || guess->shadow_generic) ? 0 : 1;
             }
             host::launch_prep<TU>(roots, ws, mods, m.value, mod_count, n_power, neg, perm, ninv_dev,
                                   ninv_dev ? ws_ninv : nullptr, go_flag, norm_arr, stream, mod_order, ninv_single,
@@ -247,6 +248,34 @@ namespace gpuntt
                     host::run_transform_lazy<TU, INV>(wide, in_flags, out_flags, stream);
                 }
             }
+        }
+
+        // The preparation kernel's own fall-back (kern::SlowArgs) walks ONE polynomial per block, stage by stage through
+        // global memory: milliseconds for FHE-sized calls, but ~40 ms per polynomial of 2^20 and most of a second at 2^24
+        // (ADVICE r5).  So when NOTHING is known about a stack (first call with this moduli buffer, or its last call found
+        // moduli outside the domain) and the ring is large -- or the call is being captured into a graph, whose replays
+        // cannot learn -- the call casts the wide net instead: every lazy family behind the exact go-flag state and the
+        // generic kernels behind them, the preparation kernel only classifies.  A few skipped launches (~6 us each) on a
+        // call of >= 100 us, once per stack.
+        constexpr int RNS_WIDE_NET_MIN_N_POWER = 17;
+        inline bool cast_wide_net(host::RnsGuess& guess, int n_power, hipStream_t stream)
+        {
+            if (!guess.unsure || forced_path() == 3)
+                return false;
+            bool wide = n_power >= RNS_WIDE_NET_MIN_N_POWER;
+            if (!wide)
+            {
+                hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+                if (hipStreamIsCapturing(stream, &st) != hipSuccess)
+                    (void) hipGetLastError();
+                wide = st != hipStreamCaptureStatusNone;
+            }
+            if (wide)
+            {
+                guess.all_families = true;
+                guess.shadow_generic = true;
+            }
+            return wide;
         }
 
         // option path = generic-capped (test hook): a device word holding kern::GO_GENERIC, so that the generic kernels of an
@@ -643,13 +672,16 @@ namespace gpuntt
         else if (batch_size > 0 && lazy_eligible<TU>(cfg.n_power, batch_size, mod_count, cfg.stream))
         {
             // preparation (classifies the stack; its own fall-back when the stack does not fit) + the predicted lazy family
-            const host::RnsGuess guess = host::rns_guess(modulus, mod_count, static_cast<int>(sizeof(TU)), false);
+            host::RnsGuess guess = host::rns_guess(modulus, mod_count, static_cast<int>(sizeof(TU)), false);
+            const bool wide_net = cast_wide_net(guess, cfg.n_power, cfg.stream);
             kern::LazyArgsT<TU> la =
                 lazy_args<TU>(device_in, device_out, root_of_unity_table, Modulus<TU>(), modulus, mod_count,
                               nullptr, cfg.n_power, cfg.reduction_poly, batch_size, cfg.stream, nullptr, nullptr,
                               &guess, in_flags);
             run_transform_lazy_rns<TU, false>(la, in_flags, 0u, cfg.stream, guess);
-            return;
+            if (!wide_net)
+                return;
+            skip_flag = la.go_flag; // the generic kernels below run iff the preparation kernel published GO_GENERIC
         }
         kern::PassArgs<TU> a = base_args<TU>(device_in, device_out, root_of_unity_table, cfg.n_power,
                                              cfg.reduction_poly, batch_size);
@@ -699,13 +731,16 @@ namespace gpuntt
         else if (batch_size > 0 && cfg.mod_inverse != nullptr &&
             lazy_eligible<TU>(cfg.n_power, batch_size, mod_count, cfg.stream))
         {
-            const host::RnsGuess guess = host::rns_guess(modulus, mod_count, static_cast<int>(sizeof(TU)), true);
+            host::RnsGuess guess = host::rns_guess(modulus, mod_count, static_cast<int>(sizeof(TU)), true);
+            const bool wide_net = cast_wide_net(guess, cfg.n_power, cfg.stream);
             kern::LazyArgsT<TU> la =
                 lazy_args<TU>(device_in, reinterpret_cast<TU*>(device_out), root_of_unity_table,
                               Modulus<TU>(), modulus, mod_count, cfg.mod_inverse, cfg.n_power,
                               cfg.reduction_poly, batch_size, cfg.stream, nullptr, nullptr, &guess, out_flags);
             run_transform_lazy_rns<TU, true>(la, 0u, out_flags, cfg.stream, guess);
-            return;
+            if (!wide_net)
+                return;
+            skip_flag = la.go_flag; // the generic kernels below run iff the preparation kernel published GO_GENERIC
         }
         kern::PassArgs<TU> a =
             base_args<TU>(device_in, reinterpret_cast<TU*>(device_out), root_of_unity_table,
@@ -1199,11 +1234,13 @@ namespace gpuntt
             if (batch_size <= 0)
                 return;
             const bool inv = (cfg.ntt_type == INVERSE);
+            const unsigned* ordered_skip_flag = nullptr;
             // fast path: whole tiles inside one polynomial
             if (cfg.n_power >= host::lazy_tile_log<T>(cfg.n_power) &&
                 lazy_eligible<T>(cfg.n_power, batch_size, mod_count, cfg.stream) && (!inv || cfg.mod_inverse != nullptr))
             {
-                const host::RnsGuess guess = host::rns_guess(modulus, mod_count, static_cast<int>(sizeof(T)), inv, mod_order);
+                host::RnsGuess guess = host::rns_guess(modulus, mod_count, static_cast<int>(sizeof(T)), inv, mod_order);
+                const bool wide_net = cast_wide_net(guess, cfg.n_power, cfg.stream);
                 const unsigned io_flags = inv ? static_cast<unsigned>(kern::F_SCALE) : 0u;
                 kern::LazyArgsT<T> la =
                     lazy_args<T>(device_in, device_out, table, Modulus<T>(), modulus, mod_count,
@@ -1213,7 +1250,9 @@ namespace gpuntt
                     run_transform_lazy_rns<T, true>(la, 0u, kern::F_SCALE, cfg.stream, guess);
                 else
                     run_transform_lazy_rns<T, false>(la, 0u, 0u, cfg.stream, guess);
-                return;
+                if (!wide_net)
+                    return;
+                ordered_skip_flag = la.go_flag; // the generic kernels below run iff the preparation kernel published GO_GENERIC
             }
             kern::PassArgs<T> a = base_args<T>(device_in, device_out, table, cfg.n_power,
                                                cfg.reduction_poly, batch_size);
@@ -1222,6 +1261,7 @@ namespace gpuntt
             a.ninv_arr = cfg.mod_inverse;
             a.mod_order = mod_order;
             a.poly_order = poly_order;
+            a.skip_flag = ordered_skip_flag;
             set_multi(a);
             if (inv)
                 host::run_transform<T, true>(a, 0u, kern::F_SCALE, cfg.stream);

@@ -765,6 +765,7 @@ namespace gpuntt
                 int streak = 0;                          // calls in a row that needed a narrower family than the predicted one
                 unsigned streak_state = kern::GO_LAZY;   // the widest of them
                 unsigned long long last_use = 0;
+                bool generic_seen = false; // the last finished call found a modulus outside the lazy families' domain
             };
             // one pinned, device-mapped allocation per device: GUESS_MAX_KEYS words, one cache line apart.  Never freed
             // (captured graphs keep writing their state to the word they were captured with; a word that has been handed to
@@ -783,6 +784,10 @@ namespace gpuntt
             // stack may need different families (31 q serves forward transforms only), a *_Modulus_Ordered call uses the
             // subset its order array names; the Merge entry points otherwise share one slot per stack
             std::map<std::tuple<int, const void*, const void*, int, int>, GuessSlot> g_guess;
+            // what stacks of the same SHAPE (device, mod_count, word size | entry | direction, ordered or not) needed last,
+            // whatever buffer they lived in: the first prediction for a moduli buffer never seen before -- a caller that
+            // uploads its stack to a fresh buffer per call keeps its family
+            std::map<std::tuple<int, int, int, bool>, unsigned> g_shape_hint;
             unsigned long long g_guess_clock = 0;
         } // namespace
 
@@ -838,6 +843,9 @@ namespace gpuntt
                     g_guess.erase(oldest);
                 }
                 reinterpret_cast<volatile unsigned*>(pool.host)[slot.word * GUESS_STRIDE] = STATE_UNKNOWN;
+                const auto hint = g_shape_hint.find(std::make_tuple(dev, mod_count, std::get<4>(key), order != nullptr));
+                if (hint != g_shape_hint.end())
+                    slot.predicted = hint->second;
                 it = g_guess.emplace(key, slot).first;
             }
             GuessSlot& s = it->second;
@@ -866,7 +874,12 @@ namespace gpuntt
                     }
                 }
                 s.have_prediction = true;
+                s.generic_seen = false;
+                g_shape_hint[std::make_tuple(dev, mod_count, std::get<4>(key), order != nullptr)] = s.predicted;
             }
+            else if (seen == kern::GO_GENERIC)
+                s.generic_seen = true;
+            gss.unsure = !s.have_prediction || s.generic_seen;
             gss.state_out = pool.dev + s.word * GUESS_STRIDE;
             gss.all_families = false;
             gss.state = s.predicted;
