@@ -103,9 +103,41 @@ EXPORTED_SYMBOLS = ["gpuntt_last_error", "gpuntt_version"] + [
 ENV_OPTIONS = {"GPUNTT_PATH": ("path", None), "GPUNTT_U32_E32": ("u32_e32", lambda v: int(v, 0))}
 
 
+TEST_HOOKS = {"no_scratch", "rns_force_fallback", "u32_e32", "reset_predictions"}
+TEST_PATHS = {"fast-strict", "generic-capped"}
+
+
 def set_option(name, value):
-    """GPU_NTT_SetOption: process-wide tuning / test switch (names in include/gpuntt/ntt_merge/ntt.cuh)."""
-    _check(load_library().gpuntt_set_option(str(name).encode(), str(value).encode()))
+    """GPU_NTT_SetOption (product options: path = default | generic | fast, check_4step_tables, rns_predict; names in
+    include/gpuntt/ntt_merge/ntt.cuh).  The TEST HOOKS of this repository (csrc/test_hooks.h: path = fast-strict |
+    generic-capped, no_scratch, rns_force_fallback, u32_e32) are not options of the public interface; this harness
+    forwards them to gpuntt_test_set_hook so that the tests and tools/ keep one call."""
+    name, value = str(name), str(value)
+    if name in TEST_HOOKS or (name == "path" and value in TEST_PATHS):
+        return set_test_hook(name, value)
+    _check(load_library().gpuntt_set_option(name.encode(), value.encode()))
+
+
+def set_test_hook(name, value):
+    """gpuntt_test_set_hook (csrc/test_hooks.h)."""
+    _check(load_library().gpuntt_test_set_hook(str(name).encode(), str(value).encode()))
+
+
+class launch_log:
+    """with launch_log() as log: ...calls...; log.kernels -> the kernels the library enqueued inside the block, in order
+    (gpuntt_test_launch_log_start / _take, csrc/test_hooks.h): ["prep_twiddles", "merge_pass_lazy:31", ...]"""
+
+    def __enter__(self):
+        _check(load_library().gpuntt_test_launch_log_start())
+        self.kernels = []
+        return self
+
+    def __exit__(self, *exc):
+        lib = load_library()
+        buf = ctypes.create_string_buffer(1 << 16)
+        lib.gpuntt_test_launch_log_take(buf, len(buf))
+        self.kernels = buf.value.decode().split()
+        return False
 
 
 def _check(rc):

@@ -1,4 +1,5 @@
 // c_api.cpp -- extern "C" boundary (include/gpuntt_c.h) over the C++ template API.
+#include <algorithm>
 #include <cstring>
 #include <exception>
 #include <initializer_list>
@@ -9,6 +10,7 @@
 #include "gpuntt/ntt_4step/ntt_4step.cuh"
 #include "gpuntt/ntt_merge/ntt.cuh"
 #include "gpuntt_c.h"
+#include "test_hooks.h"
 
 namespace gpuntt
 {
@@ -16,6 +18,10 @@ namespace gpuntt
     {
         // prep.hip (diagnostic): the preparation kernels' normalised reciprocal of every q[i]
         template <typename T> void debug_recip_norm(const T* q, T* out, unsigned long long count, hipStream_t stream);
+        // prep.hip: test hooks (csrc/test_hooks.h)
+        bool set_test_hook(const char* name, const char* value);
+        void launch_log_start();
+        std::string launch_log_take();
     } // namespace host
 } // namespace gpuntt
 
@@ -435,6 +441,30 @@ extern "C"
         });
     }
     int gpuntt_version(void) { return 101; }
+
+    // ---- test hooks (csrc/test_hooks.h; not declared by the public headers) ----------------------------------------
+    int gpuntt_test_set_hook(const char* name, const char* value)
+    {
+        return guarded([&] {
+            if (!host::set_test_hook(name, value))
+                throw std::invalid_argument("Unknown option or value!");
+        });
+    }
+    int gpuntt_test_launch_log_start(void)
+    {
+        return guarded([] { host::launch_log_start(); });
+    }
+    int gpuntt_test_launch_log_take(char* buf, int capacity)
+    {
+        const std::string s = host::launch_log_take();
+        if (buf != nullptr && capacity > 0)
+        {
+            const size_t n = std::min(s.size(), static_cast<size_t>(capacity - 1));
+            std::memcpy(buf, s.data(), n);
+            buf[n] = '\0';
+        }
+        return static_cast<int>(s.size()) + 1;
+    }
 
     int gpuntt_modulus_u32(uint32_t q, gpuntt_modulus32* out)
     {

@@ -76,7 +76,7 @@ namespace gpuntt
                 const int part = (batch_size - done < 65535) ? (batch_size - done) : 65535;
                 const dim3 grid((col + 31) / 32, (row + 31) / 32, part);
                 const unsigned long long off = static_cast<unsigned long long>(done) << n_power;
-                hipLaunchKernelGGL((kern::transpose_batch<T>), grid, dim3(256), 0, stream, in + off, out + off, row,
+                GPUNTT_LAUNCH((kern::transpose_batch<T>), grid, dim3(256), 0, stream, in + off, out + off, row,
                                    col, 1ull << n_power, skip_flag);
                 GPUNTT_HIP_CHECK(hipGetLastError());
             }

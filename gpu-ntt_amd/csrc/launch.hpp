@@ -23,6 +23,29 @@ namespace gpuntt
 {
     namespace host
     {
+        // test hook (prep.hip): the launch log.  family: the lazy range of a fast kernel (0 default, 31, 8, 4), -1 = none
+        void note_launch(const char* kernel_expr, int family = -1);
+    } // namespace host
+} // namespace gpuntt
+// EVERY kernel launch of the library: reports the kernel to the launch log (off unless a test switched it on: one relaxed
+// atomic load), then launches
+#define GPUNTT_LAUNCH(kernel, ...)                                                                                       \
+    do                                                                                                                   \
+    {                                                                                                                    \
+        ::gpuntt::host::note_launch(#kernel);                                                                            \
+        hipLaunchKernelGGL(kernel, __VA_ARGS__);                                                                         \
+    } while (0)
+#define GPUNTT_LAUNCH_FAMILY(family, kernel, ...)                                                                        \
+    do                                                                                                                   \
+    {                                                                                                                    \
+        ::gpuntt::host::note_launch(#kernel, family);                                                                    \
+        hipLaunchKernelGGL(kernel, __VA_ARGS__);                                                                         \
+    } while (0)
+
+namespace gpuntt
+{
+    namespace host
+    {
         struct Pass
         {
             bool contig;

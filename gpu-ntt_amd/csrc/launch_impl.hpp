@@ -11,7 +11,7 @@ namespace gpuntt
         template <typename T, bool INV, bool CONTIG, int K, bool FST = false>
         inline void launch_one(const kern::PassArgs<T>& a, unsigned grid, hipStream_t stream)
         {
-            hipLaunchKernelGGL((kern::merge_pass<T, INV, CONTIG, K, FST>), dim3(grid), dim3(kern::NT),
+            GPUNTT_LAUNCH((kern::merge_pass<T, INV, CONTIG, K, FST>), dim3(grid), dim3(kern::NT),
                                0, stream, a);
             GPUNTT_HIP_CHECK(hipGetLastError());
         }
@@ -85,7 +85,7 @@ namespace gpuntt
             if (cols_log > log_w)
                 cols_log = log_w;
             const unsigned grid = 1u << (log_w - cols_log);
-            hipLaunchKernelGGL((kern::column_ntt_small<T, INV>), dim3(grid), dim3(256), 0, stream, a, n, log_w,
+            GPUNTT_LAUNCH((kern::column_ntt_small<T, INV>), dim3(grid), dim3(256), 0, stream, a, n, log_w,
                                cols_log);
             GPUNTT_HIP_CHECK(hipGetLastError());
         }

@@ -13,9 +13,9 @@ template <bool INV> void launch_ring_e32(int n, int lim, const kern::LazyArgsT<u
 #define GPUNTT_E32(TL_)                                                                                                  \
     case TL_:                                                                                                            \
         if (lim == 8)                                                                                                    \
-            hipLaunchKernelGGL((kern::merge_ring_e32<TL_, INV, 8>), grid, dim3(kern::ETile<TL_>::NT), 0, stream, a);     \
+            GPUNTT_LAUNCH_FAMILY(8, (kern::merge_ring_e32<TL_, INV, 8>), grid, dim3(kern::ETile<TL_>::NT), 0, stream, a);     \
         else                                                                                                             \
-            hipLaunchKernelGGL((kern::merge_ring_e32<TL_, INV, 0>), grid, dim3(kern::ETile<TL_>::NT), 0, stream, a);     \
+            GPUNTT_LAUNCH_FAMILY(0, (kern::merge_ring_e32<TL_, INV, 0>), grid, dim3(kern::ETile<TL_>::NT), 0, stream, a);     \
         break;
     switch (n)
     {

@@ -4,6 +4,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <string>
+
 #include "launch.hpp"
 #include "merge_lazy_kernels.hpp"
 
@@ -347,6 +349,11 @@ namespace gpuntt
 
         // process-wide tuning / test options (prep.hip); the library reads no environment variable
         bool set_option(const char* name, const char* value);
+        // test hooks (csrc/test_hooks.h; not in the public headers): path = fast-strict | generic-capped, no_scratch,
+        // rns_force_fallback, u32_e32 -- and everything set_option takes
+        bool set_test_hook(const char* name, const char* value);
+        void launch_log_start();
+        std::string launch_log_take(); // space-separated kernel names ("merge_pass_lazy:31 prep_twiddles ..."), stops the log
         // 0 size heuristic, 1 generic kernels, 2 fast, 3 fast-strict (a call the fast kernels cannot take throws),
         // 4 generic-capped (4-step RNS overload: generic kernels on the capped shadow grid)
         int forced_path();
@@ -358,14 +365,6 @@ namespace gpuntt
         // 0.177 against 0.211 ms per 2^26 coefficients; the others 1-4 %).  The 4-step plans keep lazy_contig_k.
         template <typename T> inline int lazy_contig_k_merge(int n, bool inverse)
         {
-#ifdef GPUNTT_EXP_CK // stage-split sweeps (experimental builds only): GPUNTT_CK = stages of the contiguous pass
-            if (const char* e = std::getenv("GPUNTT_CK"))
-            {
-                const int k = std::atoi(e);
-                if (k >= 8 && k <= 12 && n - k >= 1 && n - k <= 8)
-                    return k;
-            }
-#endif
             if (sizeof(T) == 4)
             {
                 if (!inverse && n >= 15 && n <= 17)

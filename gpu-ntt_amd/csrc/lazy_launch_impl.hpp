@@ -10,7 +10,7 @@ namespace gpuntt
         template <typename T, int TLOG, bool INV, bool CONTIG, int K, int IN_BOUND, bool LAST, int LIMSEL = 0>
         inline void launch_lazy_one(const kern::LazyArgsT<T>& a, unsigned grid, hipStream_t stream)
         {
-            hipLaunchKernelGGL((kern::merge_pass_lazy<T, TLOG, INV, CONTIG, K, IN_BOUND, LAST, LIMSEL>), dim3(grid),
+            GPUNTT_LAUNCH_FAMILY(LIMSEL, (kern::merge_pass_lazy<T, TLOG, INV, CONTIG, K, IN_BOUND, LAST, LIMSEL>), dim3(grid),
                                dim3(kern::LTile<TLOG>::NT), 0, stream, a);
             GPUNTT_HIP_CHECK(hipGetLastError());
         }
@@ -247,7 +247,7 @@ namespace gpuntt
             {
 #define GPUNTT_CASE(KK)                                                                                               \
     case KK:                                                                                                           \
-        hipLaunchKernelGGL((kern::fourstep_first_lazy<T, KK, LIMSEL>), dim3(grid), dim3(kern::LTile<12>::NT), 0, stream, a); \
+        GPUNTT_LAUNCH_FAMILY(LIMSEL, (kern::fourstep_first_lazy<T, KK, LIMSEL>), dim3(grid), dim3(kern::LTile<12>::NT), 0, stream, a); \
         break;
                 GPUNTT_CASE(5)
                 GPUNTT_CASE(6)
@@ -274,7 +274,7 @@ namespace gpuntt
 #define GPUNTT_BIG(TLG, KK)                                                                                               \
     if (tile_log == TLG && log_n1 == KK)                                                                                   \
     {                                                                                                                      \
-        hipLaunchKernelGGL((kern::fourstep_inv_first_lazy<T, KK, LIMSEL, TLG>), dim3(grid), dim3(kern::LTile<TLG>::NT), 0,  \
+        GPUNTT_LAUNCH_FAMILY(LIMSEL, (kern::fourstep_inv_first_lazy<T, KK, LIMSEL, TLG>), dim3(grid), dim3(kern::LTile<TLG>::NT), 0,  \
                            stream, a);                                                                                     \
         GPUNTT_HIP_CHECK(hipGetLastError());                                                                               \
         return;                                                                                                            \
@@ -297,7 +297,7 @@ namespace gpuntt
             {
 #define GPUNTT_CASE(KK)                                                                                                   \
     case KK:                                                                                                               \
-        hipLaunchKernelGGL((kern::fourstep_inv_first_lazy<T, KK, LIMSEL>), dim3(grid), dim3(kern::LTile<12>::NT), 0, stream, a); \
+        GPUNTT_LAUNCH_FAMILY(LIMSEL, (kern::fourstep_inv_first_lazy<T, KK, LIMSEL>), dim3(grid), dim3(kern::LTile<12>::NT), 0, stream, a); \
         break;
                 GPUNTT_CASE(5)
                 GPUNTT_CASE(6)
@@ -323,7 +323,7 @@ namespace gpuntt
                 throw std::invalid_argument("batch_size * N too large for one launch");
             const unsigned grid = lazy_grid_cap<T, LIMSEL>(tiles, a.go_flag);
 #define GPUNTT_ROWS(K_, S_)                                                                                                \
-    hipLaunchKernelGGL((kern::merge_pass_lazy<T, 12, true, true, K_, LIM / 2, true, LIMSEL, S_>), dim3(grid),               \
+    GPUNTT_LAUNCH_FAMILY(LIMSEL, (kern::merge_pass_lazy<T, 12, true, true, K_, LIM / 2, true, LIMSEL, S_>), dim3(grid),               \
                        dim3(kern::LTile<12>::NT), 0, stream, a)
             if (log_n2 == 9 && skip == 5)
                 GPUNTT_ROWS(9, 5);
@@ -354,10 +354,10 @@ namespace gpuntt
                 throw std::invalid_argument("batch_size * N too large for one launch");
             const unsigned grid = lazy_grid_cap<T, LIMSEL>(tiles, a.go_flag);
             if (k == 9)
-                hipLaunchKernelGGL((kern::merge_pass_lazy<T, 12, false, true, 9, LIM, true, LIMSEL, 1>), dim3(grid),
+                GPUNTT_LAUNCH_FAMILY(LIMSEL, (kern::merge_pass_lazy<T, 12, false, true, 9, LIM, true, LIMSEL, 1>), dim3(grid),
                                    dim3(kern::LTile<12>::NT), 0, stream, a);
             else if (k == 11)
-                hipLaunchKernelGGL((kern::merge_pass_lazy<T, 12, false, true, 11, LIM, true, LIMSEL, 1>), dim3(grid),
+                GPUNTT_LAUNCH_FAMILY(LIMSEL, (kern::merge_pass_lazy<T, 12, false, true, 11, LIM, true, LIMSEL, 1>), dim3(grid),
                                    dim3(kern::LTile<12>::NT), 0, stream, a);
             else
                 throw std::invalid_argument("internal: bad forward 4-step last pass");
@@ -376,7 +376,7 @@ namespace gpuntt
                 throw std::invalid_argument("batch_size * N too large for one launch");
             const unsigned grid = static_cast<unsigned>(tiles);
 #define GPUNTT_SMALL(TL_, K_)                                                                                          \
-    hipLaunchKernelGGL((kern::fourstep_small_lazy<T, TL_, INV, K_, 0, NAT>), dim3(grid), dim3(kern::LTile<TL_>::NT), 0, \
+    GPUNTT_LAUNCH_FAMILY(0, (kern::fourstep_small_lazy<T, TL_, INV, K_, 0, NAT>), dim3(grid), dim3(kern::LTile<TL_>::NT), 0, \
                        stream, a)
             if constexpr (sizeof(T) == 8)
             {
@@ -424,7 +424,7 @@ namespace gpuntt
             constexpr int LIM = lazy::Mod<T, LIMSEL>::LIMIT;
             const unsigned grid = static_cast<unsigned>(a.total >> TLOG);
 #define GPUNTT_ONE(KK)                                                                            \
-    hipLaunchKernelGGL((kern::fourstep_nat_last_lazy<T, TLOG, KK, LIM, LIMSEL>), dim3(grid),       \
+    GPUNTT_LAUNCH_FAMILY(LIMSEL, (kern::fourstep_nat_last_lazy<T, TLOG, KK, LIM, LIMSEL>), dim3(grid),       \
                        dim3(kern::LTile<TLOG>::NT), 0, stream, a)
             if (k == 7)
                 GPUNTT_ONE(7);
@@ -448,7 +448,7 @@ namespace gpuntt
             {
 #define GPUNTT_CASE(KK)                                                                          \
     case KK:                                                                                      \
-        hipLaunchKernelGGL((kern::fourstep_nat_first_inv_lazy<T, TLOG, KK, LIMSEL>), dim3(grid),  \
+        GPUNTT_LAUNCH_FAMILY(LIMSEL, (kern::fourstep_nat_first_inv_lazy<T, TLOG, KK, LIMSEL>), dim3(grid),  \
                            dim3(kern::LTile<TLOG>::NT), 0, stream, a);                            \
         break;
                 GPUNTT_CASE(7)
@@ -476,11 +476,11 @@ namespace gpuntt
                 if (tiles > 0x7fffffffull)
                     throw std::invalid_argument("batch_size * N too large for one launch");
                 if (what == 2)
-                    hipLaunchKernelGGL((kern::fourstep_small_lazy<uint64_t, 12, INV, 12, LIMSEL>),
+                    GPUNTT_LAUNCH_FAMILY(LIMSEL, (kern::fourstep_small_lazy<uint64_t, 12, INV, 12, LIMSEL>),
                                        dim3(lazy_grid_cap<uint64_t, LIMSEL>(tiles, a.go_flag)),
                                        dim3(kern::LTile<12>::NT), 0, stream, a);
                 else if constexpr (LIMSEL == 4) // natural-order extension (4 q family only)
-                    hipLaunchKernelGGL((kern::fourstep_small_lazy<uint64_t, 12, INV, 12, LIMSEL, true>),
+                    GPUNTT_LAUNCH_FAMILY(LIMSEL, (kern::fourstep_small_lazy<uint64_t, 12, INV, 12, LIMSEL, true>),
                                        dim3(static_cast<unsigned>(tiles)), dim3(kern::LTile<12>::NT), 0, stream, a);
                 else
                     throw std::invalid_argument("internal: bad 4-step kernel selector");

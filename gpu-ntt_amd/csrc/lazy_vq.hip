@@ -16,7 +16,7 @@ void launch_pass_lazy_vq(const Pass& p, bool in_first, bool last, const kern::La
 #define GPUNTT_VQ(K_, IN_, LAST_)                                                                                     \
     do                                                                                                                \
     {                                                                                                                 \
-        hipLaunchKernelGGL((kern::merge_pass_lazy_vq<T, INV, K_, IN_, LAST_>), dim3(grid), dim3(kern::LTile<12>::NT), \
+        GPUNTT_LAUNCH((kern::merge_pass_lazy_vq<T, INV, K_, IN_, LAST_>), dim3(grid), dim3(kern::LTile<12>::NT), \
                            0, stream, a);                                                                             \
         GPUNTT_HIP_CHECK(hipGetLastError());                                                                          \
         return;                                                                                                       \

@@ -11,7 +11,7 @@ namespace
         {
 #define GPUNTT_CASE(KK)                                                                                                \
     case KK:                                                                                                            \
-        hipLaunchKernelGGL((kern::merge_pass_lazy_vqc<T, INV, KK, LIMSEL>), dim3(grid), dim3(kern::LTile<12>::NT), 0, stream, a); \
+        GPUNTT_LAUNCH_FAMILY(LIMSEL, (kern::merge_pass_lazy_vqc<T, INV, KK, LIMSEL>), dim3(grid), dim3(kern::LTile<12>::NT), 0, stream, a); \
         break;
             GPUNTT_CASE(4)
             GPUNTT_CASE(5)

@@ -836,10 +836,10 @@ namespace gpuntt
             if (blocks > 16384)
                 blocks = 16384; // 64 blocks per CU, grid-stride beyond
             if (wide)
-                hipLaunchKernelGGL((kern::pointwise_mul<T, VW>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0,
+                GPUNTT_LAUNCH((kern::pointwise_mul<T, VW>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0,
                                    stream, a, b, out, mods, mod, mod_count, n_power, total, skip_flag, skip_value);
             else
-                hipLaunchKernelGGL((kern::pointwise_mul<T, 1>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0,
+                GPUNTT_LAUNCH((kern::pointwise_mul<T, 1>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0,
                                    stream, a, b, out, mods, mod, mod_count, n_power, total, skip_flag, skip_value);
             GPUNTT_HIP_CHECK(hipGetLastError());
         }

@@ -621,6 +621,144 @@ namespace gpuntt
 
     namespace host
     {
+        // ---- options and test hooks -------------------------------------------------------------------
+        // The library reads NO environment variable.  PRODUCT options (GPU_NTT_SetOption / gpuntt_set_option, listed in
+        // include/gpuntt/ntt_merge/ntt.cuh): path = default | generic | fast, check_4step_tables, rns_predict.  TEST HOOKS
+        // (set_test_hook / gpuntt_test_set_hook -- a symbol the public headers do not declare; csrc/test_hooks.h): path =
+        // fast-strict | generic-capped, no_scratch, rns_force_fallback, u32_e32.  Every public entry point opens a
+        // WorkspaceScope, and the outermost scope of a thread takes ONE snapshot of all of them: a call sees the same values
+        // from its first decision to its last launch, whatever another thread sets meanwhile.
+        namespace
+        {
+            struct OptionValues
+            {
+                int path = 0;               // 0 size heuristic, 1 generic, 2 fast, 3 fast-strict, 4 generic-capped
+                int no_scratch = 0;         // test hook: behave as if the twiddle scratch could not be allocated
+                int check_4step = 1;        // 4-step entry points: verify the caller's three tables on the device
+                int rns_predict = 1;        // drop-in RNS calls: enqueue only the lazy family the stack needed last time
+                int rns_force_fallback = 0; // test hook: the preparation kernel's own fall-back serves every drop-in RNS Merge call
+                int u32_e32 = 0xf000;       // test hook: 32-bit Merge rings on the 32-coefficients-per-lane kernels (bit n = ring 2^n)
+            };
+            std::mutex g_opt_mutex;
+            std::atomic<int> g_reset_predictions{0};   // test hook reset_predictions: consumed by the next rns_guess
+            OptionValues g_opt;                        // guarded by g_opt_mutex
+            std::atomic<unsigned> g_opt_generation{1}; // bumped by every successful set
+            thread_local OptionValues t_opt;           // this thread's snapshot ...
+            thread_local unsigned t_opt_generation = 0; // ... of this generation
+            thread_local int t_scope_depth = 0;         // WorkspaceScopes open on this thread
+
+            void refresh_snapshot()
+            {
+                const unsigned gen = g_opt_generation.load(std::memory_order_acquire);
+                if (gen != t_opt_generation)
+                {
+                    std::lock_guard<std::mutex> lock(g_opt_mutex);
+                    t_opt = g_opt;
+                    t_opt_generation = g_opt_generation.load(std::memory_order_relaxed);
+                }
+            }
+            // inside an API call: the snapshot its outermost WorkspaceScope took; outside (plan construction helpers, tests
+            // poking single functions): the current values
+            const OptionValues& options()
+            {
+                if (t_scope_depth == 0)
+                    refresh_snapshot();
+                return t_opt;
+            }
+
+            bool set_option_impl(const char* name, const char* value, bool test_hooks)
+            {
+                if (name == nullptr || value == nullptr)
+                    return false;
+                const std::string k(name), v(value);
+                // numeric values: the whole string must be a number of the option's documented set -- "abc" or "7" are
+                // refused (false), not silently turned into 0 / the default
+                char* end = nullptr;
+                const long lv = std::strtol(value, &end, 0);
+                const bool is_num = end != value && *end == '\0';
+                const int iv = static_cast<int>(lv);
+                const bool bit = is_num && (lv == 0 || lv == 1);
+                std::lock_guard<std::mutex> lock(g_opt_mutex);
+                if (k == "path")
+                {
+                    const int m = v == "generic" ? 1 : v == "fast" ? 2 : (v == "default" || v.empty()) ? 0
+                                  : (test_hooks && v == "fast-strict") ? 3 : (test_hooks && v == "generic-capped") ? 4 : -1;
+                    if (m < 0)
+                        return false;
+                    g_opt.path = m;
+                }
+                else if (k == "check_4step_tables" && bit)
+                    g_opt.check_4step = iv;
+                else if (k == "rns_predict" && bit)
+                    g_opt.rns_predict = iv;
+                else if (test_hooks && k == "no_scratch" && bit)
+                    g_opt.no_scratch = iv;
+                else if (test_hooks && k == "rns_force_fallback" && bit)
+                    g_opt.rns_force_fallback = iv;
+                else if (test_hooks && k == "u32_e32" && is_num && lv >= 0 && (lv & ~0xf000L) == 0)
+                    g_opt.u32_e32 = iv; // a mask over the rings 2^12 .. 2^15
+                else if (test_hooks && k == "reset_predictions" && bit)
+                    g_reset_predictions.store(1, std::memory_order_relaxed); // rns_guess forgets every stack it has seen
+                else
+                    return false;
+                g_opt_generation.fetch_add(1, std::memory_order_release);
+                return true;
+            }
+        } // namespace
+
+        bool set_option(const char* name, const char* value) { return set_option_impl(name, value, false); }
+        bool set_test_hook(const char* name, const char* value) { return set_option_impl(name, value, true); }
+        unsigned lazy_e32_mask() { return static_cast<unsigned>(options().u32_e32); }
+        int forced_path() { return options().path; }
+        static bool rns_predict_enabled() { return options().rns_predict != 0; }
+        static bool rns_force_fallback() { return options().rns_force_fallback != 0; }
+        bool check_4step_tables() { return options().check_4step != 0; }
+
+        // ---- launch log (test hook): which kernels did a call enqueue? -----------------------------------------------------
+        // Every kernel launch of the library goes through GPUNTT_LAUNCH (launch.hpp), which reports the kernel expression of
+        // its call site here.  Off (one relaxed load per launch) unless a test switched it on through
+        // gpuntt_test_launch_log_start(); the dispatch-table test (tests/test_gpu_dispatch_table.py) compares what a call
+        // enqueued with the row of DESIGN.md's table.
+        namespace
+        {
+            std::atomic<int> g_log_on{0};
+            std::mutex g_log_mutex;
+            std::vector<std::string> g_log;
+        } // namespace
+        void note_launch(const char* kernel_expr, int family)
+        {
+            if (g_log_on.load(std::memory_order_relaxed) == 0)
+                return;
+            std::string k(kernel_expr);
+            // "(kern::merge_pass_lazy<T, TLOG, ...>)" -> "merge_pass_lazy"
+            const size_t a = k.find("kern::");
+            if (a != std::string::npos)
+                k = k.substr(a + 6);
+            const size_t b = k.find_first_of("<)( ,");
+            if (b != std::string::npos)
+                k = k.substr(0, b);
+            if (family >= 0)
+                k += ":" + std::to_string(family);
+            std::lock_guard<std::mutex> lock(g_log_mutex);
+            g_log.push_back(k);
+        }
+        void launch_log_start()
+        {
+            std::lock_guard<std::mutex> lock(g_log_mutex);
+            g_log.clear();
+            g_log_on.store(1, std::memory_order_relaxed);
+        }
+        std::string launch_log_take()
+        {
+            std::lock_guard<std::mutex> lock(g_log_mutex);
+            g_log_on.store(0, std::memory_order_relaxed);
+            std::string out;
+            for (const std::string& e : g_log)
+                out += (out.empty() ? "" : " ") + e;
+            g_log.clear();
+            return out;
+        }
+
         namespace
         {
             // One scratch chain per (device, stream) for eager calls and one per (device, stream, capture) for calls made
@@ -642,7 +780,6 @@ namespace gpuntt
             using SlotKey = std::tuple<int, hipStream_t, unsigned long long>;
             std::mutex g_ws_mutex; // guards the map itself
             std::map<SlotKey, Slot> g_ws;
-            thread_local int t_scope_depth = 0;
             thread_local std::vector<std::recursive_mutex*> t_held;
 
             // 0: the stream is not being captured; else a key unique to the capture.  (The legacy default stream cannot be
@@ -716,7 +853,11 @@ namespace gpuntt
             };
         } // namespace
 
-        WorkspaceScope::WorkspaceScope() { ++t_scope_depth; }
+        WorkspaceScope::WorkspaceScope()
+        {
+            if (t_scope_depth++ == 0)
+                refresh_snapshot(); // the options this call runs under
+        }
         WorkspaceScope::~WorkspaceScope()
         {
             if (--t_scope_depth == 0)
@@ -803,6 +944,11 @@ namespace gpuntt
             if (hipGetDevice(&dev) != hipSuccess)
                 return gss;
             std::lock_guard<std::mutex> lock(g_guess_mutex);
+            if (g_reset_predictions.exchange(0, std::memory_order_relaxed) != 0)
+            {
+                g_guess.clear(); // (the host-mapped words stay: graphs captured earlier keep writing to theirs)
+                g_shape_hint.clear();
+            }
             GuessPool& pool = g_guess_pool[dev];
             if (pool.host == nullptr)
             {
@@ -898,76 +1044,6 @@ namespace gpuntt
             return static_cast<T>((static_cast<unsigned __int128>(1) << (W - 1 + b)) / q);
         }
 
-        // ---- tuning / test options --------------------------------------------------------------------
-        // The library reads NO environment variable: every switch below is a process-wide option set through
-        // set_option() (C ABI gpuntt_set_option; the Python harness forwards GPUNTT_* variables to it when it
-        // loads the library, which is how the A/B scripts under tools/ and the tests drive them).
-        namespace
-        {
-            struct Options
-            {
-                std::atomic<int> path{0};       // 0 size heuristic, 1 generic, 2 fast, 3 fast-strict, 4 generic-capped
-                std::atomic<int> no_scratch{0}; // test hook: behave as if the twiddle scratch could not be allocated
-                std::atomic<int> check_4step{1}; // 4-step entry points: verify the caller's three tables on the device (prep_merge_from_fourstep)
-                std::atomic<int> rns_predict{1}; // drop-in RNS calls: enqueue only the lazy family the stack needed last time
-                std::atomic<int> rns_force_fallback{0}; // test hook: the preparation kernel's own fall-back serves every drop-in RNS Merge call
-                std::atomic<int> u32_e32{0xf000}; // 32-bit Merge rings served by the 32-coefficients-per-lane kernels (bit n = ring 2^n)
-            } g_opt;
-        } // namespace
-
-        bool set_option(const char* name, const char* value)
-        {
-            if (name == nullptr || value == nullptr)
-                return false;
-            const std::string k(name), v(value);
-            // numeric values: the whole string must be a number of the option's documented set -- "abc", "7" for
-            // contig_k or "13" for u32_tile are refused (false), not silently turned into 0 / the default
-            char* end = nullptr;
-            const long lv = std::strtol(value, &end, 10);
-            const bool is_num = end != value && *end == '\0';
-            const int iv = static_cast<int>(lv);
-            auto one_of = [&](std::initializer_list<int> set) {
-                if (!is_num)
-                    return false;
-                for (int x : set)
-                    if (x == iv)
-                        return true;
-                return false;
-            };
-            if (k == "path")
-            {
-                const int m = v == "generic" ? 1 : v == "fast" ? 2 : v == "fast-strict" ? 3 : v == "generic-capped" ? 4
-                              : (v == "default" || v.empty()) ? 0 : -1;
-                if (m < 0)
-                    return false;
-                g_opt.path = m;
-            }
-            else if (k == "no_scratch" || k == "check_4step_tables" || k == "rns_predict" || k == "rns_force_fallback")
-            {
-                if (!one_of({0, 1}))
-                    return false;
-                std::atomic<int>& dst = k == "no_scratch"           ? g_opt.no_scratch
-                                        : k == "check_4step_tables" ? g_opt.check_4step
-                                        : k == "rns_force_fallback" ? g_opt.rns_force_fallback
-                                                                    : g_opt.rns_predict;
-                dst = iv;
-            }
-            else if (k == "u32_e32")
-            {
-                if (!is_num || lv < 0 || (lv & ~0xf000L) != 0)
-                    return false; // a mask over the rings 2^12 .. 2^15
-                g_opt.u32_e32 = iv;
-            }
-            else
-                return false;
-            return true;
-        }
-
-        unsigned lazy_e32_mask() { return static_cast<unsigned>(g_opt.u32_e32.load(std::memory_order_relaxed)); }
-        int forced_path() { return g_opt.path.load(std::memory_order_relaxed); }
-        static bool rns_predict_enabled() { return g_opt.rns_predict.load(std::memory_order_relaxed) != 0; }
-        static bool rns_force_fallback() { return g_opt.rns_force_fallback.load(std::memory_order_relaxed) != 0; }
-
         int lazy_contig_k(int n)
         {
             // The strided pass is HBM-bound with idle VALU slots while the contiguous pass is
@@ -979,11 +1055,9 @@ namespace gpuntt
             return 12;
         }
 
-        bool check_4step_tables() { return g_opt.check_4step.load(std::memory_order_relaxed) != 0; }
-
         void* lazy_workspace(hipStream_t stream, size_t bytes, bool or_null)
         {
-            if (or_null && g_opt.no_scratch.load(std::memory_order_relaxed) != 0)
+            if (or_null && options().no_scratch != 0)
                 return nullptr; // test hook: the out-of-memory fall-back of the drop-in entry points
             bool capturing = false;
             Slot& s = slot_of(stream, &capturing);
@@ -1067,7 +1141,7 @@ namespace gpuntt
                 if (sa.enabled && grid < want)
                     grid = static_cast<unsigned>(want);
             }
-            hipLaunchKernelGGL((kern::prep_twiddles<T>), dim3(grid), dim3(256), 0, stream, roots, ws, mods, q,
+            GPUNTT_LAUNCH((kern::prep_twiddles<T>), dim3(grid), dim3(256), 0, stream, roots, ws, mods, q,
                                (mods == nullptr) ? recip_norm_host<T>(q) : static_cast<T>(0), mod_count, n, negacyclic ? 1 : 0, perm_tile_log, ninv_arr, ws_ninv, go_flag, norm_arr, mod_order,
                                fold_ninv_single ? *fold_ninv_single : static_cast<T>(0),
                                (fold_ninv_single != nullptr || (fold_ninv_rns && ninv_arr != nullptr)) ? 1 : 0, host_state,
@@ -1083,7 +1157,7 @@ namespace gpuntt
         {
             const unsigned long long count = 1ull << (log_n1 + log_n2);
             const unsigned grid = static_cast<unsigned>((count + 255) / 256);
-            hipLaunchKernelGGL((kern::prep_merge_from_fourstep<T>), dim3(grid), dim3(256), 0, stream, n1_table, w_table, ws,
+            GPUNTT_LAUNCH((kern::prep_merge_from_fourstep<T>), dim3(grid), dim3(256), 0, stream, n1_table, w_table, ws,
                                log_n1, log_n2, perm_tile_log, inverse ? 1 : 0, fold ? 1 : 0, q,
                                mods ? static_cast<T>(0) : recip_norm_host<T>(q), ninv, mods, ninv_dev, ws_ninv,
                                veto.word != nullptr ? nullptr : go_flag, norm_arr, host_state,
@@ -1104,7 +1178,7 @@ namespace gpuntt
         {
             if (count == 0)
                 return;
-            hipLaunchKernelGGL((kern::debug_recip_norm<T>), dim3(static_cast<unsigned>((count + 255) / 256)), dim3(256), 0, stream, q,
+            GPUNTT_LAUNCH((kern::debug_recip_norm<T>), dim3(static_cast<unsigned>((count + 255) / 256)), dim3(256), 0, stream, q,
                                out, count);
             GPUNTT_HIP_CHECK(hipGetLastError());
         }

@@ -12,6 +12,7 @@
 #include "gpuntt/common/common.cuh"
 #include "gpuntt/common/modular_arith.cuh"
 #include "gpuntt/common/parameter_sets.hpp"
+#include "launch.hpp"
 
 namespace gpuntt
 {
@@ -88,7 +89,7 @@ namespace gpuntt
             throw std::invalid_argument("Invalid table size!");
         const Squares<T> sq = make_squares<T>(base, modulus);
         const unsigned count = 1u << log_count;
-        hipLaunchKernelGGL((power_table<T>), dim3((count + 255u) / 256u), dim3(256), 0, stream, device_out, sq, modulus,
+        GPUNTT_LAUNCH((power_table<T>), dim3((count + 255u) / 256u), dim3(256), 0, stream, device_out, sq, modulus,
                            log_count, bit_reversed ? 1 : 0);
         GPUNTT_HIP_CHECK(hipGetLastError());
     }
@@ -106,7 +107,7 @@ namespace gpuntt
             throw std::invalid_argument("Invalid ntt_type!");
         const int log_n1 = l1[n_power - 12], log_n2 = n_power - log_n1;
         const Squares<T> sq = make_squares<T>(root, modulus);
-        hipLaunchKernelGGL((fourstep_w_table<T>), dim3((1u << n_power) / 256u), dim3(256), 0, stream, device_W, sq,
+        GPUNTT_LAUNCH((fourstep_w_table<T>), dim3((1u << n_power) / 256u), dim3(256), 0, stream, device_W, sq,
                            modulus, log_n1, log_n2, ntt_type == INVERSE ? 1 : 0);
         GPUNTT_HIP_CHECK(hipGetLastError());
     }

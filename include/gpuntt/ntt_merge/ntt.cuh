@@ -219,22 +219,20 @@ namespace gpuntt
     // so call this only when no such graph will be replayed again and no call is in flight.
     void GPU_NTT_ReleaseWorkspaces();
 
-    // Process-wide test / behaviour options (extension).  The library reads no environment variable.  name = value:
-    //   path           default | generic | fast | fast-strict | generic-capped   kernel family forced for every call
-    //                            (fast-strict: a call the fast kernels cannot take throws; test hook)
-    //   no_scratch     0 | 1     test hook: the drop-in calls behave as if their twiddle scratch could not be allocated
-    //                            (they run on the generic kernels, which need none)
+    // Process-wide behaviour options (extension).  The library reads no environment variable.  name = value:
+    //   path           default | generic | fast   kernel family for every call: the size heuristic, the element-by-element
+    //                            Barrett kernels, or the fast (lazy-residue) kernels wherever they can take the call
     //   check_4step_tables 0 | 1   4-step entry points / FourStepPlan: verify all three caller tables on the device and run
     //                            the element-by-element kernels when they are not the tables of one root
     //                            (ntt_4step/ntt_4step.cuh, "TABLES"); default 1
     //   rns_predict    0 | 1     drop-in RNS calls enqueue only the lazy kernel family predicted for their stack of moduli (same
     //                            device, moduli pointer, mod_count, direction); a stack that family cannot serve is transformed
-    //                            by the preparation kernel itself (default 1); 0: every family behind the go-flag on every call
-    //   rns_force_fallback 0 | 1 test hook: that fall-back serves every drop-in RNS Merge call (default 0)
-    // (The A/B switches of rounds 1-4 -- contig_k, xcd_order, lim31, reverse, u64_big_tiles, u32_tile, u32_ring13_batch -- are
-    // retired: their measurements are in profiles/, the library keeps the settings that won.)
+    //                            by the preparation kernel itself -- or, on rings from 2^17, by the generic kernels enqueued
+    //                            behind a call nothing is known about yet (default 1); 0: every family behind the go-flag
+    // An API call reads the options ONCE, when it starts: setting one from another thread never changes a call in flight.
     // Returns false for an unknown name or a value outside the sets above (the whole string must parse; nothing is silently
-    // mapped to a default).  Plans keep the choice made when they were created.
+    // mapped to a default).  Plans keep the choice made when they were created.  (The hooks this repository's tests use --
+    // forced failure paths, retired A/B switches -- are not options: gpu-ntt_amd/csrc/test_hooks.h.)
     bool GPU_NTT_SetOption(const char* name, const char* value);
 
 } // namespace gpuntt

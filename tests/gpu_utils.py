@@ -130,3 +130,61 @@ def find_ntt_factors(bits, logn, skip=0, clear_of_top=False):
         if pow(psi, 1 << logn, q) == q - 1:
             return q, psi * psi % q, psi
         g += 1
+
+
+def distinct_factors(widths, logn):
+    seen, out = {}, []
+    for b in widths:
+        out.append(find_ntt_factors(b, logn, skip=seen.get(b, 0), clear_of_top=True))
+        seen[b] = seen.get(b, 0) + 1
+    return out
+
+
+def distinct_factors_scaled(widths, logn):
+    """distinct NTT primes of the given widths with (q, omega, psi) for a ring of 2^logn.  Searched for 2^max(logn, 12) and
+    brought down by squaring psi: the topmost primes = 1 mod 2^(logn + 1) of a small ring lie within double rounding of
+    the power of two, get an over-stated `bit` and (61 -> 62) a mu that does not fit the word (Modulus refuses them)."""
+    out, seen = [], set()
+    lg = max(logn, 12)
+    for w in widths:
+        skip = 0
+        while True:
+            q, _, psi = find_ntt_factors(w, lg, skip)
+            if q not in seen:
+                break
+            skip += 1
+        seen.add(q)
+        psi = pow(psi, 1 << (lg - logn), q)
+        assert pow(psi, 1 << logn, q) == q - 1
+        out.append((q, psi * psi % q, psi))
+    return out
+
+
+def rns_stack(g, bits, logn, widths, poly):
+    cases = [MergeCase(g, bits, logn, poly, f) for f in distinct_factors(widths, logn)]
+    n, mc = 1 << logn, len(cases)
+    fwd = np.zeros(mc * n, dtype=cases[0].P.T)
+    inv = np.zeros_like(fwd)
+    for i, c in enumerate(cases):
+        fwd[i * n:i * n + c.prm.root_of_unity_size] = c.prm.forward_table_device_order
+        inv[i * n:i * n + c.prm.root_of_unity_size] = c.prm.inverse_table_device_order
+    return cases, g.to_device(fwd), g.to_device(inv)
+
+
+def cpu_class_on_tables(P, oprm, tabs, x_dev_layout, batch, inverse, n_inv):
+    """What the reference's CPU class makes of a GPU_4STEP_NTT call with these (device-order) tables: NTT_4STEP_CPU::ntt /
+    ::intt on the same tables in natural order (oracle: Port.fourstep_ntt_tables, pinned to the reference build with its
+    public table vectors overwritten -- tests/test_oracle_vs_reference.py), between the example programs' transposes
+    (test_4step_ntt.cu:90-178, test_4step_intt.cu:81-179), returned in the layout the GPU call writes (n1 x n2)."""
+    n, n1, n2 = oprm["n"], oprm["n1"], oprm["n2"]
+    t1 = P.bitrev_table(np.ascontiguousarray(tabs[0][:n1 >> 1]))  # the kernels read the first n1/2 (n2/2) words
+    t2 = P.bitrev_table(np.ascontiguousarray(tabs[1][:n2 >> 1]))
+    out = np.empty_like(x_dev_layout)
+    for p in range(batch):
+        a = x_dev_layout[p * n:(p + 1) * n]
+        # forward: the call reads the n2 x n1 transpose of the natural-order polynomial; inverse: what
+        # intt_first_transpose made of the spectrum
+        nat = np.ascontiguousarray(a.reshape(n1, n2).T if inverse else a.reshape(n2, n1).T).reshape(-1)
+        r = P.fourstep_ntt_tables(nat, oprm, t1, t2, tabs[2], inverse, n_inv=n_inv if inverse else None)
+        out[p * n:(p + 1) * n] = np.ascontiguousarray(r.reshape(n2, n1).T).reshape(-1)  # undo the closing GPU_Transpose
+    return out

@@ -159,10 +159,39 @@ def test_options_replace_environment_switches(g):
     for name, value in (("path", "sideways"), ("no_such_option", "1"), ("rns_predict", "yes"), ("rns_predict", "2"),
                         ("no_scratch", ""), ("check_4step_tables", "1x"), ("q59", "1"), ("contig_k", "11"), ("xcd_order", "0"),
                         ("lim31", "0"), ("reverse", "0"), ("u64_big_tiles", "13"), ("u32_tile", "12"), ("u32_ring13_batch", "0"),
-                        ("validate_4step_tables", "1")):
+                        ("validate_4step_tables", "1"),
+                        # the test hooks are NOT options of the public interface: gpuntt_set_option
+                        # refuses them, gpuntt_test_set_hook (csrc/test_hooks.h) takes them
+                        ("path", "fast-strict"), ("path", "generic-capped"), ("no_scratch", "1"), ("rns_force_fallback", "1"),
+                        ("u32_e32", "0")):
         assert lib.gpuntt_set_option(name.encode(), value.encode()) != 0, (name, value)
     assert lib.gpuntt_set_option(None, None) != 0
+    for name, value in (("path", "fast-strict"), ("path", "default"), ("no_scratch", "1"), ("no_scratch", "0"),
+                        ("rns_force_fallback", "0"), ("u32_e32", "0xf000"), ("u32_e32", "61440"), ("check_4step_tables", "1")):
+        assert lib.gpuntt_test_set_hook(name.encode(), value.encode()) == 0, (name, value)
+    for name, value in (("u32_e32", "0x10000"), ("u32_e32", "abc"), ("no_scratch", "2"), ("path", "sideways")):
+        assert lib.gpuntt_test_set_hook(name.encode(), value.encode()) != 0, (name, value)
+    # the public headers do not advertise the hooks
+    import glob
+    for h in glob.glob(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "**", "*"), recursive=True):
+        if os.path.isfile(h):
+            assert "gpuntt_test_" not in open(h).read(), h
+    # the launch log: nothing launched, nothing logged
+    with g.launch_log() as log:
+        pass
+    assert log.kernels == []
     import subprocess
     out = subprocess.run("strings -a %s | grep -c '^GPUNTT_[A-Z0-9_]*$'" % g.LIB_PATH, shell=True, capture_output=True,
                          text=True).stdout.strip()
     assert out in ("", "0"), "the library still carries GPUNTT_* environment variable names"
+
+
+def test_dispatch_table_in_design_md_is_the_tested_table():
+    """DESIGN.md 3.8 carries the table `python tests/dispatch_rows.py --markdown` prints (tests/test_gpu_dispatch_table.py
+    walks the same rows on the GPU)"""
+    from dispatch_rows import ROWS, markdown
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "DESIGN.md")).read()
+    for line in markdown().splitlines():
+        assert line in text, "DESIGN.md 3.8 is out of date: run python tests/dispatch_rows.py --markdown\n" + line
+    assert len({r["id"] for r in ROWS}) == len(ROWS) and all(r["launches"] and r["serves"] for r in ROWS)
