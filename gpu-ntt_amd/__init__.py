@@ -100,10 +100,11 @@ EXPORTED_SYMBOLS = ["gpuntt_last_error", "gpuntt_version"] + [
 
 # GPUNTT_* environment variables of the A/B scripts and tests -> library options.  The C++ library reads no
 # environment variable; this harness forwards them once, when it loads the library.
-ENV_OPTIONS = {"GPUNTT_PATH": ("path", None), "GPUNTT_U32_E32": ("u32_e32", lambda v: int(v, 0))}
+ENV_OPTIONS = {"GPUNTT_PATH": ("path", None), "GPUNTT_U32_E32": ("u32_e32", lambda v: int(v, 0)),
+               "GPUNTT_TWO_SWEEP_BIG": ("two_sweep_big", None)}
 
 
-TEST_HOOKS = {"no_scratch", "rns_force_fallback", "u32_e32", "reset_predictions"}
+TEST_HOOKS = {"no_scratch", "rns_force_fallback", "u32_e32", "reset_predictions", "two_sweep_big"}
 TEST_PATHS = {"fast-strict", "generic-capped"}
 
 

@@ -31,6 +31,10 @@ namespace gpuntt
         // largest ring (log2) that 64-bit calls may transform inside one big tile
         constexpr int lazy_u64_big_tiles() { return 14; }
 
+        // EXPERIMENT kept behind a test hook (two_sweep_big; rounds 5 and 6): 64-bit rings 2^23 / 2^24, forward, in TWO sweeps --
+        // one strided pass of 9 / 10 stages and the 14-stage contiguous pass, both on 16384-coefficient tiles -- instead of
+        // three.  Bit-exact, a third less traffic, and no faster: profiles/r06_two_sweep_big_pmc.txt names the limiter.
+        bool lazy_two_sweep_big();
         // 32-bit ring 2^13: every call takes the 8192-coefficient tile
         constexpr unsigned long long lazy_u32_small_batch() { return 0x7fffffffull; }
         // `inverse` and `polys` (transforms in the call) must be the same wherever one call asks:
@@ -54,6 +58,8 @@ namespace gpuntt
                 if (n == 21 && big >= 13)
                     return 13;
                 if (n == 22 && big >= 14)
+                    return 14;
+                if ((n == 23 || n == 24) && !inverse && lazy_two_sweep_big())
                     return 14;
                 // (2^23 / 2^24 in two sweeps -- a strided pass of 9 / 10 stages + the 14-stage contiguous pass on
                 // 16384-coefficient tiles -- was built and measured in round 5: bit-exact, -0.8 % at 2^24 x 64, +3 % at
@@ -321,7 +327,7 @@ namespace gpuntt
         }
 
         // pass list for the fast kernels: like make_plan but with the tile size as a parameter
-        inline Plan make_plan_tl(int n, int tl, int contig_k)
+        inline Plan make_plan_tl(int n, int tl, int contig_k, int max_strided = 8)
         {
             Plan pl{};
             pl.count = 0;
@@ -335,7 +341,7 @@ namespace gpuntt
             if (contig_k < tl - 4)
                 contig_k = tl - 4;
             const int s = n - contig_k;
-            const int np = (s + 7) / 8;
+            const int np = (s + max_strided - 1) / max_strided;
             int top = n;
             for (int i = 0; i < np; i++)
             {
@@ -405,6 +411,8 @@ namespace gpuntt
         inline int fourstep_fwd_tile(int n_power, int log_n1, unsigned long long polys, int lim, int& k1)
         {
             int tl = lim != 0 ? 12 : lazy_tile_log<T>(n_power, false, polys);
+            if (sizeof(T) == 8 && n_power >= 23)
+                tl = 12; // (the two-sweep experiment of the Merge rings 2^23 / 2^24 does not extend to the 4-step form)
             k1 = fourstep_first_k(n_power, log_n1, tl);
             if (tl == 14 && n_power > tl && n_power - k1 < 13)
             {
@@ -544,7 +552,10 @@ namespace gpuntt
                 a.flags |= first_in_flags | last_out_flags;
                 return launch_small_rns_lazy<T, INV>(base.n, a, stream);
             }
-            const Plan pl = make_plan_tl(pn, tl, tl == 12 ? (partial ? lazy_contig_k(pn) : lazy_contig_k_merge<T>(pn, INV)) : tl);
+            // (64-bit rings 2^23 / 2^24 on 16384-coefficient tiles, experiment: ONE strided pass of 9 / 10 stages)
+            const bool big2 = sizeof(T) == 8 && tl == 14 && pn >= 23 && !partial;
+            const Plan pl = make_plan_tl(pn, tl, tl == 12 ? (partial ? lazy_contig_k(pn) : lazy_contig_k_merge<T>(pn, INV)) : tl,
+                                         big2 ? 10 : 8);
             const void* src = base.in;
             int fwd_bound = partial ? 16 : 1; // range bound of the values in flight (forward, 31 q range: see fwd_bound_after)
             for (int i = 0; i < pl.count; i++)
@@ -569,7 +580,7 @@ namespace gpuntt
                 if (((pl.count - 1 - i) & 1) != 0 && lazy_reverse_passes())
                     a.flags |= kern::F_REVERSE;
                 // 64-bit: only the contiguous pass runs on a big tile
-                const int tlp = (sizeof(T) == 8 && !p.contig) ? 12 : tl;
+                const int tlp = (sizeof(T) == 8 && !p.contig && p.k <= 8) ? 12 : tl;
                 // rings from 2^20: the per-lane twiddles of a contiguous pass are tens of MiB per
                 // polynomial -- poly-minor block order lets a batch share them through L2
                 const unsigned long long polys = base.total >> base.n;

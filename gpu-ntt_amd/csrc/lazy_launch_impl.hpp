@@ -55,6 +55,16 @@ namespace gpuntt
                             GPUNTT_ONE(true, TLOG, 1, false);
                     }
                 }
+                // EXPERIMENT (test hook two_sweep_big): the single strided pass of 9 / 10 stages in front of the 14-stage
+                // contiguous pass (rings 2^23 / 2^24, forward): rows of 32 / 16 coefficients = 256 / 128-byte runs
+                if constexpr (TLOG == 14 && !INV)
+                    if (!p.contig && in_first && !last)
+                    {
+                        if (p.k == 9)
+                            GPUNTT_ONE(false, 9, 1, false);
+                        if (p.k == 10)
+                            GPUNTT_ONE(false, 10, 1, false);
+                    }
                 throw std::invalid_argument("internal: unsupported 64-bit big-tile pass");
             }
             else
@@ -504,7 +514,7 @@ namespace gpuntt
         {
             if (tile_log == 12)
                 return dispatch_tl<T, 12, INV>(p, in_first, last, a, stream);
-            if (tile_log == 14 && (sizeof(T) == 4 || p.contig))
+            if (tile_log == 14 && (sizeof(T) == 4 || p.contig || p.k > 8))
                 return dispatch_tl<T, 14, INV>(p, in_first, last, a, stream);
             // 8192-coefficient tile: 64-bit contiguous passes (2^13, 2^21); 32-bit: the single pass of the ring 2^13
             if (tile_log == 13 && p.contig)

@@ -8,7 +8,7 @@ void launch_pass_lazy31(const Pass& p, int tile_log, bool in_first, bool last, c
         return dispatch_tl<uint64_t, 12, false, 31>(p, in_first, last, a, stream);
     if (tile_log == 13 && p.contig)
         return dispatch_tl<uint64_t, 13, false, 31>(p, in_first, last, a, stream);
-    if (tile_log == 14 && p.contig)
+    if (tile_log == 14 && (p.contig || p.k > 8))
         return dispatch_tl<uint64_t, 14, false, 31>(p, in_first, last, a, stream);
     throw std::invalid_argument("internal: unsupported tile size in the fast path");
 }

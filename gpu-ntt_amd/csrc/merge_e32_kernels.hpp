@@ -119,7 +119,17 @@ namespace gpuntt
                         {
                             const int j0 = (h & ((1 << jb) - 1)) | ((h >> jb) << (jb + 1));
                             const int j1 = j0 | (1 << jb);
-                            const lazy::GsPlan pl = lazy::gs_plan(b[j0], b[j1], LIMIT);
+                            lazy::GsPlan pl = lazy::gs_plan(b[j0], b[j1], LIMIT);
+#ifndef GPUNTT_E32_GS_CSUB_ONLY
+                            // ko = -1: the sum is corrected by the quotient estimate (Mod32::reduce_2q: -> [0, 2q)) where a
+                            // conditional subtraction would only halve its bound -- 8 q range: a sum of two 4 q values every
+                            // SECOND stage of a run of sums instead of every stage
+                            if (pl.ko > 2)
+                            {
+                                pl.ko = -1;
+                                pl.out_u = 2;
+                            }
+#endif
                             d.ku[r][s][h] = pl.ku;
                             d.kv[r][s][h] = pl.kv;
                             d.c[r][s][h] = pl.c;
@@ -410,8 +420,10 @@ namespace gpuntt
                     {
                         constexpr int ko = SCH::d.ko[r][s][h];
                         T S = U + V;
-                        if constexpr (ko != 0)
+                        if constexpr (ko > 0)
                             S = m.template csub<ko>(S);
+                        if constexpr (ko < 0)
+                            S = m.reduce_2q(S);
                         u = S;
                     }
                     x = m.template mul<UNI>(U + m.kq(c) - V, w);

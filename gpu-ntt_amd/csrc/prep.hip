@@ -638,6 +638,7 @@ namespace gpuntt
                 int rns_predict = 1;        // drop-in RNS calls: enqueue only the lazy family the stack needed last time
                 int rns_force_fallback = 0; // test hook: the preparation kernel's own fall-back serves every drop-in RNS Merge call
                 int u32_e32 = 0xf000;       // test hook: 32-bit Merge rings on the 32-coefficients-per-lane kernels (bit n = ring 2^n)
+                int two_sweep_big = 0;      // test hook (experiment): 64-bit rings 2^23 / 2^24 forward in two sweeps on 16384-coefficient tiles
             };
             std::mutex g_opt_mutex;
             std::atomic<int> g_reset_predictions{0};   // test hook reset_predictions: consumed by the next rns_guess
@@ -697,6 +698,8 @@ namespace gpuntt
                     g_opt.rns_force_fallback = iv;
                 else if (test_hooks && k == "u32_e32" && is_num && lv >= 0 && (lv & ~0xf000L) == 0)
                     g_opt.u32_e32 = iv; // a mask over the rings 2^12 .. 2^15
+                else if (test_hooks && k == "two_sweep_big" && bit)
+                    g_opt.two_sweep_big = iv;
                 else if (test_hooks && k == "reset_predictions" && bit)
                     g_reset_predictions.store(1, std::memory_order_relaxed); // rns_guess forgets every stack it has seen
                 else
@@ -710,6 +713,7 @@ namespace gpuntt
         bool set_test_hook(const char* name, const char* value) { return set_option_impl(name, value, true); }
         unsigned lazy_e32_mask() { return static_cast<unsigned>(options().u32_e32); }
         int forced_path() { return options().path; }
+        bool lazy_two_sweep_big() { return options().two_sweep_big != 0; }
         static bool rns_predict_enabled() { return options().rns_predict != 0; }
         static bool rns_force_fallback() { return options().rns_force_fallback != 0; }
         bool check_4step_tables() { return options().check_4step != 0; }
@@ -790,11 +794,12 @@ namespace gpuntt
                     return 0ull;
                 hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
                 unsigned long long id = 0;
-                if (hipStreamGetCaptureInfo(stream, &st, &id) != hipSuccess)
-                {
-                    (void) hipGetLastError();
-                    return 0ull;
-                }
+                // A query that FAILS leaves "is this call being captured?" unknown, and guessing "no" would put a captured call
+                // on the eager chain: its epoch baked into the graph, no memset node for the veto word, its kernels replayed
+                // over the eager calls' scratch.  The call cannot be served safely: it throws.
+                GPUNTT_HIP_CHECK(hipStreamGetCaptureInfo(stream, &st, &id));
+                if (st == hipStreamCaptureStatusInvalidated)
+                    throw std::invalid_argument("the stream's capture has been invalidated");
                 return st == hipStreamCaptureStatusActive ? (id | (1ull << 63)) : 0ull;
             }
 
