@@ -807,6 +807,115 @@ namespace gpuntt
             return true;
         }
 
+        // ---- dispatch of the two GPU_4STEP_NTT overloads ------------------------------------------------------------------
+        // DESIGN.md 3.8 is this function as a table (tests/dispatch_rows.py; walked on the GPU by
+        // tests/test_gpu_dispatch_table.py).  A ROUTE enqueues the fast kernels that can take the call and answers one
+        // question: what, if anything, has to sit behind them?
+        //   nothing   the fast kernels serve the call whatever the preparation kernel finds (they are their own fall-back up
+        //             to 2^16, 2^17 forward), or the caller opted out of the table check, or a test hook asked for it
+        //   generic   the element-by-element kernels (fourstep_run), skipped on the device unless the call's go-flag says
+        //             the fast kernels did not take it (table check vetoed; modulus of another family than predicted)
+        struct Behind
+        {
+            bool generic = true;              // enqueue fourstep_run at all
+            const unsigned* flag = nullptr;   // device word it tests (nullptr: runs unconditionally)
+            unsigned skip_value = 0u;         // 0: return when *flag != GO_GENERIC; s: return when *flag == s (PassArgs::skip_value)
+            bool skip_phase1 = false;         // the fast first kernel already did the n1-point phase of a vetoed call
+            static Behind nothing() { return Behind{false, nullptr, 0u, false}; }
+        };
+        template <typename T> struct FourStepCall
+        {
+            T *in, *out;
+            const T *n1_table, *n2_table, *w_table;
+            const Modulus<T>* mods; // device-side modulus (RNS overload) or nullptr
+            Modulus<T> mod;         // host-side modulus
+            int mod_count;
+            const T* ninv_arr;
+            T ninv;
+            int n_power, l1, l2;
+            bool inverse;
+            int batch_size;
+            hipStream_t stream;
+        };
+
+        // test hook path = generic-capped, RNS overload with one modulus: the generic kernels exactly as they run behind a
+        // go-flag that names them (capped grid walking the tiles)
+        template <typename T> Behind route_generic_capped(const FourStepCall<T>& c)
+        {
+            auto* flag = static_cast<unsigned*>(host::lazy_workspace(c.stream, 16));
+            GPUNTT_HIP_CHECK(hipMemsetAsync(flag, 0, 16, c.stream));
+            return Behind{true, flag, 0u, false};
+        }
+
+        // RNS overload, ONE modulus in device memory (the reference examples' calling style, test_4step_ntt.cu:126-146): the
+        // lazy family this modulus needed last time (host::RnsGuess; unknown: every family), the preparation kernel
+        // classifies the modulus, checks the tables and publishes the go-flag
+        template <typename T> Behind route_device_modulus(const FourStepCall<T>& c)
+        {
+            const host::FourStepVeto veto = fourstep_veto<T>(c.l1, c.l2, c.stream);
+            const host::RnsGuess guess = host::rns_guess(c.mods, 1, static_cast<int>(sizeof(T)) | 0x40, c.inverse, nullptr,
+                                                         true); // (0x40: the 4-step entry keeps its own prediction slot)
+            const bool only_default = !guess.all_families && guess.state == kern::GO_LAZY;
+            const unsigned* flag = nullptr;
+            int self_fb = 0; // what the default family's kernels can do themselves: 2 everything, 1 the n1-point phase
+            auto enqueue = [&](int family, const unsigned** flag_out) {
+                // only_default: the ONE family enqueued for the call -- its kernels may be their own fall-back
+                int* self = (family == 0 && only_default) ? &self_fb : nullptr;
+                if (!c.inverse)
+                    return fourstep_run_lazy<T, false>(c.in, c.out, c.n1_table, c.n2_table, c.w_table, Modulus<T>(), T(0), c.n_power,
+                                                       c.l1, c.l2, c.batch_size, c.stream, c.mods, c.ninv_arr, flag_out, PlanUse<T>(),
+                                                       family, guess.state_out, veto, self, self != nullptr);
+                return fourstep_run_lazy<T, true>(c.in, c.out, c.n1_table, c.n2_table, c.w_table, Modulus<T>(), T(0), c.n_power, c.l1,
+                                                  c.l2, c.batch_size, c.stream, c.mods, c.ninv_arr, flag_out, PlanUse<T>(), family,
+                                                  guess.state_out, veto, self, self != nullptr);
+            };
+            // the first enqueue prepares the table and publishes the flag; with it the default family unless another is predicted
+            enqueue((guess.all_families || only_default) ? 0 : -1, &flag);
+            if (flag == nullptr)
+                return Behind{}; // no scratch / path = generic: the generic kernels are the call
+            if (self_fb == 2)
+                return Behind::nothing();
+            if constexpr (sizeof(T) == 8)
+                for (int fam : {8, 4})
+                    if (guess.all_families || guess.state == (fam == 8 ? kern::GO_LAZY_8Q : kern::GO_LAZY_4Q))
+                        enqueue(fam, nullptr);
+            if (host::forced_path() == 3)
+                return Behind::nothing(); // test hook fast-strict: the lazy families must own the call
+            Behind b{true, flag, 0u, self_fb == 1};
+            if (!guess.all_families)
+            {
+                // ONE family in front: the generic kernels run for every state but that family's (GO_GENERIC predicted: always)
+                if (guess.state == kern::GO_GENERIC)
+                    b.flag = nullptr;
+                else
+                    b.skip_value = guess.state;
+            }
+            return b;
+        }
+
+        // host-side modulus: the host picks the family; only the table check can take the call away from it
+        template <typename T> Behind route_host_modulus(const FourStepCall<T>& c)
+        {
+            const host::FourStepVeto veto = fourstep_veto<T>(c.l1, c.l2, c.stream);
+            int self_fb = 0;
+            const bool done =
+                !c.inverse ? fourstep_run_lazy<T, false>(c.in, c.out, c.n1_table, c.n2_table, c.w_table, c.mod, c.ninv, c.n_power, c.l1,
+                                                         c.l2, c.batch_size, c.stream, nullptr, nullptr, nullptr, PlanUse<T>(), 0, nullptr,
+                                                         veto, &self_fb)
+                           : fourstep_run_lazy<T, true>(c.in, c.out, c.n1_table, c.n2_table, c.w_table, c.mod, c.ninv, c.n_power, c.l1,
+                                                        c.l2, c.batch_size, c.stream, nullptr, nullptr, nullptr, PlanUse<T>(), 0, nullptr,
+                                                        veto, &self_fb);
+            if (!done)
+            {
+                if (host::forced_path() == 3) // test hook, like the Merge entry points
+                    throw std::invalid_argument("fast path unavailable for this call (path = fast-strict)");
+                return Behind{}; // modulus outside the fast kernels' domain, tiny job, no scratch, path = generic
+            }
+            if (!veto.check || host::forced_path() == 3 || self_fb == 2)
+                return Behind::nothing();
+            return Behind{true, veto.flag(), 0u, self_fb == 1}; // "return unless the state is GO_GENERIC"
+        }
+
         template <typename T>
         void fourstep_dispatch(T* in, T* out, const T* n1_table, const T* n2_table, const T* w_table,
                                const Modulus<T>* mods, Modulus<T> mod, int mod_count,
@@ -824,93 +933,22 @@ namespace gpuntt
                 return;
             if ((static_cast<unsigned long long>(batch_size) << n_power) >> kern::TL > 0x7fffffffull)
                 throw std::invalid_argument("batch_size * N too large for one launch");
-            const unsigned* skip_flag = nullptr;
-            bool skip_phase1 = false; // the fast first kernel does phase 1 itself when vetoed (kern::F_SELF_FALLBACK)
-            int self_fb = 0;          // device-side modulus: what fourstep_run_lazy reports for the default family's kernels
-            host::RnsGuess guess{kern::GO_LAZY, true, nullptr};
-            if (mods != nullptr && mod_count == 1 && host::forced_path() == 4)
-            {
-                // test hook: the generic kernels as they run behind a go-flag that says "yours" (what a
-                // 61/62-bit modulus produces) -- capped grid walking the tiles, flag word = 0
-                auto* flag = static_cast<unsigned*>(host::lazy_workspace(stream, 16));
-                GPUNTT_HIP_CHECK(hipMemsetAsync(flag, 0, 16, stream));
-                skip_flag = flag;
-            }
-            else if (mods != nullptr && mod_count == 1)
-            {
-                // one device-side modulus: the lazy family this modulus needed last time (host::RnsGuess) -- or every family
-                // -- and the generic kernels behind the go-flag.  The flag is the call's veto word: the preparation kernel
-                // also checks the caller's tables and hands the call to the generic kernels when they are not the tables of
-                // one root (prep.hip)
-                const host::FourStepVeto veto = fourstep_veto<T>(l1, l2, stream);
-                guess = host::rns_guess(mods, 1, static_cast<int>(sizeof(T)) | 0x40, ntt_type == INVERSE, nullptr, true); // (0x40: the 4-step entry keeps its own slot)
-                const bool only_default = !guess.all_families && guess.state == kern::GO_LAZY;
-                auto enqueue = [&](int family, const unsigned** flag_out) {
-                    // only_default: this is the ONE family enqueued for the call -- its kernels may be their own fall-back
-                    int* self = (family == 0 && only_default) ? &self_fb : nullptr;
-                    if (ntt_type == FORWARD)
-                        return fourstep_run_lazy<T, false>(in, out, n1_table, n2_table, w_table, Modulus<T>(), T(0), n_power, l1, l2,
-                                                           batch_size, stream, mods, ninv_arr, flag_out, PlanUse<T>(), family,
-                                                           guess.state_out, veto, self, self != nullptr);
-                    return fourstep_run_lazy<T, true>(in, out, n1_table, n2_table, w_table, Modulus<T>(), T(0), n_power, l1, l2,
-                                                      batch_size, stream, mods, ninv_arr, flag_out, PlanUse<T>(), family,
-                                                      guess.state_out, veto, self, self != nullptr);
-                };
-                // the first enqueue prepares the table and publishes the flag; with it the default family unless another
-                // one is predicted
-                enqueue((guess.all_families || only_default) ? 0 : -1, &skip_flag);
-                if (self_fb == 2 && skip_flag != nullptr)
-                    return; // the default family's kernels serve whatever the preparation kernel finds
-                skip_phase1 = (self_fb == 1 && skip_flag != nullptr);
-                if constexpr (sizeof(T) == 8)
-                {
-                    if (skip_flag != nullptr)
-                        for (int fam : {8, 4})
-                            if (guess.all_families || guess.state == (fam == 8 ? kern::GO_LAZY_8Q : kern::GO_LAZY_4Q))
-                                enqueue(fam, nullptr);
-                }
-            }
-            if (mods != nullptr && mod_count == 1 && skip_flag != nullptr && host::forced_path() == 3)
-                return; // test hook (path = fast-strict): no generic shadow launches -- the lazy families must own the call
-            if (mods == nullptr)
-            {
-                // host-side modulus: the fast kernels, and -- unless option check_4step_tables is off -- the generic
-                // kernels behind the veto word, which run only when the table check took the call away from them
-                const host::FourStepVeto veto = fourstep_veto<T>(l1, l2, stream);
-                int self_fallback = 0;
-                const bool done =
-                    (ntt_type == FORWARD)
-                        ? fourstep_run_lazy<T, false>(in, out, n1_table, n2_table, w_table, mod, ninv, n_power, l1, l2, batch_size,
-                                                      stream, nullptr, nullptr, nullptr, PlanUse<T>(), 0, nullptr, veto,
-                                                      &self_fallback)
-                        : fourstep_run_lazy<T, true>(in, out, n1_table, n2_table, w_table, mod, ninv, n_power, l1, l2, batch_size,
-                                                     stream, nullptr, nullptr, nullptr, PlanUse<T>(), 0, nullptr, veto,
-                                                     &self_fallback);
-                if (done && (!veto.check || host::forced_path() == 3 || self_fallback == 2))
-                    return; // (fast-strict: test hook, no generic shadow launches; 2: the fast kernels are their own fall-back)
-                if (done)
-                {
-                    skip_flag = veto.flag(); // all families = "return unless the state is GO_GENERIC"
-                    skip_phase1 = (self_fallback == 1);
-                }
-                else if (host::forced_path() == 3) // test hook, like the Merge entry points
-                    throw std::invalid_argument("fast path unavailable for this call (path = fast-strict)");
-            }
-            // behind lazy families: "return if one of them owns the call" (merge_kernels.hpp: PassArgs::skip_value)
-            unsigned skip_value = 0u;
-            if (skip_flag != nullptr && !guess.all_families)
-            {
-                if (guess.state == kern::GO_GENERIC)
-                    skip_flag = nullptr;
-                else
-                    skip_value = guess.state;
-            }
+            const FourStepCall<T> c{in, out, n1_table, n2_table, w_table, mods, mod, mod_count, ninv_arr, ninv, n_power, l1, l2,
+                                    ntt_type == INVERSE, batch_size, stream};
+            // overload x modulus location -> route (mod_count > 1 shares one set of tables between its moduli like the
+            // reference, ntt_4step.cu:81-82, 111-114: only the element-by-element kernels compute that)
+            const Behind behind = (mods == nullptr)                                     ? route_host_modulus<T>(c)
+                                  : (mod_count == 1 && host::forced_path() == 4)        ? route_generic_capped<T>(c)
+                                  : (mod_count == 1)                                    ? route_device_modulus<T>(c)
+                                                                                        : Behind{};
+            if (!behind.generic)
+                return;
             if (ntt_type == FORWARD)
-                fourstep_run<T, false>(in, out, n1_table, n2_table, w_table, mods, mod, mod_count,
-                                       ninv_arr, ninv, n_power, l1, l2, batch_size, stream, skip_flag, skip_value, skip_phase1);
+                fourstep_run<T, false>(in, out, n1_table, n2_table, w_table, mods, mod, mod_count, ninv_arr, ninv, n_power, l1, l2,
+                                       batch_size, stream, behind.flag, behind.skip_value, behind.skip_phase1);
             else
-                fourstep_run<T, true>(in, out, n1_table, n2_table, w_table, mods, mod, mod_count,
-                                      ninv_arr, ninv, n_power, l1, l2, batch_size, stream, skip_flag, skip_value, skip_phase1);
+                fourstep_run<T, true>(in, out, n1_table, n2_table, w_table, mods, mod, mod_count, ninv_arr, ninv, n_power, l1, l2,
+                                      batch_size, stream, behind.flag, behind.skip_value, behind.skip_phase1);
         }
     } // namespace
 
