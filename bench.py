@@ -979,6 +979,9 @@ def main():
     ap.add_argument("--cpu-polys", type=int, default=64)
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)  # PMC child pass: calls only
     ap.add_argument("--other-configs", action="store_true", help=argparse.SUPPRESS)  # with --child: the other configs' pass
+    ap.add_argument("--no-shard-overheads", action="store_true",
+                    help="c4: do not time the 1024-polynomial shard through the three call forms (kernel-trace runs: keeps the "
+                         "per-kernel average about whole-batch launches)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="default run (c2 forward, 1 GPU): do not time the other BASELINE configs beside the headline")
     ap.add_argument("--sweep", action="store_true",
@@ -1165,7 +1168,7 @@ def main():
                 line["power"] = power
             if e2e is not None:
                 line["end_to_end"] = e2e
-            if args.config == "c4":
+            if args.config == "c4" and not args.no_shard_overheads:
                 try:
                     line["shard_of_8_gpus_call_overheads"] = c4_shard_overheads(g, cfg, dev)
                 except Exception as e:  # informational only

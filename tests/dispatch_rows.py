@@ -131,11 +131,29 @@ ROWS = [
 ]
 
 
+SHORT = {"prep_twiddles": "prep", "prep_merge_from_fourstep": "prep4", "merge_pass_lazy": "lazy", "merge_ring_e32": "e32",
+         "merge_pass_lazy_vqc": "vqc", "merge_pass": "generic", "fourstep_small_lazy": "fs_small", "fourstep_first_lazy": "fs_first",
+         "fourstep_inv_first_lazy": "fs_inv_first"}
+
+
+def short(kernels):
+    """launch list in the table's shorthand: kernel template names abbreviated (SHORT), repeats as x2"""
+    out = []
+    for k in kernels:
+        name, _, fam = k.partition(":")
+        k = SHORT.get(name, name) + (":" + fam if fam else "")
+        if out and out[-1][0] == k:
+            out[-1][1] += 1
+        else:
+            out.append([k, 1])
+    return " ".join("`%s`%s" % (k, "" if c == 1 else "x%d" % c) for k, c in out)
+
+
 def markdown():
     out = ["| row | options / hooks | launches enqueued, in order | serves the call |", "|---|---|---|---|"]
     for r in ROWS:
         hooks = ", ".join("%s=%s" % kv for kv in r.get("hooks", {}).items()) or "-"
-        out.append("| %s | %s | %s | %s |" % (r["id"], hooks, " ".join("`%s`" % k for k in r["launches"]), r["serves"]))
+        out.append("| %s | %s | %s | %s |" % (r["id"], hooks, short(r["launches"]), r["serves"]))
     return "\n".join(out)
 
 

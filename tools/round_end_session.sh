@@ -19,7 +19,7 @@ python bench.py --config c5 --steps 20 --warmup 5 > "$O/bench_line_c5.json" 2> "
 # per-kernel averages (rocprofv3 --kernel-trace --stats) of the C2, C3 and C4 bench commands
 for cfg in c2 c3 c4; do
   extra="--steps 100 --warmup 10"; [ $cfg = c3 ] && extra="--steps 5 --warmup 2"
-  (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d "$O/kt_$cfg" -o kt -- python "$R/bench.py" --config $cfg $extra --no-traffic --no-cpu-baseline --no-power --no-other-configs > /dev/null 2>&1)
+  (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d "$O/kt_$cfg" -o kt -- python "$R/bench.py" --config $cfg $extra --no-traffic --no-cpu-baseline --no-power --no-other-configs --no-shard-overheads > /dev/null 2>&1)
   python tools/rocprof_summary.py "$O/kt_$cfg" > "$O/${cfg}_kernel_stats.txt" 2>&1
   rm -rf "$O/kt_$cfg"
 done
