@@ -92,9 +92,16 @@ namespace gpuntt
         // lazy_tile_log.  The prepared table of a tile is the same for both geometries.
         unsigned lazy_e32_mask();
         template <bool INV> void launch_ring_e32(int n, int lim, const kern::LazyArgsT<uint32_t>& a, hipStream_t stream);
+        // the same geometry as the contiguous pass of a larger ring's plan (tile_log stages on a 4096- / 16384-coefficient tile:
+        // forward the last pass, inverse the first); mask bit 16 of u32_e32
+        template <bool INV> void launch_tile_e32(int tile_log, int lim, const kern::LazyArgsT<uint32_t>& a, hipStream_t stream);
         template <typename T> inline int lazy_tile_log_merge(int n, bool inverse = false, unsigned long long polys = 0)
         {
             if (sizeof(T) == 4 && n == 15 && ((lazy_e32_mask() >> 15) & 1u) != 0u)
+                return 15;
+            // 32-bit ring 2^23: one strided pass of 8 stages (16384-coefficient tiles) + the 15-stage contiguous pass on the
+            // 32768-coefficient tile of the second geometry = TWO sweeps instead of three
+            if (sizeof(T) == 4 && n == 23 && ((lazy_e32_mask() >> 16) & 1u) != 0u)
                 return 15;
             return lazy_tile_log<T>(n, inverse, polys);
         }
@@ -530,9 +537,9 @@ namespace gpuntt
             const int pn = (!INV && low_stages > 0) ? low_stages : base.n;
             const bool partial = pn != base.n;
             // 32-bit rings that fill their tile: the 32-coefficients-per-lane kernels (one polynomial per block).  A table
-            // laid out for the 32768-coefficient tile has no other kernel; GPU_PolyMul's fused product keeps the old ones
+            // laid out for the 32768-coefficient tile has no other kernel
             if constexpr (sizeof(T) == 4)
-                if (!partial && base.n == tl && tl >= 12 && tl <= 15 && base.mul_in == nullptr &&
+                if (!partial && base.n == tl && tl >= 12 && tl <= 15 &&
                     (tl == 15 || ((lazy_e32_mask() >> tl) & 1u) != 0u) && (base.total & ((1ull << tl) - 1ull)) == 0ull)
                 {
                     kern::LazyArgsT<uint32_t> a = base;
@@ -580,7 +587,8 @@ namespace gpuntt
                 if (((pl.count - 1 - i) & 1) != 0 && lazy_reverse_passes())
                     a.flags |= kern::F_REVERSE;
                 // 64-bit: only the contiguous pass runs on a big tile
-                const int tlp = (sizeof(T) == 8 && !p.contig && p.k <= 8) ? 12 : tl;
+                // (32-bit plans on the 32768-coefficient tile: their strided pass runs on 16384-coefficient tiles)
+                const int tlp = (sizeof(T) == 8 && !p.contig && p.k <= 8) ? 12 : (sizeof(T) == 4 && tl == 15 && !p.contig) ? 14 : tl;
                 // rings from 2^20: the per-lane twiddles of a contiguous pass are tens of MiB per
                 // polynomial -- poly-minor block order lets a batch share them through L2
                 const unsigned long long polys = base.total >> base.n;
@@ -588,6 +596,19 @@ namespace gpuntt
                            (polys << base.n) == base.total)
                               ? static_cast<int>(polys)
                               : 0;
+                if constexpr (sizeof(T) == 4)
+                {
+                    // the full-tile contiguous pass of a 32-bit plan (forward: last, on lazy input; inverse: first) on the
+                    // 32-coefficients-per-lane geometry (GPU_PolyMul's fused product included)
+                    const bool edge = INV ? (i == 0 && pl.count > 1) : (i == pl.count - 1 && pl.count > 1);
+                    if (p.contig && p.k == tlp && (tlp == 12 || tlp == 14 || tlp == 15) && edge && !partial &&
+                        (tlp == 15 || ((lazy_e32_mask() >> 16) & 1u) != 0u))
+                    {
+                        launch_tile_e32<INV>(tlp, base.lim, a, stream);
+                        src = base.out;
+                        continue;
+                    }
+                }
                 if constexpr (sizeof(T) == 8)
                 {
                     if (base.lim == 8)

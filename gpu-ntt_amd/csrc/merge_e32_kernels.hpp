@@ -53,7 +53,7 @@ namespace gpuntt
 
         // ---- compile-time schedules of the range corrections ----------------------------------------------------------
         // forward: every register carries the same bound (both outputs of a Cooley-Tukey butterfly have bound U + TB)
-        template <int TLOG, int LIMIT, int TB> struct EFwdSched
+        template <int TLOG, int LIMIT, int TB, int IN_BOUND = 1> struct EFwdSched
         {
             struct Data
             {
@@ -63,7 +63,7 @@ namespace gpuntt
             static constexpr Data make()
             {
                 Data d{};
-                int b = 1;
+                int b = IN_BOUND;
                 for (int s = 0; s < TLOG; s++)
                 {
                     // ku > 0: conditional subtraction of ku * q; ku = -1: quotient estimate (Mod32::reduce_2q: any word ->
@@ -166,8 +166,12 @@ namespace gpuntt
             lazy::Tw32 a, b;
         };
 
-        // One tile = one polynomial.  grid = polynomials of the call.
-        template <int TLOG, bool INV, int LIM>
+        // PART = false: one tile = one polynomial (ring 2^TLOG), grid = polynomials of the call.
+        // PART = true: the tile is one of the 2^(n - TLOG) tiles of a LARGER ring and the kernel is the contiguous pass of its
+        // plan -- forward: the last pass (TLOG stages on lazy input below LIMIT q from the strided passes, canonical output);
+        // inverse: the first pass (canonical input, lazy output below LIMIT / 2 for the strided passes behind it, no n^-1).
+        // Blocks in merge_pass_lazy's order (poly-minor from 2^20, consecutive passes in opposite directions).
+        template <int TLOG, bool INV, int LIM, bool PART = false>
         __global__ __launch_bounds__(ETile<TLOG>::NT, 4) void merge_ring_e32(LazyArgsT<uint32_t> a)
         {
             using T = uint32_t;
@@ -176,29 +180,54 @@ namespace gpuntt
             using G = ETile<TLOG>;
             constexpr int NT = G::NT, NA = G::NA, WLA = G::WLA;
             constexpr int NT16 = 1 << (TLOG - 4); // "threads" of the prepared layout's permutation (16-coefficient groups)
+            constexpr bool LAST = !(PART && INV);       // canonical output
+            constexpr bool CANON_IN = !(PART && !INV);  // canonical input
             __shared__ __attribute__((aligned(16))) T lds[G::LDS_ELEMS];
 
             if (not_my_call<T, LIM>(a.go_flag, a.flags))
                 return;
             const int t = threadIdx.x;
             const unsigned tu = threadIdx.x; // lane part of every global address: one 32-bit offset beside a uniform base
-            const unsigned poly = blockIdx.x;
-            T qv = a.q;
+            const int n = PART ? a.n : TLOG;
+            unsigned poly = blockIdx.x, tip = 0u; // polynomial and tile inside it
+            if constexpr (PART)
+            {
+                const unsigned bx = (a.flags & F_REVERSE) ? (gridDim.x - 1u - blockIdx.x) : blockIdx.x;
+                const int tiles_log = n - TLOG;
+                if (a.batch > 1)
+                    poly_minor_order(bx, static_cast<unsigned>(a.batch), tiles_log, poly, tip, a.flags);
+                else
+                {
+                    poly = bx >> tiles_log;
+                    tip = bx & ((1u << tiles_log) - 1u);
+                }
+                poly = uniform32(poly);
+                tip = uniform32(tip);
+            }
+            T qv = a.q, qbit = a.q_bit, qmu = a.q_mu;
             int mi = 0;
             if (a.mods != nullptr)
             {
                 mi = static_cast<int>(uniform32(poly % static_cast<unsigned>(a.mod_count)));
-                qv = a.mods[a.mod_order != nullptr ? a.mod_order[mi] : mi].value;
+                const Modulus<T> md = a.mods[a.mod_order != nullptr ? a.mod_order[mi] : mi];
+                qv = md.value;
+                qbit = md.bit;
+                qmu = md.mu;
             }
             M m;
             m.set(qv, (a.norm_arr != nullptr) ? a.norm_arr[mi] : a.norm);
-            const TW* __restrict__ tw = a.tw + (static_cast<unsigned long long>(mi) << TLOG);
-            const __amdgpu_buffer_rsrc_t rtw = make_rsrc(tw, sizeof(TW) << TLOG);
+            const TW* __restrict__ tw = a.tw + (static_cast<unsigned long long>(mi) << n);
+            const __amdgpu_buffer_rsrc_t rtw = make_rsrc(tw, static_cast<unsigned>(sizeof(TW)) << n);
+            // first slot of the tile's twiddles of the stage at tile bit p: stage slots [2^(n-1-p), 2^(n-p)), 2^(TLOG-1-p) per tile
+            auto sbase = [&](int p) -> unsigned { return (1u << (n - 1 - p)) + (tip << (TLOG - 1 - p)); };
             const unsigned slot_poly = (a.poly_order != nullptr) ? static_cast<unsigned>(a.poly_order[poly]) : poly;
-            const unsigned long long base = static_cast<unsigned long long>(uniform32(slot_poly)) << TLOG;
+            const unsigned long long base =
+                (static_cast<unsigned long long>(uniform32(slot_poly)) << n) + (static_cast<unsigned long long>(tip) << TLOG);
             // (src may alias dst: the whole tile is read before any store)
             const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(static_cast<const T*>(a.in) + base, sizeof(T) << TLOG);
             const __amdgpu_buffer_rsrc_t rdst = make_rsrc(a.out + base, sizeof(T) << TLOG);
+            constexpr int POL_IN = CANON_IN ? BUF_NT : 0; // the hand-off between two passes should stay in the caches
+            constexpr int POL_OUT = LAST ? BUF_NT : 0;
             auto tw_pair = [&](unsigned voff, unsigned slot) -> TW {
                 const u32x2 x = __builtin_amdgcn_raw_buffer_load_b64(rtw, static_cast<int>(voff), static_cast<int>(slot * 8u), 0);
                 return TW{x.x, x.y};
@@ -217,23 +246,23 @@ namespace gpuntt
                 constexpr int FIRST = decltype(first_)::value, COUNT = decltype(count_)::value;
                 const unsigned g = tu >> 5;
                 if constexpr (FIRST == 0)
-                    w[0] = tw_pair(g << 3, 1u << (TLOG - 10));
+                    w[0] = tw_pair(g << 3, sbase(9));
                 static_for<COUNT - (FIRST == 0 ? 1 : 0)>([&](auto s_) {
                     constexpr int s = decltype(s_)::value + (FIRST == 0 ? 1 : FIRST); // stage p = 9 - s, 2^s pairs
                     constexpr int p = 9 - s;
                     const unsigned voff = g << (s + 3);
                     static_for<(1 << s) / 2>([&](auto k_) {
                         constexpr int k = decltype(k_)::value;
-                        tw_two(voff, (1u << (TLOG - 1 - p)) + 2u * k, w[(1 << s) - 1 + 2 * k], w[(1 << s) - 1 + 2 * k + 1]);
+                        tw_two(voff, sbase(p) + 2u * k, w[(1 << s) - 1 + 2 * k], w[(1 << s) - 1 + 2 * k + 1]);
                     });
                 });
             };
             // round C, stage p = 4 .. 0 (2^(4-p) pairs each): p = 4, 3 natural slots; p <= 2 the [k][16-coefficient group]
             // permutation of prep.hip -- entry (group 2t + h, k) at k * NT16 + 2t + h, i.e. ONE 16-byte load per k
             auto load_tw_c = [&](TW(&w)[E32 - 1]) {
-                w[0] = tw_pair(tu << 3, 1u << (TLOG - 5));
+                w[0] = tw_pair(tu << 3, sbase(4));
                 const unsigned voff = tu << 4;
-                tw_two(voff, 1u << (TLOG - 4), w[1], w[2]);
+                tw_two(voff, sbase(3), w[1], w[2]);
                 static_for<3>([&](auto s_) {
                     constexpr int p = 2 - decltype(s_)::value; // 2, 1, 0
                     constexpr int RP = 16 >> (p + 1);          // entries per 16-coefficient group: 2, 4, 8
@@ -241,7 +270,7 @@ namespace gpuntt
                     static_for<RP>([&](auto k_) {
                         constexpr int k = decltype(k_)::value;
                         // group 2t: twiddle index m = k; group 2t + 1: m = RP + k
-                        tw_two(voff, (1u << (TLOG - 1 - p)) + static_cast<unsigned>(k) * NT16, w[O + k], w[O + RP + k]);
+                        tw_two(voff, sbase(p) + static_cast<unsigned>(k) * NT16, w[O + k], w[O + RP + k]);
                     });
                 });
             };
@@ -251,13 +280,13 @@ namespace gpuntt
 
             if constexpr (!INV)
             {
-                using SCH = EFwdSched<TLOG, M::LIMIT, M::TB>;
+                using SCH = EFwdSched<TLOG, M::LIMIT, M::TB, CANON_IN ? 1 : M::LIMIT>;
                 // ---- round A: coalesced loads, block-uniform twiddles ---------------------------------------------------
 #pragma unroll
                 for (int j = 0; j < E32; j++)
-                    v[j] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, static_cast<int>(tu << 2), j << (WLA + 2), BUF_NT);
+                    v[j] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, static_cast<int>(tu << 2), j << (WLA + 2), POL_IN);
                 load_tw_b(twv, std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
-                if (a.flags & F_SIGNED_IN)
+                if (CANON_IN && (a.flags & F_SIGNED_IN) != 0u)
                 {
 #pragma unroll
                     for (int j = 0; j < E32; j++)
@@ -282,9 +311,9 @@ namespace gpuntt
                         constexpr int h = decltype(h_)::value;
                         constexpr int j0 = (h & ((1 << jb) - 1)) | ((h >> jb) << (jb + 1));
                         constexpr int j1 = j0 | (1 << jb);
-                        const TW w = tw[(1 << s) + (j0 >> (jb + 1))]; // scalar load (uniform address)
+                        const TW w = tw[sbase(TLOG - 1 - s) + (j0 >> (jb + 1))]; // scalar load (uniform address)
                         // first stage of a cyclic transform: table[0] = omega^0 = 1 (uniform test; V is canonical there)
-                        const bool unit = (s == 0) ? (w.w == 1u) : false;
+                        const bool unit = (s == 0 && !PART) ? (w.w == 1u) : false;
                         ct(std::integral_constant<int, s>{}, std::true_type{}, v[j0], v[j1], w, unit);
                     });
                 });
@@ -361,11 +390,21 @@ namespace gpuntt
                 {
                     const unsigned e0 = (static_cast<unsigned>(t >> 6) << 11) + 4u * (static_cast<unsigned>(t) & 63u);
                     const T* lo = lds + epad(static_cast<int>(e0));
+                    const T* mul_in = a.mul_in; // (uniform; the operand lies at the memory slot of the tile, like the output)
+                    const dev::ModCtx<T> em{qv, qbit, qmu};
+                    const __amdgpu_buffer_rsrc_t rmul = make_rsrc(mul_in != nullptr ? mul_in + base : static_cast<const T*>(a.in) + base,
+                                                                  sizeof(T) << TLOG);
 #pragma unroll
                     for (int i = 0; i < E32 / 4; i++)
                     {
-                        const u32x4 x = *reinterpret_cast<const u32x4*>(lo + 288 * i); // epad(256 i) = 288 i
-                        __builtin_amdgcn_raw_buffer_store_b128(x, rdst, static_cast<int>(e0 << 2), 1024 * i, BUF_NT);
+                        u32x4 x = *reinterpret_cast<const u32x4*>(lo + 288 * i); // epad(256 i) = 288 i
+                        if (mul_in != nullptr)
+                        {
+                            // GPU_PolyMul: the pointwise product with the other operand's transform rides on the final store
+                            const u32x4 o = __builtin_amdgcn_raw_buffer_load_b128(rmul, static_cast<int>(e0 << 2), 1024 * i, 0);
+                            x = u32x4{em.mul(x.x, o.x), em.mul(x.y, o.y), em.mul(x.z, o.z), em.mul(x.w, o.w)};
+                        }
+                        __builtin_amdgcn_raw_buffer_store_b128(x, rdst, static_cast<int>(e0 << 2), 1024 * i, POL_OUT);
                     }
                 }
             }
@@ -385,7 +424,7 @@ namespace gpuntt
                     u32x4 x[E32 / 4];
 #pragma unroll
                     for (int i = 0; i < E32 / 4; i++)
-                        x[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, static_cast<int>(e0 << 2), 1024 * i, BUF_NT);
+                        x[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, static_cast<int>(e0 << 2), 1024 * i, POL_IN);
                     load_tw_c(twv);
                     T* lo = lds + epad(static_cast<int>(e0));
 #pragma unroll
@@ -488,18 +527,22 @@ namespace gpuntt
                         constexpr int h = decltype(h_)::value;
                         constexpr int j0 = (h & ((1 << jb) - 1)) | ((h >> jb) << (jb + 1));
                         constexpr int j1 = j0 | (1 << jb);
-                        const TW w = tw[(1 << (TLOG - 1 - p)) + (j0 >> (jb + 1))];
+                        const TW w = tw[sbase(p) + (j0 >> (jb + 1))];
                         gs(std::integral_constant<int, 2>{}, s_, h_, std::true_type{},
-                           std::integral_constant<bool, s == NA - 1>{}, v[j0], v[j1], w);
+                           std::integral_constant<bool, LAST && s == NA - 1>{}, v[j0], v[j1], w);
                     });
                 });
-                const bool centred = (a.flags & F_CENTERED) != 0u;
+                const bool centred = LAST && (a.flags & F_CENTERED) != 0u;
                 static_for<E32>([&](auto j_) {
                     constexpr int j = decltype(j_)::value;
-                    T x = lazy::normalize<M::TB>(m, v[j]);
-                    if (centred)
-                        x = (x > (m.q >> 1)) ? (x - m.q) : x;
-                    __builtin_amdgcn_raw_buffer_store_b32(x, rdst, static_cast<int>(tu << 2), j << (WLA + 2), BUF_NT);
+                    T x = v[j]; // PART: lazy hand-over, below LIMIT / 2 (sums corrected to it, products below 2 q)
+                    if constexpr (LAST)
+                    {
+                        x = lazy::normalize<M::TB>(m, x);
+                        if (centred)
+                            x = (x > (m.q >> 1)) ? (x - m.q) : x;
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b32(x, rdst, static_cast<int>(tu << 2), j << (WLA + 2), POL_OUT);
                 });
             }
         }

@@ -637,7 +637,8 @@ namespace gpuntt
                 int check_4step = 1;        // 4-step entry points: verify the caller's three tables on the device
                 int rns_predict = 1;        // drop-in RNS calls: enqueue only the lazy family the stack needed last time
                 int rns_force_fallback = 0; // test hook: the preparation kernel's own fall-back serves every drop-in RNS Merge call
-                int u32_e32 = 0xf000;       // test hook: 32-bit Merge rings on the 32-coefficients-per-lane kernels (bit n = ring 2^n)
+                int u32_e32 = 0x1f000;      // test hook: 32-bit Merge rings on the 32-coefficients-per-lane kernels (bit n = ring 2^n; bit 16: the
+                                            // full-tile contiguous pass of larger rings)
                 int two_sweep_big = 0;      // test hook (experiment): 64-bit rings 2^23 / 2^24 forward in two sweeps on 16384-coefficient tiles
             };
             std::mutex g_opt_mutex;
@@ -696,8 +697,8 @@ namespace gpuntt
                     g_opt.no_scratch = iv;
                 else if (test_hooks && k == "rns_force_fallback" && bit)
                     g_opt.rns_force_fallback = iv;
-                else if (test_hooks && k == "u32_e32" && is_num && lv >= 0 && (lv & ~0xf000L) == 0)
-                    g_opt.u32_e32 = iv; // a mask over the rings 2^12 .. 2^15
+                else if (test_hooks && k == "u32_e32" && is_num && lv >= 0 && (lv & ~0x1f000L) == 0)
+                    g_opt.u32_e32 = iv; // a mask over the rings 2^12 .. 2^15; bit 16: the contiguous pass of larger rings
                 else if (test_hooks && k == "two_sweep_big" && bit)
                     g_opt.two_sweep_big = iv;
                 else if (test_hooks && k == "reset_predictions" && bit)

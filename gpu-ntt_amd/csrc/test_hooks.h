@@ -6,7 +6,8 @@
  *       path = generic-capped    the generic kernels of an RNS call on the capped grid they use behind a go-flag
  *       no_scratch = 0 | 1       the drop-in calls behave as if their twiddle scratch could not be allocated
  *       rns_force_fallback = 0|1 the preparation kernel's own fall-back serves every drop-in RNS Merge call
- *       u32_e32 = mask           32-bit Merge rings 2^12 .. 2^15 on the 32-coefficients-per-lane kernels (bit n = ring 2^n)
+ *       u32_e32 = mask           32-bit Merge rings 2^12 .. 2^15 on the 32-coefficients-per-lane kernels (bit n = ring 2^n;
+ *                                bit 16: the full-tile contiguous pass of larger rings)
  *       two_sweep_big = 0 | 1    experiment: 64-bit rings 2^23 / 2^24 forward in two sweeps on 16384-coefficient tiles
  *       reset_predictions = 1    the family prediction of the RNS overloads forgets every stack it has seen
  *   gpuntt_test_launch_log_start()      start recording the kernel of every launch the library enqueues (all threads)

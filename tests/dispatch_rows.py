@@ -54,6 +54,10 @@ ROWS = [
          launches=["prep_twiddles", "merge_ring_e32:8"], serves="e32:8"),
     dict(id="merge u32 2^16 pool fwd", entry="merge", bits=32, logn=16, batch=4, modulus="pool",
          launches=["prep_twiddles", "merge_pass_lazy:8", "merge_pass_lazy:8"], serves="lazy:8"),
+    dict(id="merge u32 2^20 pool fwd (contiguous pass on 32 coefficients per lane)", entry="merge", bits=32, logn=20, batch=2,
+         modulus="pool", launches=["prep_twiddles", "merge_pass_lazy:8", "merge_ring_e32:8"], serves="lazy:8+e32:8"),
+    dict(id="merge u32 2^23 pool inv (two sweeps)", entry="merge", bits=32, logn=23, batch=2, modulus="pool", inverse=True,
+         launches=["prep_twiddles", "merge_ring_e32:8", "merge_pass_lazy:8"], serves="e32:8+lazy:8"),
     dict(id="merge u64 2^16 pool, no_scratch", entry="merge", bits=64, logn=16, batch=4, modulus="pool",
          hooks={"no_scratch": "1"}, launches=["merge_pass", "merge_pass"], serves="generic"),
     # ------------------------------------------------------------------ Merge, RNS overload (moduli on the device)

@@ -63,7 +63,7 @@ def _set_hooks(g, hooks):
 
 
 def _unset_hooks(g, hooks):
-    defaults = {"path": "default", "no_scratch": "0", "rns_force_fallback": "0", "u32_e32": "0xf000", "rns_predict": "1",
+    defaults = {"path": "default", "no_scratch": "0", "rns_force_fallback": "0", "u32_e32": "0x1f000", "rns_predict": "1",
                 "check_4step_tables": "1"}
     for k in hooks:
         g.set_option(k, defaults[k])

@@ -11,8 +11,8 @@ from test_gpu_merge import _rns_setup, _small_prime_factors
 
 pytestmark = pytest.mark.gpu
 
-ALL_RINGS = 0xF000  # bits 12 .. 15
-DEFAULT = 0xF000
+ALL_RINGS = 0x1F000  # bits 12 .. 15: the one-tile rings; bit 16: the full-tile contiguous pass of larger rings
+DEFAULT = 0x1F000
 
 
 @pytest.fixture(scope="module")
@@ -41,6 +41,38 @@ def test_every_ring_both_directions(g, mask, poly):
                 assert np.array_equal(c.gpu_inverse(y, inplace=inplace), x), (logn, factors, batch, "inv")
                 z = c.random(batch, 77 + logn)
                 assert np.array_equal(c.gpu_inverse(z, inplace=not inplace), oracle_batch([c], z, inverse=True))
+
+
+@pytest.mark.parametrize("logn,batch", [(16, 3), (18, 3), (19, 2), (20, 3), (21, 2), (22, 2), (23, 3), (24, 1)])
+def test_contiguous_pass_of_larger_rings(g, mask, logn, batch):
+    """Rings above one tile: the full-tile contiguous pass of the plan (forward: the last pass, on lazy input from the
+    strided passes; inverse: the first, handing lazy values on) runs on the 32-coefficients-per-lane geometry where the
+    plan's contiguous pass fills its tile (4096-coefficient tiles: 2^18, 2^19, 2^24; 16384: 2^20 .. 2^22; 32768: 2^23, which
+    becomes TWO sweeps; 2^16 keeps a 9-stage pass on the 16-coefficient kernels) -- both lazy families, a stack of three
+    primes, both directions."""
+    import torch
+    # (no 30-bit prime is 1 mod 2^25: the 4 q family stops at 2^23)
+    for factors in ((None, find_ntt_factors(30, logn)) if logn <= 23 else (None,)):
+        c = MergeCase(g, 32, logn, O.X_N_plus, factors)
+        x = c.random(batch, 31 * logn + batch)
+        y = c.gpu_forward(x, inplace=True)
+        assert np.array_equal(y, oracle_batch([c], x)), (logn, factors, "fwd")
+        assert np.array_equal(c.gpu_inverse(y, inplace=False), x), (logn, factors, "inv")
+    if logn <= 20:
+        P = O.Port(32)
+        mc = 3
+        cases, fwd, inv, mods, ninv = _rns_setup(g, 32, logn, O.X_N_minus, _small_prime_factors(P, logn, mc))
+        n = 1 << logn
+        b = 4
+        x = np.concatenate([cases[p % mc].P.splitmix(70 + p, 0, n, cases[p % mc].q) for p in range(b)])
+        d = g.to_device(x)
+        g.GPU_NTT_Inplace(d, fwd, mods, g.ntt_rns_configuration(n_power=logn, reduction_poly=O.X_N_minus), b, mc)
+        torch.cuda.synchronize()
+        assert np.array_equal(g.to_host(d), oracle_batch(cases, x)), (logn, "rns fwd")
+        g.GPU_INTT_Inplace(d, inv, mods, g.ntt_rns_configuration(n_power=logn, ntt_type=g.INVERSE, reduction_poly=O.X_N_minus,
+                                                                   mod_inverse=ninv), b, mc)
+        torch.cuda.synchronize()
+        assert np.array_equal(g.to_host(d), x), (logn, "rns inv")
 
 
 def test_edge_values(g, mask):
@@ -121,21 +153,22 @@ def test_rns_stack_and_ordered_entry_points(g, mask):
             assert np.array_equal(g.to_host(o), wo), ("mod-ordered", logn, poly)
 
 
-def test_polymul_keeps_working(g, mask):
-    # GPU_PolyMul fuses the pointwise product into the forward store of the 16-coefficient kernels: the e32 dispatch
-    # must leave it alone
+def test_polymul_product_rides_on_the_final_store(g, mask):
+    # GPU_PolyMul fuses the pointwise product into the forward transform's final store: one-tile rings, a ring whose last
+    # pass is the full-tile contiguous pass (2^20), and the two-sweep ring 2^23 on the 32768-coefficient tile
     import torch
-    c = MergeCase(g, 32, 14, O.X_N_plus)
-    n, q = c.n, c.q
-    a, b = c.random(2, 5), c.random(2, 6)
-    fa, fb = oracle_batch([c], a), oracle_batch([c], b)
-    prod = (fa.astype(object) * fb.astype(object) % q).astype(c.P.T)
-    want = oracle_batch([c], prod, inverse=True)
-    da, db = g.to_device(a), g.to_device(b)
-    out = torch.zeros_like(da)
-    g.GPU_PolyMul(da, db, out, c.fwd_dev, c.inv_dev, c.prm.modulus, c.cfg(True), 2)
-    torch.cuda.synchronize()
-    assert np.array_equal(g.to_host(out), want)
+    for logn, batch in ((14, 2), (15, 2), (20, 2), (23, 1)):
+        c = MergeCase(g, 32, logn, O.X_N_plus)
+        q = c.q
+        a, b = c.random(batch, 5 + logn), c.random(batch, 6 + logn)
+        fa, fb = oracle_batch([c], a), oracle_batch([c], b)
+        prod = (fa.astype(np.uint64) * fb.astype(np.uint64) % np.uint64(q)).astype(c.P.T)
+        want = oracle_batch([c], prod, inverse=True)
+        da, db = g.to_device(a), g.to_device(b)
+        out = torch.zeros_like(da)
+        g.GPU_PolyMul(da, db, out, c.fwd_dev, c.inv_dev, c.prm.modulus, c.cfg(True), batch)
+        torch.cuda.synchronize()
+        assert np.array_equal(g.to_host(out), want), logn
 
 
 def test_plan_keeps_its_tile_when_the_option_changes(g):
@@ -184,7 +217,7 @@ def test_every_polynomial_of_a_full_chip_batch(g):
 
 def test_option_refuses_rings_outside_the_geometry(g):
     with pytest.raises(Exception):
-        g.set_option("u32_e32", 1 << 16)
+        g.set_option("u32_e32", 1 << 17)
     with pytest.raises(Exception):
         g.set_option("u32_e32", "abc")
     g.set_option("u32_e32", DEFAULT)

@@ -169,7 +169,7 @@ def test_options_replace_environment_switches(g):
     for name, value in (("path", "fast-strict"), ("path", "default"), ("no_scratch", "1"), ("no_scratch", "0"),
                         ("rns_force_fallback", "0"), ("u32_e32", "0xf000"), ("u32_e32", "61440"), ("check_4step_tables", "1")):
         assert lib.gpuntt_test_set_hook(name.encode(), value.encode()) == 0, (name, value)
-    for name, value in (("u32_e32", "0x10000"), ("u32_e32", "abc"), ("no_scratch", "2"), ("path", "sideways")):
+    for name, value in (("u32_e32", "0x20000"), ("u32_e32", "abc"), ("no_scratch", "2"), ("path", "sideways")):
         assert lib.gpuntt_test_set_hook(name.encode(), value.encode()) != 0, (name, value)
     # the public headers do not advertise the hooks
     import glob
