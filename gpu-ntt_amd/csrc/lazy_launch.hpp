@@ -101,7 +101,8 @@ namespace gpuntt
                 return 15;
             // 32-bit ring 2^23: one strided pass of 8 stages (16384-coefficient tiles) + the 15-stage contiguous pass on the
             // 32768-coefficient tile of the second geometry = TWO sweeps instead of three
-            if (sizeof(T) == 4 && n == 23 && ((lazy_e32_mask() >> 16) & 1u) != 0u)
+            // ... and 2^24 with a strided pass of 9 stages (rows of 32 coefficients = 128-byte runs)
+            if (sizeof(T) == 4 && (n == 23 || n == 24) && ((lazy_e32_mask() >> 16) & 1u) != 0u)
                 return 15;
             return lazy_tile_log<T>(n, inverse, polys);
         }
@@ -562,7 +563,7 @@ namespace gpuntt
             // (64-bit rings 2^23 / 2^24 on 16384-coefficient tiles, experiment: ONE strided pass of 9 / 10 stages)
             const bool big2 = sizeof(T) == 8 && tl == 14 && pn >= 23 && !partial;
             const Plan pl = make_plan_tl(pn, tl, tl == 12 ? (partial ? lazy_contig_k(pn) : lazy_contig_k_merge<T>(pn, INV)) : tl,
-                                         big2 ? 10 : 8);
+                                         big2 ? 10 : (sizeof(T) == 4 && tl == 15) ? 9 : 8);
             const void* src = base.in;
             int fwd_bound = partial ? 16 : 1; // range bound of the values in flight (forward, 31 q range: see fwd_bound_after)
             for (int i = 0; i < pl.count; i++)

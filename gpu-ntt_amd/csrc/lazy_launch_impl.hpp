@@ -176,6 +176,11 @@ namespace gpuntt
 #undef GPUNTT_CASE
                             default: break;
                         }
+                    // 32-bit ring 2^24 in two sweeps: ONE strided pass of 9 stages on 16384-coefficient tiles (rows of 32
+                    // coefficients) in front of the 15-stage contiguous pass of the 32-coefficients-per-lane geometry
+                    if constexpr (sizeof(T) == 4 && TLOG == 14)
+                        if (!last && in_first && p.k == 9)
+                            GPUNTT_ONE(false, 9, 1, false);
                     // strided passes that END a forward transform / BEGIN an inverse one: the PerCoefficient layout
                     // (rows = coefficients, every stage is a strided stage; default lazy range and, for 61- / 62-bit moduli
                     // in 64-bit words, the 4 q range; 4096-coefficient tiles)
@@ -218,6 +223,9 @@ namespace gpuntt
 #undef GPUNTT_CASE
                                 default: break;
                             }
+                    if constexpr (sizeof(T) == 4 && TLOG == 14)
+                        if (!in_first && last && p.k == 9) // (the inverse twin of the 9-stage pass of the 32-bit ring 2^24)
+                            GPUNTT_ONE(false, 9, LIM / 2, true);
                     if (!in_first)
                         switch (p.k * 2 + (last ? 1 : 0))
                         {
