@@ -421,6 +421,10 @@ namespace gpuntt
             int tl = lim != 0 ? 12 : lazy_tile_log<T>(n_power, false, polys);
             if (sizeof(T) == 8 && n_power >= 23)
                 tl = 12; // (the two-sweep experiment of the Merge rings 2^23 / 2^24 does not extend to the 4-step form)
+            // 32-bit ring 2^23: the gathering first pass takes 8 stages, the other 15 are ONE contiguous pass on the
+            // 32768-coefficient tile of the second geometry -- two sweeps instead of three (2^24 would need a 9-stage gather)
+            if (sizeof(T) == 4 && n_power == 23 && log_n1 <= 8 && ((lazy_e32_mask() >> 16) & 1u) != 0u)
+                tl = 15;
             k1 = fourstep_first_k(n_power, log_n1, tl);
             if (tl == 14 && n_power > tl && n_power - k1 < 13)
             {
@@ -601,8 +605,9 @@ namespace gpuntt
                 {
                     // the full-tile contiguous pass of a 32-bit plan (forward: last, on lazy input; inverse: first) on the
                     // 32-coefficients-per-lane geometry (GPU_PolyMul's fused product included)
-                    const bool edge = INV ? (i == 0 && pl.count > 1) : (i == pl.count - 1 && pl.count > 1);
-                    if (p.contig && p.k == tlp && (tlp == 12 || tlp == 14 || tlp == 15) && edge && !partial &&
+                    // (partial: the low stages of a forward 4-step behind its gathering first pass -- lazy input as well)
+                    const bool edge = INV ? (i == 0 && pl.count > 1) : (i == pl.count - 1 && (pl.count > 1 || partial));
+                    if (p.contig && p.k == tlp && (tlp == 12 || tlp == 14 || tlp == 15) && edge &&
                         (tlp == 15 || ((lazy_e32_mask() >> 16) & 1u) != 0u))
                     {
                         launch_tile_e32<INV>(tlp, base.lim, a, stream);

@@ -121,6 +121,10 @@ ROWS = [
     dict(id="4step u64 2^20 ok fwd, check_4step_tables=0", entry="4step", bits=64, logn=20, batch=2, modulus="pool", tables="ok",
          hooks={"check_4step_tables": "0"},
          launches=["prep_merge_from_fourstep", "fourstep_first_lazy:0", "merge_pass_lazy:31"], serves="lazy:0+31"),
+    dict(id="4step u32 2^20 ok fwd (last pass on 32 coefficients per lane)", entry="4step", bits=32, logn=20, batch=2,
+         modulus="pool", tables="ok",
+         launches=["prep_merge_from_fourstep", "fourstep_first_lazy:0", "merge_ring_e32:8", "merge_pass", "merge_pass"],
+         serves="lazy:0+e32:8"),
     dict(id="4step u64 2^16 61-bit ok fwd", entry="4step", bits=64, logn=16, batch=2, modulus="b61", tables="ok",
          launches=["prep_merge_from_fourstep", "fourstep_first_lazy:8", "merge_pass_lazy:8"], serves="lazy:8"),
     dict(id="4step u64 2^16 ok, path=generic", entry="4step", bits=64, logn=16, batch=2, modulus="pool", tables="ok",
