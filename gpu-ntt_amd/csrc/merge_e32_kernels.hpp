@@ -44,6 +44,7 @@ namespace gpuntt
             static constexpr int NT = 1 << (TLOG - R5);
             static constexpr int TILE = 1 << TLOG;
             static constexpr int LDS_ELEMS = TILE + (TILE >> 3);
+            static constexpr int TWB_WORDS = (NT / 64) * 128; // round-B twiddles: 64 pairs (512 B) per wave, behind the tile
             static constexpr int NA = TLOG - 10;   // stages of round A (2 .. 5)
             static constexpr int WLA = TLOG - R5;  // its register window starts here
         };
@@ -72,13 +73,8 @@ namespace gpuntt
                     if (b + TB > LIMIT)
                     {
                         const int k = lazy::csub_k(b);
-#ifdef GPUNTT_E32_CSUB_ONLY // A/B build (tools/): conditional subtractions only
-                        d.ku[s] = k;
-                        b = k;
-#else
                         d.ku[s] = (k > 2) ? -1 : k;
                         b = (k > 2) ? 2 : k;
-#endif
                     }
                     b += TB;
                 }
@@ -120,7 +116,6 @@ namespace gpuntt
                             const int j0 = (h & ((1 << jb) - 1)) | ((h >> jb) << (jb + 1));
                             const int j1 = j0 | (1 << jb);
                             lazy::GsPlan pl = lazy::gs_plan(b[j0], b[j1], LIMIT);
-#ifndef GPUNTT_E32_GS_CSUB_ONLY
                             // ko = -1: the sum is corrected by the quotient estimate (Mod32::reduce_2q: -> [0, 2q)) where a
                             // conditional subtraction would only halve its bound -- 8 q range: a sum of two 4 q values every
                             // SECOND stage of a run of sums instead of every stage
@@ -129,7 +124,6 @@ namespace gpuntt
                                 pl.ko = -1;
                                 pl.out_u = 2;
                             }
-#endif
                             d.ku[r][s][h] = pl.ku;
                             d.kv[r][s][h] = pl.kv;
                             d.c[r][s][h] = pl.c;
@@ -182,7 +176,7 @@ namespace gpuntt
             constexpr int NT16 = 1 << (TLOG - 4); // "threads" of the prepared layout's permutation (16-coefficient groups)
             constexpr bool LAST = !(PART && INV);       // canonical output
             constexpr bool CANON_IN = !(PART && !INV);  // canonical input
-            __shared__ __attribute__((aligned(16))) T lds[G::LDS_ELEMS];
+            __shared__ __attribute__((aligned(16))) T lds[G::LDS_ELEMS + G::TWB_WORDS];
 
             if (not_my_call<T, LIM>(a.go_flag, a.flags))
                 return;
@@ -238,24 +232,39 @@ namespace gpuntt
                 p1 = TW{x.z, x.w};
             };
 
-            // ---- per-lane twiddle fetches (issued early, consumed a round later) ----------------------------------------
-            // round B, stage p = 9 .. 5: the 2^(9-p) consecutive pairs from slot 2^(TLOG-1-p) + ((t >> 5) << (9 - p))
-            // (FIRST = 0, COUNT = 4: stages 9 .. 6, 15 pairs; FIRST = 4, COUNT = 1: stage 5, 16 pairs -- the forward kernel
-            // asks for the second half only after round A, which needs the registers)
-            auto load_tw_b = [&](TW(&w)[E32 - 1], auto first_, auto count_) {
-                constexpr int FIRST = decltype(first_)::value, COUNT = decltype(count_)::value;
-                const unsigned g = tu >> 5;
-                if constexpr (FIRST == 0)
-                    w[0] = tw_pair(g << 3, sbase(9));
-                static_for<COUNT - (FIRST == 0 ? 1 : 0)>([&](auto s_) {
-                    constexpr int s = decltype(s_)::value + (FIRST == 0 ? 1 : FIRST); // stage p = 9 - s, 2^s pairs
-                    constexpr int p = 9 - s;
-                    const unsigned voff = g << (s + 3);
+            // ---- round B twiddles (stages 9 .. 5): staged in LDS per wave ----------------------------------------------------
+            // The 32 lanes of a half-wave (one value of g = t >> 5) use the SAME 31 pairs -- 2^s consecutive pairs from slot
+            // sbase(9 - s) + (g << s) for s = 0 .. 4 -- so a wave needs 62 pairs in all.  Lane l < 62 fetches one of them at the
+            // start of the kernel and drops it into the wave's own 512-byte area; the butterflies read them back with 16-byte
+            // broadcast reads, stage by stage.  (Per-lane loads of those pairs moved 127 KiB per tile through the vector
+            // memory path for 4 KiB of distinct data: knocking them out made C4 5.7 % faster, tools/ko_e32.py; this gets
+            // most of that back, frees 62 VGPRs across rounds A and B, and needs no barrier: the area is wave-private.)
+            //   area layout (pairs): [h * 32 + 2^s + k] for half h, stage s, k < 2^s; index h * 32 is unused
+            TW* const twb_area = reinterpret_cast<TW*>(lds + G::LDS_ELEMS) + (static_cast<unsigned>(t) >> 6) * 64u;
+            auto stage_twb = [&]() {
+                const unsigned l = tu & 63u, h = l >> 5, r = l & 31u; // r = 2^s + k, r = 0 unused
+                if (r != 0u)
+                {
+                    const unsigned s_ = 31u - static_cast<unsigned>(__clz(r)), k = r - (1u << s_);
+                    const unsigned g = ((tu >> 6) << 1) + h;
+                    // slot of stage p = 9 - s_: sbase(p) + (g << s_) + k, with sbase(p) = 2^(n - 10 + s_) + (tip << (TLOG - 10 + s_))
+                    const unsigned slot = (1u << (n - 10 + s_)) + (tip << (TLOG - 10 + s_)) + (g << s_) + k;
+                    twb_area[l] = tw_pair(slot << 3, 0u);
+                }
+            };
+            // the 2^s pairs of stage s for this lane's half-wave
+            auto read_twb = [&](auto s_, TW(&w)[16]) {
+                constexpr int s = decltype(s_)::value;
+                const TW* src = twb_area + ((tu >> 5) & 1u) * 32u + (1u << s);
+                if constexpr (s == 0)
+                    w[0] = src[0];
+                else
                     static_for<(1 << s) / 2>([&](auto k_) {
                         constexpr int k = decltype(k_)::value;
-                        tw_two(voff, sbase(p) + 2u * k, w[(1 << s) - 1 + 2 * k], w[(1 << s) - 1 + 2 * k + 1]);
+                        const u32x4 x = *reinterpret_cast<const u32x4*>(src + 2 * k);
+                        w[2 * k] = TW{x.x, x.y};
+                        w[2 * k + 1] = TW{x.z, x.w};
                     });
-                });
             };
             // round C, stage p = 4 .. 0 (2^(4-p) pairs each): p = 4, 3 natural slots; p <= 2 the [k][16-coefficient group]
             // permutation of prep.hip -- entry (group 2t + h, k) at k * NT16 + 2t + h, i.e. ONE 16-byte load per k
@@ -285,7 +294,7 @@ namespace gpuntt
 #pragma unroll
                 for (int j = 0; j < E32; j++)
                     v[j] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, static_cast<int>(tu << 2), j << (WLA + 2), POL_IN);
-                load_tw_b(twv, std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
+                stage_twb();
                 if (CANON_IN && (a.flags & F_SIGNED_IN) != 0u)
                 {
 #pragma unroll
@@ -317,7 +326,6 @@ namespace gpuntt
                         ct(std::integral_constant<int, s>{}, std::true_type{}, v[j0], v[j1], w, unit);
                     });
                 });
-                load_tw_b(twv, std::integral_constant<int, 4>{}, std::integral_constant<int, 1>{});
                 // ---- exchange A -> B (block-wide) ----------------------------------------------------------------------
                 {
                     T* lw = lds + epad(t);
@@ -334,12 +342,13 @@ namespace gpuntt
                 static_for<R5>([&](auto s_) {
                     constexpr int s = decltype(s_)::value; // stage p = 9 - s, register bit jb = 4 - s
                     constexpr int jb = R5 - 1 - s;
+                    TW wb[16];
+                    read_twb(s_, wb);
                     static_for<E32 / 2>([&](auto h_) {
                         constexpr int h = decltype(h_)::value;
                         constexpr int j0 = (h & ((1 << jb) - 1)) | ((h >> jb) << (jb + 1));
                         constexpr int j1 = j0 | (1 << jb);
-                        ct(std::integral_constant<int, NA + s>{}, std::false_type{}, v[j0], v[j1],
-                           twv[(1 << s) - 1 + (j0 >> (jb + 1))], false);
+                        ct(std::integral_constant<int, NA + s>{}, std::false_type{}, v[j0], v[j1], wb[j0 >> (jb + 1)], false);
                     });
                 });
                 load_tw_c(twv);
@@ -426,6 +435,7 @@ namespace gpuntt
                     for (int i = 0; i < E32 / 4; i++)
                         x[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, static_cast<int>(e0 << 2), 1024 * i, POL_IN);
                     load_tw_c(twv);
+                    stage_twb();
                     T* lo = lds + epad(static_cast<int>(e0));
 #pragma unroll
                     for (int i = 0; i < E32 / 4; i++)
@@ -479,7 +489,6 @@ namespace gpuntt
                            twv[(1 << (4 - s)) - 1 + (j0 >> (jb + 1))]);
                     });
                 });
-                load_tw_b(twv, std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{});
                 {
                     u32x4* lc = reinterpret_cast<u32x4*>(lds + 36 * t);
 #pragma unroll
@@ -497,12 +506,14 @@ namespace gpuntt
                 static_for<R5>([&](auto s_) {
                     constexpr int s = decltype(s_)::value; // stage p = 5 + s, register bit jb = s
                     constexpr int jb = s;
+                    TW wb[16];
+                    read_twb(std::integral_constant<int, 4 - s>{}, wb); // stage p = 9 - (4 - s)
                     static_for<E32 / 2>([&](auto h_) {
                         constexpr int h = decltype(h_)::value;
                         constexpr int j0 = (h & ((1 << jb) - 1)) | ((h >> jb) << (jb + 1));
                         constexpr int j1 = j0 | (1 << jb);
                         gs(std::integral_constant<int, 1>{}, s_, h_, std::false_type{}, std::false_type{}, v[j0], v[j1],
-                           twv[(1 << (4 - s)) - 1 + (j0 >> (jb + 1))]);
+                           wb[j0 >> (jb + 1)]);
                     });
                 });
                 {
