@@ -124,6 +124,14 @@ def set_test_hook(name, value):
     _check(load_library().gpuntt_test_set_hook(str(name).encode(), str(value).encode()))
 
 
+def scratch_stats():
+    """gpuntt_test_scratch_stats (csrc/test_hooks.h): the twiddle scratch of captured calls, which their graph owns."""
+    out = (ctypes.c_ulonglong * 6)()
+    _check(load_library().gpuntt_test_scratch_stats(out))
+    names = ("graph_owned", "died", "pooled", "reused", "chains_erased", "chains")
+    return dict(zip(names, (int(v) for v in out)))
+
+
 class launch_log:
     """with launch_log() as log: ...calls...; log.kernels -> the kernels the library enqueued inside the block, in order
     (gpuntt_test_launch_log_start / _take, csrc/test_hooks.h): ["prep_twiddles", "merge_pass_lazy:31", ...]"""

@@ -22,6 +22,7 @@ namespace gpuntt
         bool set_test_hook(const char* name, const char* value);
         void launch_log_start();
         std::string launch_log_take();
+        void scratch_stats(unsigned long long out[6]);
     } // namespace host
 } // namespace gpuntt
 
@@ -464,6 +465,11 @@ extern "C"
             buf[n] = '\0';
         }
         return static_cast<int>(s.size()) + 1;
+    }
+
+    int gpuntt_test_scratch_stats(unsigned long long out[6])
+    {
+        return guarded([&] { host::scratch_stats(out); });
     }
 
     int gpuntt_modulus_u32(uint32_t q, gpuntt_modulus32* out)

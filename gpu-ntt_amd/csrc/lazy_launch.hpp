@@ -368,6 +368,7 @@ namespace gpuntt
         bool set_test_hook(const char* name, const char* value);
         void launch_log_start();
         std::string launch_log_take(); // space-separated kernel names ("merge_pass_lazy:31 prep_twiddles ..."), stops the log
+        void scratch_stats(unsigned long long out[6]); // test hook: graph-owned scratch of capture chains (prep.hip)
         // 0 size heuristic, 1 generic kernels, 2 fast, 3 fast-strict (a call the fast kernels cannot take throws),
         // 4 generic-capped (4-step RNS overload: generic kernels on the capped shadow grid)
         int forced_path();

@@ -18,6 +18,7 @@
 #include <tuple>
 #include <mutex>
 #include <stdexcept>
+#include <thread>
 #include <vector>
 
 #include "lazy_launch.hpp"
@@ -767,14 +768,17 @@ namespace gpuntt
         namespace
         {
             // One scratch chain per (device, stream) for eager calls and one per (device, stream, capture) for calls made
-            // while the stream is being captured into a hipGraph.  A buffer that has ever been handed out is NEVER freed,
-            // and never handed to another chain, before GPU_NTT_ReleaseWorkspaces(): kernels already enqueued -- or baked
-            // into a captured graph that may be replayed at any later time, on any stream -- keep reading it.  Growth
-            // allocates a new buffer and RETIRES the old one (steps of at least 1.5 x, so the retired buffers of a chain add
-            // up to less than twice the live one).  A captured call never shares its buffer with eager calls: replaying
-            // the graph on another stream while eager calls run on the capture stream touches two different buffers.
+            // while the stream is being captured into a hipGraph.  A buffer of an EAGER chain that has ever been handed out
+            // is never freed, and never handed to another chain, before GPU_NTT_ReleaseWorkspaces(): kernels already
+            // enqueued keep reading it.  A buffer of a CAPTURE chain lives as long as the graph it was captured into and the
+            // executables made from it (below).  Growth allocates a new buffer and RETIRES the old one (steps of at least
+            // 1.5 x, so the retired buffers of a chain add up to less than twice the live one).  A captured call never
+            // shares its buffer with eager calls: replaying the graph on another stream while eager calls run on the
+            // capture stream touches two different buffers.
+            using SlotKey = std::tuple<int, hipStream_t, unsigned long long>;
             struct Slot
             {
+                SlotKey key{};
                 void* ptr = nullptr; // start of the buffer = its header (WS_HEADER bytes); the user area lies behind it
                 size_t bytes = 0;    // size of the user area
                 unsigned long long seq = 0; // calls that took a veto epoch from this chain (lazy_workspace_veto)
@@ -782,10 +786,103 @@ namespace gpuntt
                 std::recursive_mutex mu;    // held by a host thread for the duration of one API call
             };
             constexpr size_t WS_HEADER = 256;
-            using SlotKey = std::tuple<int, hipStream_t, unsigned long long>;
-            std::mutex g_ws_mutex; // guards the map itself
+            std::mutex g_ws_mutex; // guards the map itself (and g_capture_pool, g_ws_stats)
             std::map<SlotKey, Slot> g_ws;
             thread_local std::vector<std::recursive_mutex*> t_held;
+
+            // ---- capture chains belong to their GRAPH (round 6) ------------------------------------------------------
+            // A buffer allocated for a call that is being captured is retained by the graph through a hipUserObject; when the
+            // graph AND every executable instantiated from it are gone (ROCm keeps the object alive for the executables like
+            // CUDA does: tools/probe_userobject.hip), the object's destructor reports the buffer dead.  Dead buffers are not
+            // freed (hipFree synchronises the device) but POOLED: the next capture chain that needs a buffer takes one that is
+            // large enough.  A program that re-captures periodically therefore stops growing after its first captures, and the
+            // map node of a dead chain is erased.  The destructor runs on a runtime thread and must not call HIP: it only
+            // appends to g_dead; lazy_workspace() and release_workspaces() drain that list.
+            struct DeadBuffer
+            {
+                SlotKey key;
+                void* ptr;
+                size_t total; // bytes of the allocation (header + user area)
+            };
+            std::mutex g_dead_mutex;
+            std::vector<DeadBuffer> g_dead;                         // guarded by g_dead_mutex
+            std::vector<std::pair<void*, size_t>> g_capture_pool;   // (pointer, bytes of the allocation); guarded by g_ws_mutex
+            struct WsStats
+            {
+                unsigned long long graph_owned = 0, died = 0, pooled_now = 0, reused = 0, chains_erased = 0;
+            } g_ws_stats; // guarded by g_ws_mutex
+            void capture_buffer_dead(void* p)
+            {
+                DeadBuffer* d = static_cast<DeadBuffer*>(p);
+                if (d->ptr != nullptr) // (null: the graph never took the object, lazy_workspace() keeps the buffer)
+                {
+                    std::lock_guard<std::mutex> lock(g_dead_mutex);
+                    g_dead.push_back(*d);
+                }
+                delete d;
+            }
+            // hands the buffers of dead graphs to the pool and erases chains that own nothing any more.  Never blocks on a
+            // chain's lock (a chain that is busy keeps its entry for the next drain).
+            void drain_dead_captures()
+            {
+                std::vector<DeadBuffer> dead;
+                {
+                    std::lock_guard<std::mutex> lock(g_dead_mutex);
+                    if (g_dead.empty())
+                        return;
+                    dead.swap(g_dead);
+                }
+                std::vector<DeadBuffer> again;
+                {
+                    std::lock_guard<std::mutex> lock(g_ws_mutex);
+                    for (const DeadBuffer& d : dead)
+                    {
+                        auto it = g_ws.find(d.key);
+                        if (it == g_ws.end())
+                            continue; // (the chain is gone: release_workspaces() freed the buffer meanwhile)
+                        Slot& s = it->second;
+                        std::unique_lock<std::recursive_mutex> sl(s.mu, std::try_to_lock);
+                        if (!sl.owns_lock())
+                        {
+                            again.push_back(d);
+                            continue;
+                        }
+                        bool found = false;
+                        if (s.ptr == d.ptr)
+                        {
+                            s.ptr = nullptr;
+                            s.bytes = 0;
+                            found = true;
+                        }
+                        else
+                            for (auto r = s.retired.begin(); r != s.retired.end(); ++r)
+                                if (*r == d.ptr)
+                                {
+                                    s.retired.erase(r);
+                                    found = true;
+                                    break;
+                                }
+                        if (found) // (not found: release_workspaces() freed it and the address may belong to someone else now)
+                        {
+                            g_capture_pool.emplace_back(d.ptr, d.total);
+                            g_ws_stats.died++;
+                        }
+                        if (s.ptr == nullptr && s.retired.empty() && std::get<2>(d.key) != 0ull)
+                        {
+                            sl.unlock();
+                            sl.release();
+                            g_ws.erase(it); // a capture's key is never used again once the capture has ended
+                            g_ws_stats.chains_erased++;
+                        }
+                    }
+                    g_ws_stats.pooled_now = g_capture_pool.size();
+                }
+                if (!again.empty())
+                {
+                    std::lock_guard<std::mutex> lock(g_dead_mutex);
+                    g_dead.insert(g_dead.end(), again.begin(), again.end());
+                }
+            }
 
             // 0: the stream is not being captured; else a key unique to the capture.  (The legacy default stream cannot be
             // captured, and asking about it while another stream captures in global mode is itself an error.)
@@ -831,7 +928,11 @@ namespace gpuntt
                 Slot* sp;
                 {
                     std::lock_guard<std::mutex> lock(g_ws_mutex);
-                    sp = &g_ws[std::make_tuple(dev, stream, cap)]; // map nodes never move and are never erased
+                    // map nodes never move; the node of a CAPTURE chain is erased once its graph is gone and it owns nothing
+                    // (drain_dead_captures) -- no call can be using it then, a capture's key dies with the capture
+                    const SlotKey key = std::make_tuple(dev, stream, cap);
+                    sp = &g_ws[key];
+                    sp->key = key;
                 }
                 if (t_scope_depth > 0)
                     t_slot_cache = SlotCache{stream, sp, cap != 0ull};
@@ -877,28 +978,59 @@ namespace gpuntt
 
         void release_workspaces()
         {
-            // lock order: never hold the map's mutex while taking a slot's -- a thread inside an API call holds its
-            // slot and re-enters lazy_workspace() (map mutex) for the next buffer of the same call
-            std::vector<Slot*> slots;
+            // lock order: never BLOCK on a slot's lock while holding the map's mutex -- a thread inside an API call holds
+            // its slot and re-enters lazy_workspace() (map mutex) for the next buffer of the same call.  So: try each
+            // chain under the map's mutex, take what can be taken, and come back for the chains that were busy.
+            drain_dead_captures();
+            std::vector<void*> doomed;
+            for (;;)
             {
-                std::lock_guard<std::mutex> lock(g_ws_mutex);
-                for (auto& kv : g_ws)
-                    slots.push_back(&kv.second); // map nodes never move and are never erased
-            }
-            for (Slot* sp : slots)
-            {
-                Slot& s = *sp;
-                std::lock_guard<std::recursive_mutex> sl(s.mu);
-                if (s.ptr != nullptr)
+                bool busy = false;
                 {
-                    (void) hipFree(s.ptr); // synchronises the device
-                    s.ptr = nullptr;
-                    s.bytes = 0;
+                    std::lock_guard<std::mutex> lock(g_ws_mutex);
+                    for (auto it = g_ws.begin(); it != g_ws.end();)
+                    {
+                        Slot& s = it->second;
+                        std::unique_lock<std::recursive_mutex> sl(s.mu, std::try_to_lock);
+                        if (!sl.owns_lock())
+                        {
+                            busy = true;
+                            ++it;
+                            continue;
+                        }
+                        if (s.ptr != nullptr)
+                            doomed.push_back(s.ptr);
+                        s.ptr = nullptr;
+                        s.bytes = 0;
+                        doomed.insert(doomed.end(), s.retired.begin(), s.retired.end());
+                        s.retired.clear();
+                        // (the node stays: a thread may be between slot_of() and its lock; the user objects of graphs that
+                        // are still alive will report buffers this chain no longer lists, and drain ignores those)
+                        ++it;
+                    }
+                    for (auto& pb : g_capture_pool)
+                        doomed.push_back(pb.first);
+                    g_capture_pool.clear();
+                    g_ws_stats.pooled_now = 0;
                 }
-                for (void* old : s.retired)
-                    (void) hipFree(old);
-                s.retired.clear();
+                if (!busy)
+                    break;
+                std::this_thread::yield();
             }
+            for (void* p : doomed)
+                (void) hipFree(p); // synchronises the device
+        }
+
+        void scratch_stats(unsigned long long out[6])
+        {
+            drain_dead_captures();
+            std::lock_guard<std::mutex> lock(g_ws_mutex);
+            out[0] = g_ws_stats.graph_owned;   // buffers handed to a graph (hipGraphRetainUserObject)
+            out[1] = g_ws_stats.died;          // of those, reported dead by their graph and moved to the pool
+            out[2] = g_capture_pool.size();    // buffers waiting in the pool
+            out[3] = g_ws_stats.reused;        // capture-chain buffers taken from the pool instead of hipMalloc
+            out[4] = g_ws_stats.chains_erased; // map nodes of dead capture chains erased
+            out[5] = g_ws.size();              // chains alive
         }
 
         // ---- which lazy family will a drop-in RNS call need?  (RnsGuess, lazy_launch.hpp) ------------------------------
@@ -1061,10 +1193,49 @@ namespace gpuntt
             return 12;
         }
 
+        namespace
+        {
+            // the graph being captured on `stream` retains the buffer: capture_buffer_dead() runs when the graph and all
+            // executables made from it are destroyed.  Failure at any step leaves the buffer with the chain for good, which
+            // is what every buffer did before round 6.
+            void give_to_graph(hipStream_t stream, const SlotKey& key, void* ptr, size_t total)
+            {
+                hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+                unsigned long long id = 0;
+                hipGraph_t graph = nullptr;
+                const hipGraphNode_t* deps = nullptr;
+                size_t ndeps = 0;
+                if (hipStreamGetCaptureInfo_v2(stream, &st, &id, &graph, &deps, &ndeps) != hipSuccess ||
+                    st != hipStreamCaptureStatusActive || graph == nullptr)
+                {
+                    (void) hipGetLastError();
+                    return;
+                }
+                DeadBuffer* d = new DeadBuffer{key, ptr, total};
+                hipUserObject_t obj = nullptr;
+                if (hipUserObjectCreate(&obj, d, capture_buffer_dead, 1, hipUserObjectNoDestructorSync) != hipSuccess)
+                {
+                    (void) hipGetLastError();
+                    delete d;
+                    return;
+                }
+                if (hipGraphRetainUserObject(graph, obj, 1, hipGraphUserObjectMove) != hipSuccess)
+                {
+                    (void) hipGetLastError();
+                    d->ptr = nullptr; // the destructor reports nothing
+                    (void) hipUserObjectRelease(obj, 1);
+                    return;
+                }
+                std::lock_guard<std::mutex> lock(g_ws_mutex);
+                g_ws_stats.graph_owned++;
+            }
+        } // namespace
+
         void* lazy_workspace(hipStream_t stream, size_t bytes, bool or_null)
         {
             if (or_null && options().no_scratch != 0)
                 return nullptr; // test hook: the out-of-memory fall-back of the drop-in entry points
+            drain_dead_captures();
             bool capturing = false;
             Slot& s = slot_of(stream, &capturing);
             SlotLock lock(s);
@@ -1082,9 +1253,30 @@ namespace gpuntt
                 if (capturing)
                     (void) hipThreadExchangeStreamCaptureMode(&mode);
                 void* fresh = nullptr;
-                hipError_t err = hipMalloc(&fresh, WS_HEADER + want);
+                hipError_t err = hipSuccess;
+                if (capturing)
+                {
+                    // a buffer whose graph is gone, if one is large enough (best fit): re-capturing programs stop growing
+                    std::lock_guard<std::mutex> lock(g_ws_mutex);
+                    auto best = g_capture_pool.end();
+                    for (auto it = g_capture_pool.begin(); it != g_capture_pool.end(); ++it)
+                        if (it->second >= WS_HEADER + want && (best == g_capture_pool.end() || it->second < best->second))
+                            best = it;
+                    if (best != g_capture_pool.end())
+                    {
+                        fresh = best->first;
+                        want = best->second - WS_HEADER;
+                        g_capture_pool.erase(best);
+                        g_ws_stats.reused++;
+                        g_ws_stats.pooled_now = g_capture_pool.size();
+                    }
+                }
+                if (fresh == nullptr)
+                    err = hipMalloc(&fresh, WS_HEADER + want);
                 if (capturing)
                     (void) hipThreadExchangeStreamCaptureMode(&mode);
+                if (err == hipSuccess && capturing)
+                    give_to_graph(stream, s.key, fresh, WS_HEADER + want);
                 // header: the veto word of the 4-step table check (lazy_workspace_veto) starts at "no call yet" = all ones
                 if (err == hipSuccess)
                 {

@@ -13,6 +13,9 @@
  *   gpuntt_test_launch_log_start()      start recording the kernel of every launch the library enqueues (all threads)
  *   gpuntt_test_launch_log_take(buf, n) stop; the kernels since start, space-separated ("prep_twiddles merge_pass_lazy:31 ..."),
  *                                       fast kernels with their lazy range behind a colon; returns the length needed
+ *   gpuntt_test_scratch_stats(out[6])   the twiddle scratch of captured calls, which their graph owns (prep.hip): buffers handed to
+ *                                       a graph, of those reported dead by their graph, buffers pooled now, buffers re-used from
+ *                                       the pool, chains erased, chains alive
  * Options are snapshot once per API call (prep.hip), so a hook set while another thread's call is in flight does not change
  * that call. */
 #ifndef GPUNTT_TEST_HOOKS_H
@@ -24,6 +27,7 @@ extern "C"
     int gpuntt_test_set_hook(const char* name, const char* value);
     int gpuntt_test_launch_log_start(void);
     int gpuntt_test_launch_log_take(char* buf, int capacity);
+    int gpuntt_test_scratch_stats(unsigned long long out[6]);
 #ifdef __cplusplus
 }
 #endif

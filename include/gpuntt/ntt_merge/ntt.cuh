@@ -23,8 +23,9 @@
 //     re-derives from the caller's table into a library-owned scratch buffer: one chain per (device, stream),
 //     and one per capture while a stream is being captured into a hipGraph.  First use / a larger ring
 //     allocates with hipMalloc; NOTHING is freed, reused for another chain or synchronised on before
-//     GPU_NTT_ReleaseWorkspaces(), so a graph captured from these calls can be replayed at any time on any
-//     stream.  A host thread holds the chain's lock from the preparation launch to its last kernel launch,
+//     GPU_NTT_ReleaseWorkspaces() -- except that the buffer of a captured call belongs to its graph and is
+//     pooled for the next capture once the graph and its executables have been destroyed -- so a graph
+//     captured from these calls can be replayed at any time on any stream.  A host thread holds the chain's lock from the preparation launch to its last kernel launch,
 //     so threads sharing a stream are serialised there and stream order keeps their launches apart.
 //     Callers that want zero allocation / preparation per call use NTTPlan<T> below (caller-owned
 //     workspace, tables prepared once).

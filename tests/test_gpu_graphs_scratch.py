@@ -223,6 +223,73 @@ def test_graph_replay_on_another_stream_while_eager_calls_use_the_capture_stream
         assert np.array_equal(g.to_host(fe), wante), rep
         assert np.array_equal(g.to_host(fe2), wante2), rep
 
+def test_capture_scratch_belongs_to_its_graph_and_is_reused_when_the_graph_dies(g):
+    """a program that re-captures periodically must not grow without bound.  The twiddle scratch of a captured
+    call is retained by the graph being captured (hipGraphRetainUserObject, prep.hip: give_to_graph); when the graph and
+    its executable are destroyed the buffer goes to a pool and the next capture takes it from there, and the map node of
+    the dead chain is erased.  24 capture / replay / destroy rounds of two ring sizes: allocations stop after the first
+    rounds; a graph kept alive from round 0 still replays exactly at the end (its buffer was never handed on); results of
+    every round equal the oracle."""
+    import gc
+    import torch
+    cases = [MergeCase(g, 64, 13, O.X_N_plus), MergeCase(g, 32, 15, O.X_N_minus)]
+    s = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    before = g.scratch_stats()
+    keep = None
+    rounds = 24
+    for r in range(rounds):
+        c = cases[r % 2]
+        batch = 3
+        x = c.random(batch, 54000 + r)
+        d = g.to_device(x)
+        f = torch.zeros_like(d)
+        o = torch.zeros_like(d)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s):
+            cs = torch.cuda.current_stream()
+            g.GPU_NTT(d, f, c.fwd_dev, c.prm.modulus, c.cfg(stream=cs), batch)
+            g.GPU_INTT(f, o, c.inv_dev, c.prm.modulus, c.cfg(True, stream=cs), batch)
+        for _ in range(2):
+            f.zero_()
+            o.zero_()
+            graph.replay()
+            torch.cuda.synchronize()
+            assert np.array_equal(g.to_host(f), c.P.merge_ntt(x, c.oprm)), r
+            assert np.array_equal(g.to_host(o), x), r
+        if r == 0:
+            keep = (graph, c, x, d, f, o)
+        else:
+            del graph
+            gc.collect()
+    after = g.scratch_stats()
+    owned = after["graph_owned"] - before["graph_owned"]
+    died = after["died"] - before["died"]
+    reused = after["reused"] - before["reused"]
+    assert owned >= rounds, (before, after)                    # every capture chain's buffer went to its graph
+    assert died >= rounds - 2, (before, after)                 # ... and came back when the graph was destroyed
+    assert reused >= rounds - 4, (before, after)               # later captures allocate nothing
+    assert after["pooled"] <= before["pooled"] + 3, (before, after)
+    assert after["chains"] <= before["chains"] + 4, (before, after)  # dead chains leave the map
+    graph, c, x, d, f, o = keep
+    f.zero_()
+    o.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(g.to_host(f), c.P.merge_ntt(x, c.oprm))
+    assert np.array_equal(g.to_host(o), x)
+    # releasing everything while the kept graph is alive, then destroying it: its buffer is reported dead but belongs to
+    # nobody any more -- nothing is pooled twice and calls afterwards stay exact
+    g.release_workspaces()
+    del graph, keep
+    gc.collect()
+    st = g.scratch_stats()
+    assert st["pooled"] == 0, st
+    c = cases[0]
+    x = c.random(2, 54999)
+    assert np.array_equal(c.gpu_forward(x), c.P.merge_ntt(x, c.oprm))
+
 def test_release_workspaces_after_growth(g):
     """GPU_NTT_ReleaseWorkspaces() frees live and retired buffers; calls afterwards allocate afresh and stay exact."""
     import torch
