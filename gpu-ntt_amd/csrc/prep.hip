@@ -804,8 +804,10 @@ namespace gpuntt
                 void* ptr;
                 size_t total; // bytes of the allocation (header + user area)
             };
-            std::mutex g_dead_mutex;
-            std::vector<DeadBuffer> g_dead;                         // guarded by g_dead_mutex
+            // (both on the heap and never destroyed: the runtime may destroy a leaked graph, and call its user objects'
+            // destructors, after this library's static objects are gone)
+            std::mutex& g_dead_mutex = *new std::mutex;
+            std::vector<DeadBuffer>& g_dead = *new std::vector<DeadBuffer>; // guarded by g_dead_mutex
             std::vector<std::pair<void*, size_t>> g_capture_pool;   // (pointer, bytes of the allocation); guarded by g_ws_mutex
             struct WsStats
             {
