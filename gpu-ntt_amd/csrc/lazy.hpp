@@ -110,6 +110,21 @@ namespace gpuntt
             return d;
         }
 
+        // a * b - 1 (mod 2^64): the accumulator starts from the inline constant -1 (mulc below)
+        template <bool SB> __device__ __forceinline__ uint64_t mad32m1(uint32_t a, uint32_t b)
+        {
+            uint64_t d, cy;
+            if constexpr (SB)
+                asm("v_mad_u64_u32 %0, %1, %2, %3, -1" : "=v"(d), "=s"(cy) : "v"(a), "s"(b));
+            else
+                asm("v_mad_u64_u32 %0, %1, %2, %3, -1" : "=v"(d), "=s"(cy) : "v"(a), "v"(b));
+            return d;
+        }
+        // ~w + u  =  u - w - 1 (mod 2^32) as ONE instruction, v_xad_u32 (w ^ -1) + u: the sum u + v of a value u and the
+        // COMPLEMENT w = ~v of a value v
+        // (plain C: the compiler selects v_xad_u32 for it, and an asm statement costs an s_nop of the hazard recogniser)
+        __device__ __forceinline__ uint32_t xad_not(uint32_t w, uint32_t u) { return (w ^ 0xffffffffu) + u; }
+
         // ---- 64-bit: sloppy-quotient Shoup product in [0, 4q); LIMIT 16 needs q < 2^60, LIMIT 8 q < 2^61 ------
         template <int LIM, bool VQ = false> struct Mod64
         {
@@ -311,6 +326,20 @@ namespace gpuntt
             {
                 const uint32_t qh = __umulhi(x, t.wp);
                 return lo32(mad32<!VQ>(qh, qneg, mad32z<UNI>(x, t.w)));
+            }
+            // The COMPLEMENT ~r of the product r = x * w (mod q) + {0, 1} q, for the same three instructions: with
+            // wneg = 2^32 - w,  qh * q + (x * wneg - 1)  =  -(x * w - qh * q) - 1  (mod 2^32).  A Gentleman-Sande butterfly
+            // whose second operand arrives complemented is two instructions instead of three (merge_e32_kernels.hpp).
+            template <bool UNI = false> __device__ __forceinline__ uint32_t mulc(uint32_t x, uint32_t wneg, uint32_t wp) const
+            {
+                const uint32_t qh = __umulhi(x, wp);
+                return lo32(mad32<!VQ>(qh, q, mad32m1<UNI>(x, wneg)));
+            }
+            // the conditional subtraction of k q on a complemented value: ~min(v, v - kq) = max(~v, ~v + kq)
+            template <int K> __device__ __forceinline__ uint32_t csub_c(uint32_t w) const
+            {
+                const uint32_t d = w + kq(K);
+                return d > w ? d : w;
             }
             // acc + T, T = x * w (mod q) + {0, 1} q
             template <bool UNI, bool ZERO = false>

@@ -249,7 +249,12 @@ namespace gpuntt
                     const unsigned g = ((tu >> 6) << 1) + h;
                     // slot of stage p = 9 - s_: sbase(p) + (g << s_) + k, with sbase(p) = 2^(n - 10 + s_) + (tip << (TLOG - 10 + s_))
                     const unsigned slot = (1u << (n - 10 + s_)) + (tip << (TLOG - 10 + s_)) + (g << s_) + k;
-                    twb_area[l] = tw_pair(slot << 3, 0u);
+                    TW pr = tw_pair(slot << 3, 0u);
+                    // inverse: the odd twiddles of every stage but the round's last feed butterflies whose outputs leave
+                    // complemented (gs below), which multiply by the NEGATED twiddle -- negated here, once per tile
+                    if (INV && s_ >= 1u && (k & 1u) != 0u)
+                        pr.w = 0u - pr.w;
+                    twb_area[l] = pr;
                 }
             };
             // the 2^s pairs of stage s for this lane's half-wave
@@ -454,28 +459,60 @@ namespace gpuntt
                         v[4 * k + 3] = x.w;
                     }
                 }
-                auto gs = [&](auto r_, auto s_, auto h_, auto uni_, auto last_, T& u, T& x, const TW& w) {
+                // Gentleman-Sande butterfly  (U, V) -> (U + V, (U + c q - V) w)  with the SECOND operand of every stage but a
+                // round's first arriving COMPLEMENTED (W = ~V): then the sum is one v_xad_u32 ((W ^ -1) + U) or, where the
+                // next stage wants it complemented, one v_sub (W - U = ~(U + V)); the difference is one v_add3 (U + W +
+                // (c q + 1)); and the product comes out complemented for the same three instructions (Mod32::mulc: the
+                // twiddle negated, the accumulator started from -1).  Which form a register holds is a compile-time fact:
+                // a stage's outputs are complemented iff the next stage of the round uses them as second operands (VC / OC
+                // below); a round starts and ends with plain values (the exchanges and the stores see nothing of this).
+                // 5 instructions per butterfly instead of 6, like the forward one.
+                auto gs = [&](auto r_, auto s_, auto h_, auto uni_, auto last_, auto vc_, auto oc_, T& u, T& x, const TW& w) {
                     constexpr int r = decltype(r_)::value, s = decltype(s_)::value, h = decltype(h_)::value;
+                    constexpr bool NEGATED = (r == 1); // round B: stage_twb() stored the negated twiddle where OC holds
                     constexpr bool UNI = decltype(uni_)::value, LASTST = decltype(last_)::value;
+                    constexpr bool VC = decltype(vc_)::value, OC = decltype(oc_)::value;
                     constexpr int ku = SCH::d.ku[r][s][h], kv = SCH::d.kv[r][s][h], c = SCH::d.c[r][s][h];
                     T U = u, V = x;
                     if constexpr (ku != 0)
                         U = m.template csub<ku>(U);
                     if constexpr (kv != 0)
-                        V = m.template csub<kv>(V);
+                    {
+                        if constexpr (VC)
+                            V = m.template csub_c<kv>(V);
+                        else
+                            V = m.template csub<kv>(V);
+                    }
                     if constexpr (LASTST)
-                        u = m.template mul<true>(U + V, ninv); // the last twiddle was prepared as w * n^-1
+                    {
+                        const T S = VC ? lazy::xad_not(V, U) : static_cast<T>(U + V);
+                        u = m.template mul<true>(S, ninv); // the last twiddle was prepared as w * n^-1
+                    }
                     else
                     {
                         constexpr int ko = SCH::d.ko[r][s][h];
-                        T S = U + V;
-                        if constexpr (ko > 0)
-                            S = m.template csub<ko>(S);
-                        if constexpr (ko < 0)
-                            S = m.reduce_2q(S);
-                        u = S;
+                        if constexpr (!OC || ko < 0)
+                        {
+                            T S = VC ? lazy::xad_not(V, U) : static_cast<T>(U + V);
+                            if constexpr (ko > 0)
+                                S = m.template csub<ko>(S);
+                            if constexpr (ko < 0)
+                                S = m.reduce_2q(S);
+                            u = OC ? static_cast<T>(~S) : S;
+                        }
+                        else
+                        {
+                            T Sc = VC ? static_cast<T>(V - U) : static_cast<T>(~(U + V));
+                            if constexpr (ko > 0)
+                                Sc = m.template csub_c<ko>(Sc);
+                            u = Sc;
+                        }
                     }
-                    x = m.template mul<UNI>(U + m.kq(c) - V, w);
+                    const T D = VC ? static_cast<T>(U + V + (m.kq(c) + 1u)) : static_cast<T>(U + m.kq(c) - V);
+                    if constexpr (OC)
+                        x = m.template mulc<UNI>(D, NEGATED ? w.w : static_cast<T>(0u - w.w), w.wp);
+                    else
+                        x = m.template mul<UNI>(D, w);
                 };
                 // ---- round C: stages 0 .. 4 ---------------------------------------------------------------------------
                 static_for<R5>([&](auto s_) {
@@ -485,8 +522,10 @@ namespace gpuntt
                         constexpr int h = decltype(h_)::value;
                         constexpr int j0 = (h & ((1 << jb) - 1)) | ((h >> jb) << (jb + 1));
                         constexpr int j1 = j0 | (1 << jb);
-                        gs(std::integral_constant<int, 0>{}, s_, h_, std::false_type{}, std::false_type{}, v[j0], v[j1],
-                           twv[(1 << (4 - s)) - 1 + (j0 >> (jb + 1))]);
+                        constexpr int kk = j0 >> (jb + 1);
+                        gs(std::integral_constant<int, 0>{}, s_, h_, std::false_type{}, std::false_type{},
+                           std::integral_constant<bool, (s > 0)>{}, std::integral_constant<bool, (s < R5 - 1) && (kk & 1)>{},
+                           v[j0], v[j1], twv[(1 << (4 - s)) - 1 + kk]);
                     });
                 });
                 {
@@ -512,8 +551,10 @@ namespace gpuntt
                         constexpr int h = decltype(h_)::value;
                         constexpr int j0 = (h & ((1 << jb) - 1)) | ((h >> jb) << (jb + 1));
                         constexpr int j1 = j0 | (1 << jb);
-                        gs(std::integral_constant<int, 1>{}, s_, h_, std::false_type{}, std::false_type{}, v[j0], v[j1],
-                           wb[j0 >> (jb + 1)]);
+                        constexpr int kk = j0 >> (jb + 1);
+                        gs(std::integral_constant<int, 1>{}, s_, h_, std::false_type{}, std::false_type{},
+                           std::integral_constant<bool, (s > 0)>{}, std::integral_constant<bool, (s < R5 - 1) && (kk & 1)>{},
+                           v[j0], v[j1], wb[kk]);
                     });
                 });
                 {
@@ -538,23 +579,32 @@ namespace gpuntt
                         constexpr int h = decltype(h_)::value;
                         constexpr int j0 = (h & ((1 << jb) - 1)) | ((h >> jb) << (jb + 1));
                         constexpr int j1 = j0 | (1 << jb);
-                        const TW w = tw[sbase(p) + (j0 >> (jb + 1))];
+                        constexpr int kk = j0 >> (jb + 1);
+                        const TW w = tw[sbase(p) + kk];
                         gs(std::integral_constant<int, 2>{}, s_, h_, std::true_type{},
-                           std::integral_constant<bool, LAST && s == NA - 1>{}, v[j0], v[j1], w);
+                           std::integral_constant<bool, LAST && s == NA - 1>{}, std::integral_constant<bool, (s > 0)>{},
+                           std::integral_constant<bool, (s < NA - 1) && (kk & 1)>{}, v[j0], v[j1], w);
                     });
                 });
-                const bool centred = LAST && (a.flags & F_CENTERED) != 0u;
-                static_for<E32>([&](auto j_) {
-                    constexpr int j = decltype(j_)::value;
-                    T x = v[j]; // PART: lazy hand-over, below LIMIT / 2 (sums corrected to it, products below 2 q)
-                    if constexpr (LAST)
-                    {
-                        x = lazy::normalize<M::TB>(m, x);
-                        if (centred)
-                            x = (x > (m.q >> 1)) ? (x - m.q) : x;
-                    }
-                    __builtin_amdgcn_raw_buffer_store_b32(x, rdst, static_cast<int>(tu << 2), j << (WLA + 2), POL_OUT);
-                });
+                // (signed callers, GPU_INTT<Data32s>: a BRANCH on the block-uniform flag -- as a select the centring costs
+                // every caller four instructions per coefficient beside the two of the normalisation)
+                auto store_all = [&](auto centred_) {
+                    static_for<E32>([&](auto j_) {
+                        constexpr int j = decltype(j_)::value;
+                        T x = v[j]; // PART: lazy hand-over, below LIMIT / 2 (sums corrected to it, products below 2 q)
+                        if constexpr (LAST)
+                        {
+                            x = lazy::normalize<M::TB>(m, x);
+                            if constexpr (decltype(centred_)::value)
+                                x = (x > (m.q >> 1)) ? (x - m.q) : x;
+                        }
+                        __builtin_amdgcn_raw_buffer_store_b32(x, rdst, static_cast<int>(tu << 2), j << (WLA + 2), POL_OUT);
+                    });
+                };
+                if (LAST && __builtin_amdgcn_readfirstlane(a.flags & F_CENTERED) != 0u)
+                    store_all(std::true_type{});
+                else
+                    store_all(std::false_type{});
             }
         }
     } // namespace kern

@@ -917,21 +917,27 @@ namespace gpuntt
                                 v[j] = lazy::normalize<SCH::d.bout[r][j], false>(m, v[j]);
                             });
                     }
+                    else if constexpr (LAST && INV)
+                    {
+                        // (signed callers, GPU_INTT<Data64s>: a BRANCH on the block-uniform flag -- as a select the centring
+                        // costs every caller a compare, a select and a subtraction per coefficient)
+                        if (__builtin_amdgcn_readfirstlane(a.flags & F_CENTERED) != 0u)
+                            static_for<EPT>([&](auto j_) {
+                                constexpr int j = decltype(j_)::value;
+                                const T x = lazy::normalize<M::TB>(m, v[j]); // n^-1 went in with the last stage
+                                v[j] = (x > (m.q >> 1)) ? (x - m.q) : x;
+                            });
+                        else
+                            static_for<EPT>([&](auto j_) {
+                                constexpr int j = decltype(j_)::value;
+                                v[j] = lazy::normalize<M::TB>(m, v[j]);
+                            });
+                    }
                     else if constexpr (LAST)
                     {
                         static_for<EPT>([&](auto j_) {
                             constexpr int j = decltype(j_)::value;
-                            if constexpr (INV)
-                            {
-                                T x = lazy::normalize<M::TB>(m, v[j]); // n^-1 went in with the last stage
-                                if (a.flags & F_CENTERED)
-                                    x = (x > (m.q >> 1)) ? (x - m.q) : x;
-                                v[j] = x;
-                            }
-                            else
-                            {
-                                v[j] = lazy::normalize<SCH::d.bout[r][j]>(m, v[j]);
-                            }
+                            v[j] = lazy::normalize<SCH::d.bout[r][j]>(m, v[j]);
                         });
                     }
                     if constexpr (XP == Xp::small_inv)

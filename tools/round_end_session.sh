@@ -25,8 +25,11 @@ for cfg in c2 c3 c4; do
 done
 mv "$O/c2_kernel_stats.txt" "$O/bench_kernel_stats.txt"
 # SQ counters of the two headline-class kernels on this library
-bash tools/pmc_sq.sh "${1:-gpurun_out/round_end}/pmc_c2" c2 5 2>&1 | sed "s|gpurun_out/||" > "$O/pmc_c2.txt"; rm -rf "$O/pmc_c2" "$O"/pmc_c2.p*.log
-bash tools/pmc_sq.sh "${1:-gpurun_out/round_end}/pmc_c4" c4full 5 2>&1 > "$O/pmc_c4.txt"; rm -rf "$O/pmc_c4" "$O"/pmc_c4.p*.log
+# (tools/pmc_sq.sh takes its output name relative to gpurun_out/)
+REL="${1:-gpurun_out/round_end}"; REL="${REL#gpurun_out/}"
+{ sha256sum gpu-ntt_amd/lib/libgpuntt.so | sed 's/^/# library sha256 /'; bash tools/pmc_sq.sh "$REL/pmc_c2" c2 5 2>&1; } > "$O/pmc_c2.txt"; rm -rf "$O/pmc_c2" "$O"/pmc_c2.p*.log
+{ sha256sum gpu-ntt_amd/lib/libgpuntt.so | sed 's/^/# library sha256 /'; bash tools/pmc_sq.sh "$REL/pmc_c4" c4full 5 2>&1; } > "$O/pmc_c4.txt"; rm -rf "$O/pmc_c4" "$O"/pmc_c4.p*.log
+{ sha256sum gpu-ntt_amd/lib/libgpuntt.so | sed 's/^/# library sha256 /'; bash tools/pmc_sq.sh "$REL/pmc_c4i" merge:32:14:8192:inv 5 2>&1; } > "$O/pmc_c4i.txt"; rm -rf "$O/pmc_c4i" "$O"/pmc_c4i.p*.log
 # north_star's table: every ring 2^12 .. 2^24, both algorithms, both word sizes, both directions
 python bench.py --sweep --sweep-bits 64 > "$O/sweep_u64.jsonl" 2> "$O/sweep_u64.err"
 python bench.py --sweep --sweep-bits 32 > "$O/sweep_u32.jsonl" 2> "$O/sweep_u32.err"
