@@ -109,9 +109,9 @@ namespace gpuntt
 
         // Library-owned scratch for the prepared twiddles of the drop-in calls: one chain of buffers per (device, stream)
         // for eager calls, one per (device, stream, capture) for calls made while the stream is being captured into a
-        // hipGraph; stream-ordered reuse inside a chain.  A buffer is never freed or synchronised on before
-        // GPU_NTT_ReleaseWorkspaces(): growth allocates a new buffer and retires the old one, because kernels already
-        // enqueued -- or captured into a graph that is replayed later -- still read it (prep.hip).
+        // hipGraph; stream-ordered reuse inside a chain.  A buffer is never freed or synchronised on while anything can
+        // still read it: growth allocates a new buffer and retires the old one; an eager chain's buffers live until
+        // GPU_NTT_ReleaseWorkspaces(), a capture chain's belong to the captured graph and are pooled when it dies (prep.hip).
         // Inside a WorkspaceScope (every public entry point opens one) the calling thread keeps the chain's lock until
         // the scope ends, i.e. from the preparation launch to the last kernel launch of the call: two host threads on
         // one stream cannot interleave A.prep, B.prep, A.kernels.
